@@ -1,0 +1,108 @@
+/*
+ * oracle/ -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (plonky2-merkle-trees_amd/, include/) never links, imports or calls it.
+ *
+ * What it restates (reference = /root/reference, hashcloak/plonky2-merkle-trees):
+ *   - src/simple_merkle_tree/simple_merkle_tree.rs:18-109  (MerkleTree, verify_merkle_proof)
+ *   - src/mmr/merkle_mountain_ranges.rs:39-270             (MMR, MMR_proof, index maths)
+ * and the third-party arithmetic those call (NOT in /root/reference, un-vendored deps):
+ *   - plonky2 git rev 3b21b87d0ab3f8ef4b9ff0b9dd70f8e32f5573f4: PoseidonHash
+ *     (hash/poseidon.rs, hash/hashing.rs), MerkleTree/MerkleCap (hash/merkle_tree.rs),
+ *     PolynomialBatch (fri/oracle.rs)
+ *   - plonky2_field 0.1.0: GoldilocksField, fft.rs
+ *   restated from their published algorithm.
+ *
+ * Parity pinning:
+ *   PINNED   Poseidon permutation, two_to_one, no-op leaf hash, tree build, Merkle path:
+ *            every golden value the reference holds (simple_merkle_tree.rs:136-140,
+ *            :181-190, :210-211) and the 32 index-table rows (merkle_mountain_ranges.rs:280-327)
+ *            are checked in tests/test_oracle_golden.py.
+ *   UNPINNED ("parity unpinned") sponge with >8 inputs, FFT/LDE/Merkle-cap conventions:
+ *            the reference holds no vector for them; they follow plonky2's published
+ *            conventions from recall and are checked only
+ *            through mathematical identities (IFFT.FFT = id, LDE == direct evaluation).
+ *
+ * All values crossing this API are canonical Goldilocks elements (< p) as little-endian u64;
+ * a HashOut is 4 consecutive u64.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_GOLDILOCKS_P 0xFFFFFFFF00000001ULL /* src/mmr/common.rs:3 */
+
+/* ---- field (plonky2_field::goldilocks_field) ---- */
+uint64_t oracle_gl_add(uint64_t a, uint64_t b);
+uint64_t oracle_gl_sub(uint64_t a, uint64_t b);
+uint64_t oracle_gl_mul(uint64_t a, uint64_t b);
+uint64_t oracle_gl_pow(uint64_t a, uint64_t e);
+uint64_t oracle_gl_inv(uint64_t a);
+uint64_t oracle_gl_primitive_root_of_unity(unsigned log_n);
+
+/* ---- Poseidon (plonky2::hash::poseidon, hashing) ---- */
+void oracle_poseidon_permute(uint64_t state[12]);
+void oracle_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+void oracle_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);
+void oracle_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);
+
+/* ---- simple_merkle_tree.rs ---- */
+/* levels_out: level-major, level i has n>>i HashOuts, levels 0..k-1 => (2n-2) HashOuts.
+ * Returns count_levels (= log2 n), or -1 where the reference panics (n not a power of two, n < 2). */
+int oracle_merkle_build(const uint64_t *leaves, size_t n, uint64_t *levels_out, uint64_t root[4]);
+int oracle_merkle_get_proof(const uint64_t *levels, size_t n, size_t leaf_index, uint64_t *proof_out);
+int oracle_merkle_get_in_between_hashes(const uint64_t *levels, const uint64_t root[4], size_t n,
+                                        size_t leaf_index, uint64_t *out);
+int oracle_verify_merkle_proof(uint64_t leaf, size_t leaf_index, const uint64_t root[4],
+                               const uint64_t *hashes, size_t n_hashes);
+
+/* ---- merkle_mountain_ranges.rs ---- */
+typedef struct oracle_mmr oracle_mmr;
+uint64_t oracle_get_heights_bitmap_for_mmr_size(size_t mmr_size, size_t *remainder);
+size_t oracle_get_mmr_index(size_t leaf_normal_index);
+oracle_mmr *oracle_mmr_new(void);
+void oracle_mmr_free(oracle_mmr *m);
+void oracle_mmr_add_leaf(oracle_mmr *m, uint64_t leaf);
+void oracle_mmr_add_leaves(oracle_mmr *m, const uint64_t *leaves, size_t n); /* for leaf { add_leaf } */
+size_t oracle_mmr_len(const oracle_mmr *m);
+const uint64_t *oracle_mmr_elements(const oracle_mmr *m);
+/* returns number of peaks, -1 where the reference panics (empty MMR / len >= 2^32) */
+int oracle_mmr_get_peaks(const oracle_mmr *m, uint64_t *peaks_out);
+int oracle_mmr_bagging_the_peaks(const oracle_mmr *m, uint64_t root[4]);
+/* siblings_out: up to 64 HashOuts, lefts_out: up to 64 bytes. Returns n siblings or -1 (index OOB). */
+int oracle_mmr_get_subtree_proof_elm(const oracle_mmr *m, size_t mmr_index, uint64_t *siblings_out,
+                                     uint8_t *lefts_out);
+int oracle_mmr_get_proof(const oracle_mmr *m, size_t mmr_index, uint64_t *siblings_out,
+                         uint8_t *lefts_out, int *n_siblings, uint64_t *peaks_out, int *n_peaks,
+                         size_t *mmr_size);
+/* 1 = true, 0 = false, -1 = the reference's assert!(peaks.contains(..)) panics (:245) */
+int oracle_mmr_proof_verify(const uint64_t *siblings, const uint8_t *lefts, int n_siblings,
+                            const uint64_t *peaks, int n_peaks, uint64_t leaf, const uint64_t root[4]);
+
+/* ---- plonky2_field fft.rs / plonky2 fri/oracle.rs + hash/merkle_tree.rs  [parity unpinned] ---- */
+void oracle_fft(uint64_t *a, unsigned log_n);  /* natural order in/out: out[i] = f(w^i) */
+void oracle_ifft(uint64_t *a, unsigned log_n); /* inverse of the above */
+/* out[i] = f(shift * w_{n*2^rate_bits}^i), i in natural order; out has n << rate_bits entries */
+void oracle_coset_lde(const uint64_t *coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                      uint64_t *out);
+/* Merkle tree over n leaves of `width` elements (row-major n x width), n = 2^k, cap_height <= k.
+ * digests_out: level-major (level 0 = leaf digests, n HashOuts; level j has n>>j), levels 0 .. k-cap_height-1;
+ * cap_out: 2^cap_height HashOuts (the level k-cap_height row). */
+int oracle_merkle_cap_commit(const uint64_t *leaves, size_t n, size_t width, unsigned cap_height,
+                             uint64_t *digests_out, uint64_t *cap_out);
+/* PolynomialBatch::from_coeffs / from_values: polys row-major n_polys x 2^log_n.
+ * leaves_out: (n<<rate_bits) x n_polys row-major, leaf index bit-reversed (leaf[brev(i)] = all polys at point i). */
+int oracle_polynomial_batch_commit(const uint64_t *polys, int is_values, size_t n_polys, unsigned log_n,
+                                   unsigned rate_bits, unsigned cap_height, uint64_t *leaves_out,
+                                   uint64_t *digests_out, uint64_t *cap_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,272 @@
+"""ctypes binding of oracle/liboracle.so (the CPU restatement; TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+P = 0xFFFFFFFF00000001
+
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build_oracle(force=False):
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _arr(x, shape=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = lib = C.CDLL(build_oracle())
+        lib.oracle_gl_add.restype = lib.oracle_gl_sub.restype = lib.oracle_gl_mul.restype = C.c_uint64
+        lib.oracle_gl_pow.restype = lib.oracle_gl_inv.restype = C.c_uint64
+        lib.oracle_gl_primitive_root_of_unity.restype = C.c_uint64
+        for f in (lib.oracle_gl_add, lib.oracle_gl_sub, lib.oracle_gl_mul, lib.oracle_gl_pow):
+            f.argtypes = [C.c_uint64, C.c_uint64]
+        lib.oracle_gl_inv.argtypes = [C.c_uint64]
+        lib.oracle_gl_primitive_root_of_unity.argtypes = [C.c_uint]
+        lib.oracle_poseidon_permute.argtypes = [_u64p]
+        lib.oracle_two_to_one.argtypes = [_u64p, _u64p, _u64p]
+        lib.oracle_hash_no_pad.argtypes = [_u64p, C.c_size_t, _u64p]
+        lib.oracle_hash_or_noop.argtypes = [_u64p, C.c_size_t, _u64p]
+        lib.oracle_merkle_build.argtypes = [_u64p, C.c_size_t, _u64p, _u64p]
+        lib.oracle_merkle_get_proof.argtypes = [_u64p, C.c_size_t, C.c_size_t, _u64p]
+        lib.oracle_merkle_get_in_between_hashes.argtypes = [_u64p, _u64p, C.c_size_t, C.c_size_t, _u64p]
+        lib.oracle_verify_merkle_proof.argtypes = [C.c_uint64, C.c_size_t, _u64p, _u64p, C.c_size_t]
+        lib.oracle_get_heights_bitmap_for_mmr_size.argtypes = [C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.oracle_get_heights_bitmap_for_mmr_size.restype = C.c_uint64
+        lib.oracle_get_mmr_index.argtypes = [C.c_size_t]
+        lib.oracle_get_mmr_index.restype = C.c_size_t
+        lib.oracle_mmr_new.restype = C.c_void_p
+        lib.oracle_mmr_free.argtypes = [C.c_void_p]
+        lib.oracle_mmr_add_leaf.argtypes = [C.c_void_p, C.c_uint64]
+        lib.oracle_mmr_add_leaves.argtypes = [C.c_void_p, _u64p, C.c_size_t]
+        lib.oracle_mmr_len.argtypes = [C.c_void_p]
+        lib.oracle_mmr_len.restype = C.c_size_t
+        lib.oracle_mmr_elements.argtypes = [C.c_void_p]
+        lib.oracle_mmr_elements.restype = _u64p
+        lib.oracle_mmr_get_peaks.argtypes = [C.c_void_p, _u64p]
+        lib.oracle_mmr_bagging_the_peaks.argtypes = [C.c_void_p, _u64p]
+        lib.oracle_mmr_get_subtree_proof_elm.argtypes = [C.c_void_p, C.c_size_t, _u64p, _u8p]
+        lib.oracle_mmr_get_proof.argtypes = [C.c_void_p, C.c_size_t, _u64p, _u8p, C.POINTER(C.c_int), _u64p,
+                                             C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        lib.oracle_mmr_proof_verify.argtypes = [_u64p, _u8p, C.c_int, _u64p, C.c_int, C.c_uint64, _u64p]
+        lib.oracle_fft.argtypes = [_u64p, C.c_uint]
+        lib.oracle_ifft.argtypes = [_u64p, C.c_uint]
+        lib.oracle_coset_lde.argtypes = [_u64p, C.c_uint, C.c_uint, C.c_uint64, _u64p]
+        lib.oracle_merkle_cap_commit.argtypes = [_u64p, C.c_size_t, C.c_size_t, C.c_uint, _u64p, _u64p]
+        lib.oracle_polynomial_batch_commit.argtypes = [_u64p, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint,
+                                                       _u64p, _u64p, _u64p]
+
+    # ---- field
+    def mul(self, a, b): return self.lib.oracle_gl_mul(a, b)
+    def add(self, a, b): return self.lib.oracle_gl_add(a, b)
+    def sub(self, a, b): return self.lib.oracle_gl_sub(a, b)
+    def pow(self, a, e): return self.lib.oracle_gl_pow(a, e)
+    def inv(self, a): return self.lib.oracle_gl_inv(a)
+    def root_of_unity(self, log_n): return self.lib.oracle_gl_primitive_root_of_unity(log_n)
+
+    # ---- poseidon
+    def permute(self, state):
+        s = _arr(state).copy()
+        assert s.size == 12
+        self.lib.oracle_poseidon_permute(_ptr(s))
+        return s
+
+    def permute_batch(self, states):
+        s = _arr(states).reshape(-1, 12).copy()
+        for row in s:
+            self.lib.oracle_poseidon_permute(_ptr(row))
+        return s
+
+    def two_to_one(self, l, r):
+        l, r, out = _arr(l), _arr(r), np.zeros(4, np.uint64)
+        self.lib.oracle_two_to_one(_ptr(l), _ptr(r), _ptr(out))
+        return out
+
+    def hash_no_pad(self, x):
+        x, out = _arr(x), np.zeros(4, np.uint64)
+        self.lib.oracle_hash_no_pad(_ptr(x), x.size, _ptr(out))
+        return out
+
+    def hash_or_noop(self, x):
+        x, out = _arr(x), np.zeros(4, np.uint64)
+        self.lib.oracle_hash_or_noop(_ptr(x), x.size, _ptr(out))
+        return out
+
+    # ---- simple merkle tree
+    def merkle_build(self, leaves):
+        leaves = _arr(leaves)
+        n = leaves.size
+        levels = np.zeros((max(2 * n - 2, 1), 4), np.uint64)
+        root = np.zeros(4, np.uint64)
+        k = self.lib.oracle_merkle_build(_ptr(leaves), n, _ptr(levels), _ptr(root))
+        if k < 0:
+            raise ValueError("reference panics: leaf count must be a power of two >= 2")
+        return k, levels, root
+
+    def merkle_get_proof(self, levels, n, idx):
+        k = n.bit_length() - 1
+        out = np.zeros((k, 4), np.uint64)
+        rc = self.lib.oracle_merkle_get_proof(_ptr(levels), n, idx, _ptr(out))
+        if rc < 0:
+            raise IndexError("reference asserts leaf_index < n")
+        return out
+
+    def merkle_get_in_between_hashes(self, levels, root, n, idx):
+        k = n.bit_length() - 1
+        out = np.zeros((k, 4), np.uint64)
+        root = _arr(root)
+        rc = self.lib.oracle_merkle_get_in_between_hashes(_ptr(levels), _ptr(root), n, idx, _ptr(out))
+        if rc < 0:
+            raise IndexError("reference asserts leaf_index < n")
+        return out[:rc]
+
+    def verify_merkle_proof(self, leaf, idx, root, hashes):
+        root, hashes = _arr(root), _arr(hashes).reshape(-1, 4)
+        return bool(self.lib.oracle_verify_merkle_proof(int(leaf), idx, _ptr(root), _ptr(hashes), hashes.shape[0]))
+
+    # ---- mmr
+    def heights_bitmap(self, size):
+        rem = C.c_size_t(0)
+        bm = self.lib.oracle_get_heights_bitmap_for_mmr_size(size, C.byref(rem))
+        return bm, rem.value
+
+    def get_mmr_index(self, n): return self.lib.oracle_get_mmr_index(n)
+
+    def mmr(self, leaves=None):
+        return OracleMMR(self, leaves)
+
+    def mmr_proof_verify(self, siblings, lefts, peaks, leaf, root):
+        sib = _arr(siblings).reshape(-1, 4)
+        lf = np.ascontiguousarray(np.asarray(lefts, dtype=np.uint8))
+        pk = _arr(peaks).reshape(-1, 4)
+        root = _arr(root)
+        rc = self.lib.oracle_mmr_proof_verify(_ptr(sib), lf.ctypes.data_as(_u8p), sib.shape[0], _ptr(pk),
+                                              pk.shape[0], int(leaf), _ptr(root))
+        if rc < 0:
+            raise AssertionError("reference panics: assert!(self.peaks.contains(&next_hash))")
+        return bool(rc)
+
+    # ---- fft / commit
+    def fft(self, a):
+        a = _arr(a).copy()
+        self.lib.oracle_fft(_ptr(a), a.size.bit_length() - 1)
+        return a
+
+    def ifft(self, a):
+        a = _arr(a).copy()
+        self.lib.oracle_ifft(_ptr(a), a.size.bit_length() - 1)
+        return a
+
+    def coset_lde(self, coeffs, rate_bits, shift=7):
+        c = _arr(coeffs)
+        out = np.zeros(c.size << rate_bits, np.uint64)
+        self.lib.oracle_coset_lde(_ptr(c), c.size.bit_length() - 1, rate_bits, shift, _ptr(out))
+        return out
+
+    def merkle_cap_commit(self, leaves, cap_height):
+        leaves = _arr(leaves)
+        n, w = leaves.shape
+        k = n.bit_length() - 1
+        n_dig = sum(n >> j for j in range(k - cap_height))
+        digests = np.zeros((max(n_dig, 1), 4), np.uint64)
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        rc = self.lib.oracle_merkle_cap_commit(_ptr(leaves), n, w, cap_height, _ptr(digests), _ptr(cap))
+        if rc < 0:
+            raise ValueError("bad merkle_cap_commit shape")
+        return digests[:n_dig], cap
+
+    def polynomial_batch_commit(self, polys, is_values, rate_bits=3, cap_height=4):
+        polys = _arr(polys)
+        n_polys, n = polys.shape
+        log_n = n.bit_length() - 1
+        big = n << rate_bits
+        k = log_n + rate_bits
+        leaves = np.zeros((big, n_polys), np.uint64)
+        n_dig = sum(big >> j for j in range(k - cap_height))
+        digests = np.zeros((max(n_dig, 1), 4), np.uint64)
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        rc = self.lib.oracle_polynomial_batch_commit(_ptr(polys), int(bool(is_values)), n_polys, log_n, rate_bits,
+                                                     cap_height, _ptr(leaves), _ptr(digests), _ptr(cap))
+        if rc < 0:
+            raise ValueError("bad polynomial_batch_commit shape")
+        return leaves, digests[:n_dig], cap
+
+
+class OracleMMR:
+    def __init__(self, oracle, leaves=None):
+        self.o = oracle
+        self.h = oracle.lib.oracle_mmr_new()
+        if leaves is not None:
+            self.add_leaves(leaves)
+
+    def __del__(self):
+        try:
+            self.o.lib.oracle_mmr_free(self.h)
+        except Exception:
+            pass
+
+    def add_leaf(self, leaf): self.o.lib.oracle_mmr_add_leaf(self.h, int(leaf))
+
+    def add_leaves(self, leaves):
+        leaves = _arr(leaves)
+        self.o.lib.oracle_mmr_add_leaves(self.h, _ptr(leaves), leaves.size)
+
+    def __len__(self): return self.o.lib.oracle_mmr_len(self.h)
+
+    @property
+    def elements(self):
+        n = len(self)
+        if n == 0:
+            return np.zeros((0, 4), np.uint64)
+        p = self.o.lib.oracle_mmr_elements(self.h)
+        return np.ctypeslib.as_array(p, shape=(n * 4,)).reshape(n, 4).copy()
+
+    def get_peaks(self):
+        out = np.zeros((64, 4), np.uint64)
+        n = self.o.lib.oracle_mmr_get_peaks(self.h, _ptr(out))
+        if n < 0:
+            raise OverflowError("reference panics in get_peaks (empty MMR or len >= 2^32)")
+        return out[:n].copy()
+
+    def bagging_the_peaks(self):
+        out = np.zeros(4, np.uint64)
+        if self.o.lib.oracle_mmr_bagging_the_peaks(self.h, _ptr(out)) < 0:
+            raise OverflowError("reference panics in get_peaks (empty MMR or len >= 2^32)")
+        return out
+
+    def get_proof(self, mmr_index):
+        sib = np.zeros((64, 4), np.uint64)
+        lefts = np.zeros(64, np.uint8)
+        peaks = np.zeros((64, 4), np.uint64)
+        ns, npk, sz = C.c_int(0), C.c_int(0), C.c_size_t(0)
+        rc = self.o.lib.oracle_mmr_get_proof(self.h, mmr_index, _ptr(sib), lefts.ctypes.data_as(_u8p), C.byref(ns),
+                                             _ptr(peaks), C.byref(npk), C.byref(sz))
+        if rc < 0:
+            raise IndexError("reference panics: index out of bounds")
+        return {"mmr_size": sz.value, "siblings": sib[:ns.value].copy(), "lefts": lefts[:ns.value].copy(),
+                "peaks": peaks[:npk.value].copy()}
+
+    def get_proof_normal_index(self, normal_index):
+        return self.get_proof(self.o.get_mmr_index(normal_index))
