@@ -1,0 +1,173 @@
+/*
+ * p2mt.h -- C ABI of the MI355X-native Poseidon/Goldilocks Merkle + MMR + commit library
+ *           (libp2mt_hip.so, built from plonky2-merkle-trees_amd/csrc/).
+ *
+ * This is the drop-in boundary for the hot path of hashcloak/plonky2-merkle-trees.
+ * The reference has no FFI of its own: its hot path is reached through its public Rust API and,
+ * below that, plonky2's per-hash `Hasher` trait, which is useless as a GPU boundary (one hash per
+ * call).  The boundary is therefore one level up and batch-shaped; every entry point names the
+ * reference interface (file:line under /root/reference) it replaces.  INTEGRATION.md shows the Rust
+ * `extern "C"` block + shim a maintainer would add.
+ *
+ * Conventions
+ *   - GoldilocksField = u64 (little-endian host order).  Inputs may be non-canonical (>= p);
+ *     every output is canonical (< p = 0xFFFFFFFF00000001).
+ *   - HashOut = 4 consecutive u64 (32-byte record); Vec<HashOut> = contiguous records.
+ *   - Every function returns 0 on success or a negative p2mt_status; the reference's convention is
+ *     panic (assert!/unwrap/log2_strict), the shim maps non-zero to panic!.  No exceptions cross.
+ *   - Host-pointer entry points copy in/out synchronously.  `_dev` entry points take pointers to
+ *     device memory (hipMalloc / torch tensors), enqueue on the library stream and do not
+ *     synchronise unless they return host-visible results.
+ *   - Caller owns every buffer; device-resident state lives only behind opaque handles.
+ *   - A handle is not thread-safe; distinct handles are independent.
+ *   - All hashing runs on the GPU.  There is no CPU fallback: without a HIP device every compute
+ *     entry point returns P2MT_EHIP.
+ */
+#ifndef P2MT_H
+#define P2MT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum p2mt_status {
+  P2MT_OK = 0,
+  P2MT_EINVAL = -1,   /* bad size / index: where the reference panics (log2_strict, assert!, index OOB) */
+  P2MT_ENOMEM = -2,   /* host or device allocation failed */
+  P2MT_EHIP = -3,     /* HIP runtime error or no device; see p2mt_last_error() */
+  P2MT_ERANGE = -4,   /* size limits of the reference: len >= 2^32 (merkle_mountain_ranges.rs:184), n >= 2^30 (:264) */
+  P2MT_ENOTPEAK = -5  /* MMR_proof::verify: assert!(self.peaks.contains(&next_hash)) (merkle_mountain_ranges.rs:245) */
+} p2mt_status;
+
+#define P2MT_GOLDILOCKS_FIELD_ORDER 0xFFFFFFFF00000001ULL /* src/mmr/common.rs:3 */
+#define P2MT_MAX_PROOF_LEN 64
+
+/* ------------------------------------------------------------------ device / runtime control */
+int p2mt_init(int device);              /* select device, upload Poseidon tables; idempotent */
+int p2mt_device_count(void);            /* number of visible HIP devices (0 => nothing can run) */
+int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches (NULL = default stream) */
+int p2mt_sync(void);                    /* hipStreamSynchronize on the library stream */
+const char *p2mt_last_error(void);
+/* Kernel variant for the Poseidon permutation: mds 0 = v_mad_u64_u32, 1 = v_dot2_u32_u16;
+ * partial 0 = spec-form partial rounds, 1 = sparse "fast" form.  All variants are bit-identical. */
+int p2mt_set_variant(int mds, int partial);
+int p2mt_get_variant(int *mds, int *partial);
+/* HIP-event timer on the library stream (what bench.py uses for per-launch durations). */
+int p2mt_timer_start(void);
+int p2mt_timer_stop(float *elapsed_ms); /* records + synchronises the stop event */
+
+/* ------------------------------------------------------------------ plonky2 Hasher, batch-shaped
+ * Replaces PoseidonHash::{two_to_one, hash_or_noop, hash_no_pad} + Poseidon::poseidon
+ * (plonky2 @3b21b87, absent) as called at simple_merkle_tree.rs:23,33,45,93,100,102 and
+ * merkle_mountain_ranges.rs:91,96,111,125,233,238,240,249. */
+int p2mt_poseidon_permute_batch(const uint64_t *in /*[n][12]*/, uint64_t *out /*[n][12]*/, size_t n);
+int p2mt_poseidon_permute_batch_dev(const uint64_t *d_in, uint64_t *d_out, size_t n);
+int p2mt_two_to_one_batch(const uint64_t *in /*[n][8] = left|right*/, uint64_t *out /*[n][4]*/, size_t n);
+int p2mt_two_to_one_batch_dev(const uint64_t *d_in, uint64_t *d_out, size_t n);
+/* hash_or_noop of n rows of `len` elements each (len <= 4: zero-padded copy, no permutation; else sponge) */
+int p2mt_hash_or_noop_batch(const uint64_t *in /*[n][len]*/, size_t n, size_t len, uint64_t *out /*[n][4]*/);
+int p2mt_hash_or_noop_batch_dev(const uint64_t *d_in, size_t n, size_t len, uint64_t *d_out);
+/* hash_n_to_hash_no_pad (always the sponge, even for len <= 4) */
+int p2mt_hash_no_pad_batch(const uint64_t *in /*[n][len]*/, size_t n, size_t len, uint64_t *out /*[n][4]*/);
+int p2mt_hash_no_pad_batch_dev(const uint64_t *d_in, size_t n, size_t len, uint64_t *d_out);
+
+/* ------------------------------------------------------------------ simple_merkle_tree.rs
+ * MerkleTree::build (simple_merkle_tree.rs:28-51).  n must be a power of two >= 2 (else P2MT_EINVAL:
+ * log2_strict panic :30 / usize underflow :38).  levels_out is level-major and matches
+ * `MerkleTree.tree`: level i has n>>i HashOuts, levels 0..log2(n)-1, (2n-2) HashOuts in total;
+ * root_out gets `MerkleTree.root`. */
+int p2mt_merkle_build_pow2(const uint64_t *leaves, size_t n, uint64_t *levels_out /*[(2n-2)][4]*/,
+                           uint64_t *root_out /*[4]*/);
+int p2mt_merkle_build_pow2_dev(const uint64_t *d_leaves, size_t n, uint64_t *d_levels_out, uint64_t *d_root_out);
+/* get_merkle_proof (:55-74) / get_in_between_hashes (:76-86) on a level-major tree held by the caller
+ * (pure index arithmetic + copies; host memory). */
+int p2mt_merkle_get_proof(const uint64_t *levels, size_t n, size_t leaf_index, uint64_t *proof_out /*[log2 n][4]*/);
+int p2mt_merkle_get_in_between_hashes(const uint64_t *levels, const uint64_t *root, size_t n, size_t leaf_index,
+                                      uint64_t *out /*[log2 n][4]*/);
+/* verify_merkle_proof (:91-109), batched: result_out[i] = 1/0.  All proofs have n_hashes siblings. */
+int p2mt_verify_merkle_proof_batch(const uint64_t *leaves /*[m]*/, const uint64_t *leaf_indices /*[m]*/,
+                                   const uint64_t *roots /*[m][4]*/, const uint64_t *hashes /*[m][n_hashes][4]*/,
+                                   size_t n_hashes, size_t m, uint8_t *result_out /*[m]*/);
+
+/* ------------------------------------------------------------------ merkle_mountain_ranges.rs
+ * Index maths (pure host functions). */
+uint64_t p2mt_get_heights_bitmap_for_mmr_size(size_t mmr_size, size_t *remainder_out); /* :39-81 */
+int64_t p2mt_get_mmr_index(size_t leaf_normal_index); /* :257-270; P2MT_ERANGE where the i32 maths overflows */
+
+/* Device-resident MMR: `elements` is the reference's post-order Vec<HashOut> (:8-12), kept in HBM. */
+typedef struct p2mt_mmr p2mt_mmr;
+int p2mt_mmr_create(p2mt_mmr **out);                    /* MMR::new (:84-86) */
+int p2mt_mmr_destroy(p2mt_mmr *m);
+int p2mt_mmr_reserve(p2mt_mmr *m, size_t n_leaves);     /* pre-size HBM for n_leaves (no reallocation while extending) */
+int p2mt_mmr_reset(p2mt_mmr *m);                        /* back to the empty MMR, keeps the allocation */
+/* MMR::add_leaf (:89-120) for k leaves at once: identical `elements` to k successive add_leaf calls. */
+int p2mt_mmr_extend(p2mt_mmr *m, const uint64_t *leaves, size_t k);
+int p2mt_mmr_extend_dev(p2mt_mmr *m, const uint64_t *d_leaves, size_t k);
+size_t p2mt_mmr_num_leaves(const p2mt_mmr *m);
+size_t p2mt_mmr_len(const p2mt_mmr *m);                 /* elements.len() = 2N - popcount(N) */
+const uint64_t *p2mt_mmr_elements_dev(const p2mt_mmr *m); /* device pointer to elements[0] */
+int p2mt_mmr_copy_elements(const p2mt_mmr *m, size_t first, size_t count, uint64_t *out /*[count][4]*/);
+/* MMR::get_peaks (:179-200).  P2MT_EINVAL on the empty MMR, P2MT_ERANGE for len >= 2^32 (Quirk Q6). */
+int p2mt_mmr_peaks(const p2mt_mmr *m, uint64_t *peaks_out /*[<=64][4]*/, int *n_peaks);
+/* MMR::bagging_the_peaks (:122-127): hash_or_noop over all peak elements (one peak => the peak). */
+int p2mt_mmr_root(const p2mt_mmr *m, uint64_t *root_out /*[4]*/);
+/* MMR::get_proof (:209-223) = get_subtree_proof_elm (:147-176) + get_peaks. */
+int p2mt_mmr_proof(const p2mt_mmr *m, size_t mmr_index, uint64_t *siblings_out /*[<=64][4]*/,
+                   uint8_t *lefts_out /*[<=64]*/, int *n_siblings, uint64_t *peaks_out /*[<=64][4]*/, int *n_peaks,
+                   size_t *mmr_size);
+/* Many proofs per call: siblings_out is [m][max_siblings][4], n_siblings_out [m]. */
+int p2mt_mmr_proof_batch(const p2mt_mmr *m, const uint64_t *mmr_indices, size_t count, size_t max_siblings,
+                         uint64_t *siblings_out, uint8_t *lefts_out, int32_t *n_siblings_out);
+/* MMR_proof::verify (:232-252).  *result_out = 1/0; returns P2MT_ENOTPEAK where the reference panics (:245). */
+int p2mt_mmr_proof_verify(const uint64_t *siblings, const uint8_t *lefts, int n_siblings, const uint64_t *peaks,
+                          int n_peaks, uint64_t leaf, const uint64_t *root, int *result_out);
+/* Batched verify against one peak set/root: status_out[i] = 1 ok, 0 root mismatch, P2MT_ENOTPEAK (-5). */
+int p2mt_mmr_proof_verify_batch(const uint64_t *siblings /*[m][max_siblings][4]*/, const uint8_t *lefts,
+                                const int32_t *n_siblings, size_t max_siblings, const uint64_t *peaks, int n_peaks,
+                                const uint64_t *leaves /*[m]*/, const uint64_t *root, size_t m,
+                                int8_t *status_out /*[m]*/);
+
+/* ------------------------------------------------------------------ multi-GPU sharded build
+ * Rank r of `world` (both powers of two) owns leaves [r*n_local, (r+1)*n_local) of a 2^k-leaf MMR and
+ * builds that perfect subtree locally with p2mt_mmr_extend*.  After an all-gather of the `world`
+ * 32-byte subtree roots (the only exchange; done by the host side with RCCL), this hashes the top
+ * log2(world) levels.  top_nodes_out: (world-1) HashOuts, level-major bottom-up; root_out: the peak. */
+int p2mt_mmr_combine_shard_roots(const uint64_t *shard_roots /*[world][4]*/, size_t world,
+                                 uint64_t *top_nodes_out /*[world-1][4] or NULL*/, uint64_t *root_out /*[4]*/);
+/* post-order position of the first element of shard `rank` and of top node (height h above shard roots, index j) */
+size_t p2mt_mmr_shard_first_pos(size_t n_local, size_t rank);
+size_t p2mt_mmr_node_pos(size_t last_leaf, unsigned height); /* 2L - popcount(L) + h */
+
+/* ------------------------------------------------------------------ Plonky2 commit step
+ * Replaces, inside CircuitData::prove (called at mmr_plonky2_verifier.rs:148 and
+ * mmr_plonky2_verifier_1_recursion.rs:192,218), plonky2's PolynomialBatch::from_values/from_coeffs:
+ * IFFT -> x2^rate_bits coset LDE (shift 7) -> transpose -> bit-reverse -> MerkleTree::new(cap_height),
+ * and its pieces fft_with_options / ifft_with_options / MerkleTree::new. */
+int p2mt_ntt_batch(uint64_t *data /*[n_polys][2^log_n], in place*/, unsigned log_n, size_t n_polys, int inverse);
+int p2mt_ntt_batch_dev(uint64_t *d_data, unsigned log_n, size_t n_polys, int inverse);
+/* out[j][i] = f_j(shift * w^i), w = primitive 2^(log_n+rate_bits)-th root, natural order */
+int p2mt_coset_lde_batch(const uint64_t *coeffs /*[n_polys][2^log_n]*/, unsigned log_n, unsigned rate_bits,
+                         uint64_t shift, size_t n_polys, uint64_t *out /*[n_polys][2^(log_n+rate_bits)]*/);
+int p2mt_coset_lde_batch_dev(const uint64_t *d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                             size_t n_polys, uint64_t *d_out);
+/* MerkleTree::new(leaves, cap_height): n = 2^k leaves of `width` elements (row-major n x width).
+ * digests_out: level-major, level 0 = leaf digests, levels 0..k-cap_height-1; may be NULL.  cap_out: 2^cap_height. */
+int p2mt_merkle_cap_commit(const uint64_t *leaves, size_t n, size_t width, unsigned cap_height,
+                           uint64_t *digests_out, uint64_t *cap_out);
+int p2mt_merkle_cap_commit_dev(const uint64_t *d_leaves, size_t n, size_t width, unsigned cap_height,
+                               uint64_t *d_digests_out, uint64_t *d_cap_out);
+/* PolynomialBatch::from_values (is_values = 1) / from_coeffs (0).  leaves_out: [2^(log_n+rate_bits)][n_polys],
+ * leaf index bit-reversed; digests_out/cap_out as above.  Any output pointer may be NULL except cap_out. */
+int p2mt_polynomial_batch_commit(const uint64_t *polys /*[n_polys][2^log_n]*/, int is_values, size_t n_polys,
+                                 unsigned log_n, unsigned rate_bits, unsigned cap_height, uint64_t *leaves_out,
+                                 uint64_t *digests_out, uint64_t *cap_out);
+int p2mt_polynomial_batch_commit_dev(const uint64_t *d_polys, int is_values, size_t n_polys, unsigned log_n,
+                                     unsigned rate_bits, unsigned cap_height, uint64_t *d_leaves_out,
+                                     uint64_t *d_digests_out, uint64_t *d_cap_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2MT_H */

@@ -1,0 +1,29 @@
+"""plonky2-merkle-trees_amd: MI355X-native Poseidon/Goldilocks Merkle tree, MMR and Plonky2 commit kernels.
+
+The product is the HIP library `libp2mt_hip.so` behind the C ABI of include/p2mt.h; this package is the
+host-side mirror of the reference's public API over that ABI (ctypes), used by the tests and bench.py.
+Import name: `plonky2_merkle_trees_amd` (registered by __graft_entry__.load_package(), since the directory
+name carries a hyphen).
+"""
+from . import _native
+from ._native import P2mtError, P2mtPanic, lib
+from .hashing import (hash_no_pad, hash_no_pad_batch, hash_or_noop, hash_or_noop_batch, poseidon_permute_batch,
+                      two_to_one, two_to_one_batch)
+from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_batch
+from . import distributed
+from .distributed import ShardedMMR
+from .mmr import (MMR, MMR_proof, get_heights_bitmap_for_mmr_size, get_mmr_index, verify_proof_batch)
+
+GOLDILOCKS_FIELD_ORDER = 18446744069414584321  # src/mmr/common.rs:3
+
+
+def init(device=0):
+    _native.check(lib().p2mt_init(device))
+
+
+def set_variant(mds, partial):
+    _native.check(lib().p2mt_set_variant(mds, partial))
+
+
+def device_count():
+    return lib().p2mt_device_count()

@@ -1,0 +1,142 @@
+"""ctypes binding of libp2mt_hip.so -- the C ABI declared in include/p2mt.h.
+
+There is NO fallback: if the shared library is missing this module raises at import of `lib()`,
+and every compute entry point fails with P2MT_EHIP when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libp2mt_hip.so")
+
+P2MT_OK, P2MT_EINVAL, P2MT_ENOMEM, P2MT_EHIP, P2MT_ERANGE, P2MT_ENOTPEAK = 0, -1, -2, -3, -4, -5
+MAX_PROOF_LEN = 64
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+i32p = C.POINTER(C.c_int32)
+intp = C.POINTER(C.c_int)
+sizep = C.POINTER(C.c_size_t)
+voidp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/p2mt.h (checked by tests/test_abi_cpu.py)
+SIGNATURES = {
+    "p2mt_init": (C.c_int, [C.c_int]),
+    "p2mt_device_count": (C.c_int, []),
+    "p2mt_set_stream": (C.c_int, [voidp]),
+    "p2mt_sync": (C.c_int, []),
+    "p2mt_last_error": (C.c_char_p, []),
+    "p2mt_set_variant": (C.c_int, [C.c_int, C.c_int]),
+    "p2mt_get_variant": (C.c_int, [intp, intp]),
+    "p2mt_timer_start": (C.c_int, []),
+    "p2mt_timer_stop": (C.c_int, [C.POINTER(C.c_float)]),
+    "p2mt_poseidon_permute_batch": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_poseidon_permute_batch_dev": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_two_to_one_batch": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_two_to_one_batch_dev": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_hash_or_noop_batch": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_hash_or_noop_batch_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_hash_no_pad_batch": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_hash_no_pad_batch_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_merkle_build_pow2": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_merkle_build_pow2_dev": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_merkle_get_proof": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_merkle_get_in_between_hashes": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_verify_merkle_proof_batch": (C.c_int, [voidp, voidp, voidp, voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_get_heights_bitmap_for_mmr_size": (C.c_uint64, [C.c_size_t, sizep]),
+    "p2mt_get_mmr_index": (C.c_int64, [C.c_size_t]),
+    "p2mt_mmr_create": (C.c_int, [C.POINTER(voidp)]),
+    "p2mt_mmr_destroy": (C.c_int, [voidp]),
+    "p2mt_mmr_reserve": (C.c_int, [voidp, C.c_size_t]),
+    "p2mt_mmr_reset": (C.c_int, [voidp]),
+    "p2mt_mmr_extend": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_mmr_extend_dev": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_mmr_num_leaves": (C.c_size_t, [voidp]),
+    "p2mt_mmr_len": (C.c_size_t, [voidp]),
+    "p2mt_mmr_elements_dev": (voidp, [voidp]),
+    "p2mt_mmr_copy_elements": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_mmr_peaks": (C.c_int, [voidp, voidp, intp]),
+    "p2mt_mmr_root": (C.c_int, [voidp, voidp]),
+    "p2mt_mmr_proof": (C.c_int, [voidp, C.c_size_t, voidp, voidp, intp, voidp, intp, sizep]),
+    "p2mt_mmr_proof_batch": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp, voidp]),
+    "p2mt_mmr_proof_verify": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.c_uint64, voidp, intp]),
+    "p2mt_mmr_proof_verify_batch": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, C.c_int, voidp, voidp,
+                                              C.c_size_t, voidp]),
+    "p2mt_mmr_combine_shard_roots": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_mmr_shard_first_pos": (C.c_size_t, [C.c_size_t, C.c_size_t]),
+    "p2mt_mmr_node_pos": (C.c_size_t, [C.c_size_t, C.c_uint]),
+    "p2mt_ntt_batch": (C.c_int, [voidp, C.c_uint, C.c_size_t, C.c_int]),
+    "p2mt_ntt_batch_dev": (C.c_int, [voidp, C.c_uint, C.c_size_t, C.c_int]),
+    "p2mt_coset_lde_batch": (C.c_int, [voidp, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t, voidp]),
+    "p2mt_coset_lde_batch_dev": (C.c_int, [voidp, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t, voidp]),
+    "p2mt_merkle_cap_commit": (C.c_int, [voidp, C.c_size_t, C.c_size_t, C.c_uint, voidp, voidp]),
+    "p2mt_merkle_cap_commit_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, C.c_uint, voidp, voidp]),
+    "p2mt_polynomial_batch_commit": (C.c_int, [voidp, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, voidp,
+                                               voidp, voidp]),
+    "p2mt_polynomial_batch_commit_dev": (C.c_int, [voidp, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, voidp,
+                                                   voidp, voidp]),
+}
+
+
+class P2mtError(RuntimeError):
+    """Non-zero status from the C ABI.  Where the reference panics, `code` says which panic."""
+
+    def __init__(self, code, msg):
+        super().__init__("p2mt status %d: %s" % (code, msg))
+        self.code = code
+
+
+class P2mtPanic(P2mtError):
+    """The reference would panic here (assert!/unwrap/log2_strict)."""
+
+
+_lib = None
+
+
+def lib():
+    """Load libp2mt_hip.so (once).  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc == P2MT_OK:
+        return
+    msg = lib().p2mt_last_error().decode("utf-8", "replace")
+    if rc in (P2MT_EINVAL, P2MT_ERANGE, P2MT_ENOTPEAK):
+        raise P2mtPanic(rc, msg)
+    raise P2mtError(rc, msg)
+
+
+def as_u64(x, shape=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def ptr(a):
+    """void* of a numpy array, a raw integer device address, or a torch tensor (host or device)."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    raise TypeError("cannot take the address of %r" % type(a))

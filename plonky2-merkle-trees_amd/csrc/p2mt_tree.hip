@@ -1,0 +1,810 @@
+// p2mt_tree.hip -- Poseidon batch kernels, power-of-two Merkle tree and device-resident MMR.
+//
+// Replaces the hashing loops of
+//   /root/reference/src/simple_merkle_tree/simple_merkle_tree.rs:18-109   (MerkleTree, verify_merkle_proof)
+//   /root/reference/src/mmr/merkle_mountain_ranges.rs:84-252              (MMR, MMR_proof)
+// HBM layout: a HashOut is a 32-byte record (4 x u64, AoS) exactly as the reference's Vec<HashOut>, so
+// `MerkleTree.tree` (level-major) and `MMR.elements` (post-order) can be copied out verbatim.
+// One lane computes one node (poseidon.hip.h); a level of the tree is one launch.  The MMR is built
+// level-synchronously straight into its post-order positions: the node of height h whose last leaf is L
+// lives at 2L - popcount(L) + h, its right child at pos-1, its left child at pos-2^h.
+#include "poseidon.hip.h"
+#include "runtime.h"
+
+#include <string.h>
+
+#include <vector>
+
+using gl::u32;
+using gl::u64;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct __attribute__((aligned(16))) Hash4 {
+  u64 v[4];
+};
+
+GL_DEV void load_hash(const u64* p, u64 (&h)[4]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+  const ulonglong2 a = q[0], b = q[1];
+  h[0] = a.x; h[1] = a.y; h[2] = b.x; h[3] = b.y;
+}
+GL_DEV void store_hash(u64* p, const u64 (&h)[4]) {
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
+  q[0] = make_ulonglong2(h[0], h[1]);
+  q[1] = make_ulonglong2(h[2], h[3]);
+}
+
+GL_DEV size_t node_pos(size_t last_leaf, unsigned h) { return 2 * last_leaf - (size_t)__popcll(last_leaf) + h; }
+
+// ---------------------------------------------------------------- stateless batch kernels
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = in[12 * i + k];
+  poseidon::permute<M, PR>(s);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) out[12 * i + k] = gl::canon(s[k]);
+}
+
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 l[4], r[4], o[4];
+  load_hash(in + 8 * i, l);
+  load_hash(in + 8 * i + 4, r);
+  poseidon::two_to_one<M, PR>(l, r, o);
+  store_hash(out + 4 * i, o);
+}
+
+// hash_or_noop / hash_no_pad of `len`-element rows: overwrite-mode sponge, rate 8, one row per lane.
+template <int M, int PR>
+GL_DEV void sponge_row(const u64* __restrict__ row, size_t len, u64 (&o)[4]) {
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = 0;
+#pragma unroll 1
+  for (size_t off = 0; off < len; off += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (off + k < len) s[k] = row[off + k];
+    poseidon::permute<M, PR>(s);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = gl::canon(s[k]);
+}
+
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
+                                                      u64* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 o[4];
+  if (noop_short && len <= 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (size_t)k < len ? gl::canon(in[i * len + k]) : 0;
+  } else {
+    sponge_row<M, PR>(in + i * len, len, o);
+  }
+  store_hash(out + 4 * i, o);
+}
+
+// ---------------------------------------------------------------- simple_merkle_tree.rs
+// level0[i] = hash_or_noop([leaf]) = [leaf, 0, 0, 0]  (:33; no permutation, Quirk Q1)
+__global__ __launch_bounds__(kBlock) void k_leaf_digests(const u64* __restrict__ leaves, u64* __restrict__ level0, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const u64 o[4] = {gl::canon(leaves[i]), 0, 0, 0};
+  store_hash(level0 + 4 * i, o);
+}
+
+// next_level_hashes (:21-25): out[j] = two_to_one(in[2j], in[2j+1])
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n_out) return;
+  u64 l[4], r[4], o[4];
+  load_hash(in + 8 * j, l);
+  load_hash(in + 8 * j + 4, r);
+  poseidon::two_to_one<M, PR>(l, r, o);
+  store_hash(out + 4 * j, o);
+}
+
+// verify_merkle_proof (:91-109), one proof per lane
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_verify_merkle_proof(const u64* __restrict__ leaves, const u64* __restrict__ idx,
+                                                                const u64* __restrict__ roots,
+                                                                const u64* __restrict__ hashes, size_t n_hashes, size_t m,
+                                                                uint8_t* __restrict__ result) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  u64 cur[4] = {gl::canon(leaves[i]), 0, 0, 0};
+  u64 index = idx[i];
+#pragma unroll 1
+  for (size_t k = 0; k < n_hashes; ++k) {
+    u64 sib[4], l[4], r[4];
+    load_hash(hashes + 4 * (i * n_hashes + k), sib);
+    const bool even = (index & 1) == 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      l[t] = even ? cur[t] : sib[t];
+      r[t] = even ? sib[t] : cur[t];
+    }
+    poseidon::two_to_one<M, PR>(l, r, cur);
+    index >>= 1;
+  }
+  u64 root[4];
+  load_hash(roots + 4 * i, root);
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ok = ok && (cur[t] == gl::canon(root[t]));
+  result[i] = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- merkle_mountain_ranges.rs
+// add_leaf's push of hash_or_noop([leaf]) (:91/:96/:104) for leaves [n0, n0+k): leaf i sits at 2i - popcount(i)
+__global__ __launch_bounds__(kBlock) void k_mmr_leaves(const u64* __restrict__ leaves, u64* __restrict__ elements, size_t n0,
+                                                       size_t k) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= k) return;
+  const size_t i = n0 + t;
+  const u64 o[4] = {gl::canon(leaves[t]), 0, 0, 0};
+  store_hash(elements + 4 * node_pos(i, 0), o);
+}
+
+// the carry chain of add_leaf (:106-119), level-synchronous: all height-h nodes j in [j0, j1)
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_mmr_level(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1) {
+  const size_t j = j0 + (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= j1) return;
+  const size_t last_leaf = ((j + 1) << h) - 1;
+  const size_t pos = node_pos(last_leaf, h);
+  u64 l[4], r[4], o[4];
+  load_hash(elements + 4 * (pos - ((size_t)1 << h)), l);
+  load_hash(elements + 4 * (pos - 1), r);
+  poseidon::two_to_one<M, PR>(l, r, o);
+  store_hash(elements + 4 * pos, o);
+}
+
+struct PosList {
+  u64 pos[P2MT_MAX_PROOF_LEN];
+  int n;
+};
+
+// get_peaks (:179-200) gather + bagging_the_peaks (:122-127): one lane (<= 32 permutations)
+template <int M, int PR>
+__global__ void k_mmr_peaks_root(const u64* __restrict__ elements, PosList pl, u64* __restrict__ peaks_out,
+                                 u64* __restrict__ root_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < pl.n; ++i) {
+    u64 h[4];
+    load_hash(elements + 4 * pl.pos[i], h);
+    store_hash(peaks_out + 4 * i, h);
+  }
+  u64 o[4];
+  if (pl.n == 1) {  // hash_or_noop of 4 elements: the peak itself (Quirk Q2)
+    load_hash(peaks_out, o);
+  } else {
+    sponge_row<M, PR>(peaks_out, (size_t)pl.n * 4, o);
+  }
+  store_hash(root_out, o);
+}
+
+// bagging of caller-supplied peaks (MMR_proof::verify :248-249)
+template <int M, int PR>
+__global__ void k_bag_peaks(const u64* __restrict__ peaks, int n_peaks, u64* __restrict__ root_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u64 o[4];
+  if (n_peaks * 4 <= 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = k < n_peaks * 4 ? gl::canon(peaks[k]) : 0;
+  } else {
+    sponge_row<M, PR>(peaks, (size_t)n_peaks * 4, o);
+  }
+  store_hash(root_out, o);
+}
+
+// remainder of the greedy perfect-subtree decomposition of x == height of the element at index x
+// (get_heights_bitmap_for_mmr_size(x).1, :39-81)
+__host__ __device__ inline unsigned mmr_remainder(size_t x) {
+  if (x == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  size_t sub = (~(size_t)0) >> __clzll((long long)x);
+#else
+  size_t sub = (~(size_t)0) >> __builtin_clzll((unsigned long long)x);
+#endif
+  while (sub) {
+    if (x >= sub) x -= sub;
+    sub >>= 1;
+  }
+  return (unsigned)x;
+}
+
+// get_subtree_proof_elm (:147-176): walk up from mmr_index; one proof per lane; siblings gathered from HBM
+__global__ __launch_bounds__(kBlock) void k_mmr_proof_batch(const u64* __restrict__ elements, size_t len,
+                                                            const u64* __restrict__ indices, size_t count,
+                                                            size_t max_sib, u64* __restrict__ sib_out,
+                                                            uint8_t* __restrict__ lefts_out, int32_t* __restrict__ n_out) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  size_t cur = indices[t];
+  if (cur >= len) {  // the reference panics (index out of bounds)
+    n_out[t] = -1;
+    return;
+  }
+  int n = 0;
+  unsigned h = 0;
+  for (;;) {
+    const size_t span = ((size_t)2 << h) - 1;
+    size_t sib;
+    bool left;
+    if (cur >= span && mmr_remainder(cur - span) == h) {  // :157-164 element `span` before is at the same height
+      sib = cur - span;
+      left = true;
+      cur += 1;
+    } else {  // add_right_elm (:129-144)
+      const size_t nxt = cur + span;
+      if (!(nxt < len - 1)) break;
+      sib = nxt;
+      left = false;
+      cur = nxt + 1;
+    }
+    if ((size_t)n < max_sib) {
+      u64 hsh[4];
+      load_hash(elements + 4 * sib, hsh);
+      store_hash(sib_out + 4 * (t * max_sib + n), hsh);
+      lefts_out[t * max_sib + n] = left ? 1 : 0;
+    }
+    ++n;
+    ++h;
+  }
+  n_out[t] = n;
+}
+
+// MMR_proof::verify (:232-252), one proof per lane; `bagged` = hash_or_noop(peaks) computed once by k_bag_peaks
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_mmr_verify_batch(const u64* __restrict__ sib, const uint8_t* __restrict__ lefts,
+                                                             const int32_t* __restrict__ n_sib, size_t max_sib,
+                                                             const u64* __restrict__ peaks, int n_peaks,
+                                                             const u64* __restrict__ leaves, const u64* __restrict__ root,
+                                                             const u64* __restrict__ bagged, size_t m,
+                                                             int8_t* __restrict__ status) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  u64 cur[4] = {gl::canon(leaves[i]), 0, 0, 0};
+  const int ns = n_sib[i];
+#pragma unroll 1
+  for (int k = 0; k < ns; ++k) {
+    u64 s[4], l[4], r[4];
+    load_hash(sib + 4 * (i * max_sib + k), s);
+    const bool on_left = lefts[i * max_sib + k] != 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      l[t] = on_left ? s[t] : cur[t];
+      r[t] = on_left ? cur[t] : s[t];
+    }
+    poseidon::two_to_one<M, PR>(l, r, cur);
+  }
+  bool found = false;
+  for (int p = 0; p < n_peaks; ++p) {
+    bool eq = true;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) eq = eq && (gl::canon(peaks[4 * p + t]) == cur[t]);
+    found = found || eq;
+  }
+  if (!found) {
+    status[i] = (int8_t)P2MT_ENOTPEAK;  // the reference panics here (:245)
+    return;
+  }
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ok = ok && (bagged[t] == gl::canon(root[t]));
+  status[i] = ok ? 1 : 0;
+}
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// Launch KERNEL<mds, partial> for the runtime-selected variant.
+#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                        \
+  do {                                                                                                 \
+    hipStream_t st_ = p2mt::rt().stream;                                                               \
+    switch (p2mt::rt().mds * 2 + p2mt::rt().partial) {                                                 \
+      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
+      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
+      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
+    }                                                                                                  \
+    P2MT_LAUNCH_CHECK();                                                                               \
+  } while (0)
+
+namespace p2mt {
+
+// exported to the other translation units
+int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, u64* d_out) {
+  if (n == 0) return P2MT_OK;
+  P2MT_DISPATCH(k_hash_rows, grid_for(n), kBlock, d_in, n, len, noop_short, d_out);
+  return P2MT_OK;
+}
+int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
+  if (n_out == 0) return P2MT_OK;
+  P2MT_DISPATCH(k_merkle_level, grid_for(n_out), kBlock, d_in, d_out, n_out);
+  return P2MT_OK;
+}
+
+}  // namespace p2mt
+
+using p2mt::DevBuf;
+using p2mt::rt;
+
+// =================================================================== stateless batch entry points
+extern "C" int p2mt_poseidon_permute_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_DISPATCH(k_permute_batch, grid_for(n), kBlock, d_in, d_out, n);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_poseidon_permute_batch(const uint64_t* in, uint64_t* out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf b;
+  P2MT_TRY(b.alloc(n * 96));
+  P2MT_HIP(hipMemcpyAsync(b.p, in, n * 96, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_poseidon_permute_batch_dev(b.as<u64>(), b.as<u64>(), n));
+  P2MT_HIP(hipMemcpyAsync(out, b.p, n * 96, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_two_to_one_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_DISPATCH(k_two_to_one_batch, grid_for(n), kBlock, d_in, d_out, n);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_two_to_one_batch(const uint64_t* in, uint64_t* out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bo;
+  P2MT_TRY(bi.alloc(n * 64));
+  P2MT_TRY(bo.alloc(n * 32));
+  P2MT_HIP(hipMemcpyAsync(bi.p, in, n * 64, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_two_to_one_batch_dev(bi.as<u64>(), bo.as<u64>(), n));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+static int hash_rows_host(const uint64_t* in, size_t n, size_t len, int noop_short, uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!out || (!in && len)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bo;
+  P2MT_TRY(bi.alloc(n * len * 8));
+  P2MT_TRY(bo.alloc(n * 32));
+  if (len) P2MT_HIP(hipMemcpyAsync(bi.p, in, n * len * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt::launch_hash_rows_dev(bi.as<u64>(), n, len, noop_short, bo.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_hash_or_noop_batch(const uint64_t* in, size_t n, size_t len, uint64_t* out) {
+  return hash_rows_host(in, n, len, 1, out);
+}
+extern "C" int p2mt_hash_no_pad_batch(const uint64_t* in, size_t n, size_t len, uint64_t* out) {
+  return hash_rows_host(in, n, len, 0, out);
+}
+extern "C" int p2mt_hash_or_noop_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  return p2mt::launch_hash_rows_dev(d_in, n, len, 1, d_out);
+}
+extern "C" int p2mt_hash_no_pad_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  return p2mt::launch_hash_rows_dev(d_in, n, len, 0, d_out);
+}
+
+// =================================================================== simple_merkle_tree.rs
+static int log2_strict(size_t n) {
+  if (n == 0 || (n & (n - 1))) return -1;
+  return __builtin_ctzll((unsigned long long)n);
+}
+
+extern "C" int p2mt_merkle_build_pow2_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_levels, uint64_t* d_root) {
+  P2MT_TRY(p2mt::ensure_init());
+  const int k = log2_strict(n);
+  if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
+  if (!d_leaves || !d_levels || !d_root) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  hipLaunchKernelGGL(k_leaf_digests, dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_leaves, d_levels, n);
+  P2MT_LAUNCH_CHECK();
+  u64* cur = d_levels;
+  size_t cur_n = n;
+  for (int i = 0; i < k - 1; ++i) {  // levels 1 .. k-1
+    u64* next = cur + 4 * cur_n;
+    P2MT_TRY(p2mt::launch_merkle_level_dev(cur, next, cur_n / 2));
+    cur = next;
+    cur_n /= 2;
+  }
+  return p2mt::launch_merkle_level_dev(cur, d_root, 1);  // root = two_to_one(last[0], last[1])
+}
+
+extern "C" int p2mt_merkle_build_pow2(const uint64_t* leaves, size_t n, uint64_t* levels_out, uint64_t* root_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  const int k = log2_strict(n);
+  if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
+  if (!leaves || !levels_out || !root_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bl, bt;
+  P2MT_TRY(bl.alloc(n * 8));
+  P2MT_TRY(bt.alloc((2 * n - 2 + 1) * 32));
+  u64* d_root = bt.as<u64>() + 4 * (2 * n - 2);
+  P2MT_HIP(hipMemcpyAsync(bl.p, leaves, n * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_merkle_build_pow2_dev(bl.as<u64>(), n, bt.as<u64>(), d_root));
+  P2MT_HIP(hipMemcpyAsync(levels_out, bt.p, (2 * n - 2) * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+static const uint64_t* level_ptr(const uint64_t* levels, size_t n, int level) {
+  size_t off = 0;
+  for (int i = 0; i < level; ++i) off += n >> i;
+  return levels + 4 * off;
+}
+
+extern "C" int p2mt_merkle_get_proof(const uint64_t* levels, size_t n, size_t leaf_index, uint64_t* proof_out) {
+  const int k = log2_strict(n);
+  if (k < 1 || !levels || !proof_out) return p2mt::fail(P2MT_EINVAL, "get_merkle_proof: bad tree");
+  if (leaf_index >= n) return p2mt::fail(P2MT_EINVAL, "get_merkle_proof: assert!(leaf_index < n)");
+  size_t idx = leaf_index;
+  for (int i = 0; i < k; ++i, idx >>= 1) memcpy(proof_out + 4 * i, level_ptr(levels, n, i) + 4 * (idx ^ 1), 32);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_merkle_get_in_between_hashes(const uint64_t* levels, const uint64_t* root, size_t n,
+                                                 size_t leaf_index, uint64_t* out) {
+  const int k = log2_strict(n);
+  if (k < 1 || !levels || !root || !out) return p2mt::fail(P2MT_EINVAL, "get_in_between_hashes: bad tree");
+  if (leaf_index >= n) return p2mt::fail(P2MT_EINVAL, "get_in_between_hashes: assert!(leaf_index < n)");
+  size_t idx = leaf_index >> 1;
+  for (int i = 1; i < k; ++i, idx >>= 1) memcpy(out + 4 * (i - 1), level_ptr(levels, n, i) + 4 * idx, 32);
+  memcpy(out + 4 * (k - 1), root, 32);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_verify_merkle_proof_batch(const uint64_t* leaves, const uint64_t* leaf_indices, const uint64_t* roots,
+                                              const uint64_t* hashes, size_t n_hashes, size_t m, uint8_t* result_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (m == 0) return P2MT_OK;
+  if (!leaves || !leaf_indices || !roots || (!hashes && n_hashes) || !result_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bl, bi, br, bh, bo;
+  P2MT_TRY(bl.alloc(m * 8));
+  P2MT_TRY(bi.alloc(m * 8));
+  P2MT_TRY(br.alloc(m * 32));
+  P2MT_TRY(bh.alloc(m * n_hashes * 32));
+  P2MT_TRY(bo.alloc(m));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(bl.p, leaves, m * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bi.p, leaf_indices, m * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(br.p, roots, m * 32, hipMemcpyHostToDevice, st));
+  if (n_hashes) P2MT_HIP(hipMemcpyAsync(bh.p, hashes, m * n_hashes * 32, hipMemcpyHostToDevice, st));
+  P2MT_DISPATCH(k_verify_merkle_proof, grid_for(m), kBlock, bl.as<u64>(), bi.as<u64>(), br.as<u64>(), bh.as<u64>(),
+                n_hashes, m, bo.as<uint8_t>());
+  P2MT_HIP(hipMemcpyAsync(result_out, bo.p, m, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}
+
+// =================================================================== merkle_mountain_ranges.rs
+extern "C" uint64_t p2mt_get_heights_bitmap_for_mmr_size(size_t mmr_size, size_t* remainder_out) {
+  // one bit per perfect subtree that fits, scanning sizes 2^(b+1)-1 from the largest not exceeding
+  // the all-ones envelope of mmr_size down to 1 (:39-81)
+  uint64_t bitmap = 0;
+  size_t rest = mmr_size;
+  if (mmr_size) {
+    for (size_t sub = (~(size_t)0) >> __builtin_clzll((unsigned long long)mmr_size); sub; sub >>= 1) {
+      bitmap <<= 1;
+      if (rest >= sub) {
+        bitmap |= 1;
+        rest -= sub;
+      }
+    }
+  }
+  if (remainder_out) *remainder_out = rest;
+  return bitmap;
+}
+
+extern "C" int64_t p2mt_get_mmr_index(size_t n) {
+  // 2n - popcount(n); the reference accumulates 2^(i+1)-1 per set bit i in i32 and panics on overflow (:264)
+  if (n >> 30) return P2MT_ERANGE;
+  const int64_t r = 2 * (int64_t)n - __builtin_popcountll((unsigned long long)n);
+  return r > INT32_MAX ? (int64_t)P2MT_ERANGE : r;
+}
+
+extern "C" size_t p2mt_mmr_node_pos(size_t last_leaf, unsigned height) {
+  return 2 * last_leaf - (size_t)__builtin_popcountll((unsigned long long)last_leaf) + height;
+}
+
+extern "C" size_t p2mt_mmr_shard_first_pos(size_t n_local, size_t rank) {
+  const size_t first_leaf = n_local * rank;
+  return 2 * first_leaf - (size_t)__builtin_popcountll((unsigned long long)first_leaf);
+}
+
+struct p2mt_mmr {
+  u64* elements = nullptr;  // device, post-order HashOut records
+  size_t cap_nodes = 0;
+  size_t n_leaves = 0;
+  u64* scratch = nullptr;  // device: 64 peaks + root (65 HashOuts)
+};
+
+static size_t mmr_len_for(size_t n_leaves) { return 2 * n_leaves - (size_t)__builtin_popcountll((unsigned long long)n_leaves); }
+
+extern "C" int p2mt_mmr_create(p2mt_mmr** out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  p2mt_mmr* m = new (std::nothrow) p2mt_mmr();
+  if (!m) return p2mt::fail(P2MT_ENOMEM, "host allocation failed");
+  hipError_t e = hipMalloc((void**)&m->scratch, 65 * 32);
+  if (e != hipSuccess) {
+    delete m;
+    return p2mt::fail_hip(e, "hipMalloc(scratch)", __FILE__, __LINE__);
+  }
+  *out = m;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_destroy(p2mt_mmr* m) {
+  if (!m) return P2MT_OK;
+  if (m->elements) (void)hipFree(m->elements);
+  if (m->scratch) (void)hipFree(m->scratch);
+  delete m;
+  return P2MT_OK;
+}
+
+static int mmr_grow(p2mt_mmr* m, size_t need_nodes) {
+  if (need_nodes <= m->cap_nodes) return P2MT_OK;
+  size_t cap = m->cap_nodes ? m->cap_nodes : 1024;
+  while (cap < need_nodes) cap *= 2;
+  if (m->cap_nodes == 0) cap = need_nodes > 1024 ? need_nodes : 1024;  // first allocation: exact (reserve)
+  u64* fresh = nullptr;
+  hipError_t e = hipMalloc((void**)&fresh, cap * 32);
+  if (e != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc failed while growing the MMR");
+  const size_t used = mmr_len_for(m->n_leaves);
+  if (used) P2MT_HIP(hipMemcpyAsync(fresh, m->elements, used * 32, hipMemcpyDeviceToDevice, rt().stream));
+  if (m->elements) {
+    P2MT_HIP(hipStreamSynchronize(rt().stream));
+    (void)hipFree(m->elements);
+  }
+  m->elements = fresh;
+  m->cap_nodes = cap;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_reserve(p2mt_mmr* m, size_t n_leaves) {
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  return mmr_grow(m, 2 * n_leaves);
+}
+
+extern "C" int p2mt_mmr_reset(p2mt_mmr* m) {
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  m->n_leaves = 0;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  if (k == 0) return P2MT_OK;
+  if (!d_leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  const size_t n0 = m->n_leaves, n1 = n0 + k;
+  if (n1 < n0 || (n1 >> 40)) return p2mt::fail(P2MT_ERANGE, "MMR too large");
+  P2MT_TRY(mmr_grow(m, mmr_len_for(n1)));
+  hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(k)), dim3(kBlock), 0, rt().stream, d_leaves, m->elements, n0, k);
+  P2MT_LAUNCH_CHECK();
+  // height-h node j is new iff it ends after leaf n0 and is complete iff it ends by n1: j in [n0>>h, n1>>h)
+  for (unsigned h = 1; (n1 >> h) > (n0 >> h); ++h) {
+    const size_t j0 = n0 >> h, j1 = n1 >> h;
+    P2MT_DISPATCH(k_mmr_level, grid_for(j1 - j0), kBlock, m->elements, h, j0, j1);
+  }
+  m->n_leaves = n1;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  if (k == 0) return P2MT_OK;
+  if (!leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf b;
+  P2MT_TRY(b.alloc(k * 8));
+  P2MT_HIP(hipMemcpyAsync(b.p, leaves, k * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_mmr_extend_dev(m, b.as<u64>(), k));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));  // the staging buffer dies with this call
+  return P2MT_OK;
+}
+
+extern "C" size_t p2mt_mmr_num_leaves(const p2mt_mmr* m) { return m ? m->n_leaves : 0; }
+extern "C" size_t p2mt_mmr_len(const p2mt_mmr* m) { return m ? mmr_len_for(m->n_leaves) : 0; }
+extern "C" const uint64_t* p2mt_mmr_elements_dev(const p2mt_mmr* m) { return m ? m->elements : nullptr; }
+
+extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t count, uint64_t* out) {
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  const size_t len = mmr_len_for(m->n_leaves);
+  if (first > len || count > len - first) return p2mt::fail(P2MT_EINVAL, "copy_elements: range out of bounds");
+  if (count == 0) return P2MT_OK;
+  if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_HIP(hipMemcpyAsync(out, m->elements + 4 * first, count * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+// peaks left to right = one per set bit of N, decreasing height; the peak of height b ends at the running leaf prefix
+static int mmr_peak_positions(const p2mt_mmr* m, PosList* pl) {
+  const size_t len = mmr_len_for(m->n_leaves);
+  if (len == 0) return p2mt::fail(P2MT_EINVAL, "get_peaks on an empty MMR (the reference overflows a shift, Q6)");
+  if (len > 0xFFFFFFFFull) return p2mt::fail(P2MT_ERANGE, "get_peaks: mmr_len.to_u32().unwrap() (Q6)");
+  pl->n = 0;
+  size_t prefix = 0;
+  for (int b = 63; b >= 0; --b) {
+    if ((m->n_leaves >> b) & 1) {
+      prefix += (size_t)1 << b;
+      pl->pos[pl->n++] = p2mt_mmr_node_pos(prefix - 1, (unsigned)b);
+    }
+  }
+  return P2MT_OK;
+}
+
+static int mmr_peaks_root(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks, uint64_t* root_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  PosList pl;
+  P2MT_TRY(mmr_peak_positions(m, &pl));
+  u64* d_peaks = m->scratch;
+  u64* d_root = m->scratch + 4 * 64;
+  P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, d_peaks, d_root);
+  if (peaks_out) P2MT_HIP(hipMemcpyAsync(peaks_out, d_peaks, (size_t)pl.n * 32, hipMemcpyDeviceToHost, rt().stream));
+  if (root_out) P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  if (n_peaks) *n_peaks = pl.n;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_peaks(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks) {
+  if (!peaks_out || !n_peaks) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  return mmr_peaks_root(m, peaks_out, n_peaks, nullptr);
+}
+
+extern "C" int p2mt_mmr_root(const p2mt_mmr* m, uint64_t* root_out) {
+  if (!root_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  return mmr_peaks_root(m, nullptr, nullptr, root_out);
+}
+
+extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indices, size_t count, size_t max_siblings,
+                                    uint64_t* siblings_out, uint8_t* lefts_out, int32_t* n_siblings_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  if (count == 0) return P2MT_OK;
+  if (!mmr_indices || !siblings_out || !lefts_out || !n_siblings_out || max_siblings == 0)
+    return p2mt::fail(P2MT_EINVAL, "null pointer");
+  const size_t len = mmr_len_for(m->n_leaves);
+  if (len == 0) return p2mt::fail(P2MT_EINVAL, "get_proof on an empty MMR");
+  DevBuf bi, bs, bl, bn;
+  P2MT_TRY(bi.alloc(count * 8));
+  P2MT_TRY(bs.alloc(count * max_siblings * 32));
+  P2MT_TRY(bl.alloc(count * max_siblings));
+  P2MT_TRY(bn.alloc(count * 4));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(bi.p, mmr_indices, count * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemsetAsync(bs.p, 0, count * max_siblings * 32, st));
+  P2MT_HIP(hipMemsetAsync(bl.p, 0, count * max_siblings, st));
+  hipLaunchKernelGGL(k_mmr_proof_batch, dim3(grid_for(count)), dim3(kBlock), 0, st, (const u64*)m->elements, len,
+                     bi.as<u64>(), count, max_siblings, bs.as<u64>(), bl.as<uint8_t>(), bn.as<int32_t>());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipMemcpyAsync(siblings_out, bs.p, count * max_siblings * 32, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(lefts_out, bl.p, count * max_siblings, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(n_siblings_out, bn.p, count * 4, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  for (size_t i = 0; i < count; ++i) {
+    if (n_siblings_out[i] < 0) return p2mt::fail(P2MT_EINVAL, "get_proof: mmr_index out of bounds");
+    if ((size_t)n_siblings_out[i] > max_siblings) return p2mt::fail(P2MT_EINVAL, "get_proof: max_siblings too small");
+  }
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_proof(const p2mt_mmr* m, size_t mmr_index, uint64_t* siblings_out, uint8_t* lefts_out,
+                              int* n_siblings, uint64_t* peaks_out, int* n_peaks, size_t* mmr_size) {
+  if (!siblings_out || !lefts_out || !n_siblings || !peaks_out || !n_peaks) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  const uint64_t idx = mmr_index;
+  int32_t ns = 0;
+  P2MT_TRY(p2mt_mmr_proof_batch(m, &idx, 1, P2MT_MAX_PROOF_LEN, siblings_out, lefts_out, &ns));
+  P2MT_TRY(p2mt_mmr_peaks(m, peaks_out, n_peaks));
+  *n_siblings = ns;
+  if (mmr_size) *mmr_size = p2mt_mmr_len(m);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8_t* lefts, const int32_t* n_siblings,
+                                           size_t max_siblings, const uint64_t* peaks, int n_peaks, const uint64_t* leaves,
+                                           const uint64_t* root, size_t m, int8_t* status_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (m == 0) return P2MT_OK;
+  if (!n_siblings || !peaks || !leaves || !root || !status_out || n_peaks < 0 || n_peaks > 64)
+    return p2mt::fail(P2MT_EINVAL, "bad argument");
+  if (max_siblings && (!siblings || !lefts)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  for (size_t i = 0; i < m; ++i)
+    if (n_siblings[i] < 0 || (size_t)n_siblings[i] > max_siblings) return p2mt::fail(P2MT_EINVAL, "n_siblings out of range");
+  DevBuf bs, bl, bn, bp, bv, br, bb, bo;
+  const size_t ms = max_siblings ? max_siblings : 1;
+  P2MT_TRY(bs.alloc(m * ms * 32));
+  P2MT_TRY(bl.alloc(m * ms));
+  P2MT_TRY(bn.alloc(m * 4));
+  P2MT_TRY(bp.alloc((size_t)(n_peaks ? n_peaks : 1) * 32));
+  P2MT_TRY(bv.alloc(m * 8));
+  P2MT_TRY(br.alloc(32));
+  P2MT_TRY(bb.alloc(32));
+  P2MT_TRY(bo.alloc(m));
+  hipStream_t st = rt().stream;
+  if (max_siblings) {
+    P2MT_HIP(hipMemcpyAsync(bs.p, siblings, m * ms * 32, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(bl.p, lefts, m * ms, hipMemcpyHostToDevice, st));
+  }
+  P2MT_HIP(hipMemcpyAsync(bn.p, n_siblings, m * 4, hipMemcpyHostToDevice, st));
+  if (n_peaks) P2MT_HIP(hipMemcpyAsync(bp.p, peaks, (size_t)n_peaks * 32, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bv.p, leaves, m * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(br.p, root, 32, hipMemcpyHostToDevice, st));
+  P2MT_DISPATCH(k_bag_peaks, 1, 64, (const u64*)bp.as<u64>(), n_peaks, bb.as<u64>());
+  P2MT_DISPATCH(k_mmr_verify_batch, grid_for(m), kBlock, (const u64*)bs.as<u64>(), (const uint8_t*)bl.as<uint8_t>(),
+                (const int32_t*)bn.as<int32_t>(), ms, (const u64*)bp.as<u64>(), n_peaks, (const u64*)bv.as<u64>(),
+                (const u64*)br.as<u64>(), (const u64*)bb.as<u64>(), m, bo.as<int8_t>());
+  P2MT_HIP(hipMemcpyAsync(status_out, bo.p, m, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_proof_verify(const uint64_t* siblings, const uint8_t* lefts, int n_siblings, const uint64_t* peaks,
+                                     int n_peaks, uint64_t leaf, const uint64_t* root, int* result_out) {
+  if (!result_out || n_siblings < 0 || n_siblings > P2MT_MAX_PROOF_LEN) return p2mt::fail(P2MT_EINVAL, "bad argument");
+  int8_t status = 0;
+  const int32_t ns = n_siblings;
+  P2MT_TRY(p2mt_mmr_proof_verify_batch(siblings, lefts, &ns, (size_t)n_siblings, peaks, n_peaks, &leaf, root, 1, &status));
+  if (status == (int8_t)P2MT_ENOTPEAK) return p2mt::fail(P2MT_ENOTPEAK, "MMR_proof::verify: assert!(self.peaks.contains(&next_hash))");
+  *result_out = status;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_combine_shard_roots(const uint64_t* shard_roots, size_t world, uint64_t* top_nodes_out,
+                                            uint64_t* root_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!shard_roots || !root_out || world == 0 || (world & (world - 1))) return p2mt::fail(P2MT_EINVAL, "world must be a power of two");
+  if (world == 1) {
+    memcpy(root_out, shard_roots, 32);
+    return P2MT_OK;
+  }
+  // level-major pairing of the shard roots: world/2 + world/4 + ... + 1 = world-1 nodes
+  DevBuf b;
+  P2MT_TRY(b.alloc((2 * world - 1) * 32));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(b.p, shard_roots, world * 32, hipMemcpyHostToDevice, st));
+  u64* cur = b.as<u64>();
+  for (size_t cnt = world; cnt > 1; cnt /= 2) {
+    P2MT_TRY(p2mt::launch_merkle_level_dev(cur, cur + 4 * cnt, cnt / 2));
+    cur += 4 * cnt;
+  }
+  if (top_nodes_out)
+    P2MT_HIP(hipMemcpyAsync(top_nodes_out, b.as<u64>() + 4 * world, (world - 1) * 32, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(root_out, cur, 32, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}

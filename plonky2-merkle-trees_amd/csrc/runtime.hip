@@ -1,0 +1,102 @@
+// runtime.hip -- process-global runtime of libp2mt_hip.so: device selection, stream, error text, HIP-event timer.
+#include "runtime.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+namespace p2mt {
+
+Runtime& rt() {
+  static Runtime r;
+  return r;
+}
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line) {
+  snprintf(rt().err, sizeof(rt().err), "HIP error '%s' in %s (%s:%d)", hipGetErrorString(e), what, file, line);
+  (void)hipGetLastError();  // clear the sticky error
+  return P2MT_EHIP;
+}
+
+int fail(int code, const char* msg) {
+  snprintf(rt().err, sizeof(rt().err), "%s", msg);
+  return code;
+}
+
+int ensure_init() {
+  if (rt().initialised) return P2MT_OK;
+  return p2mt_init(rt().device);
+}
+
+}  // namespace p2mt
+
+using p2mt::rt;
+
+extern "C" int p2mt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int p2mt_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    return p2mt::fail(P2MT_EHIP, "no HIP device available: this library has no CPU fallback");
+  }
+  if (device < 0 || device >= n) return p2mt::fail(P2MT_EINVAL, "device index out of range");
+  P2MT_HIP(hipSetDevice(device));
+  if (rt().initialised && rt().device == device) return P2MT_OK;
+  rt().device = device;
+  if (rt().ev_start) (void)hipEventDestroy(rt().ev_start);
+  if (rt().ev_stop) (void)hipEventDestroy(rt().ev_stop);
+  P2MT_HIP(hipEventCreate(&rt().ev_start));
+  P2MT_HIP(hipEventCreate(&rt().ev_stop));
+  rt().initialised = true;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_set_stream(void* hip_stream) {
+  rt().stream = static_cast<hipStream_t>(hip_stream);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_sync(void) {
+  P2MT_TRY(p2mt::ensure_init());
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" const char* p2mt_last_error(void) { return rt().err; }
+
+extern "C" int p2mt_set_variant(int mds, int partial) {
+  if (mds < 0 || mds > 1 || partial < 0 || partial > 1) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  rt().mds = mds;
+  rt().partial = partial;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_get_variant(int* mds, int* partial) {
+  if (mds) *mds = rt().mds;
+  if (partial) *partial = rt().partial;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_timer_start(void) {
+  P2MT_TRY(p2mt::ensure_init());
+  P2MT_HIP(hipEventRecord(rt().ev_start, rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_timer_stop(float* elapsed_ms) {
+  P2MT_TRY(p2mt::ensure_init());
+  P2MT_HIP(hipEventRecord(rt().ev_stop, rt().stream));
+  P2MT_HIP(hipEventSynchronize(rt().ev_stop));
+  float ms = 0;
+  P2MT_HIP(hipEventElapsedTime(&ms, rt().ev_start, rt().ev_stop));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return P2MT_OK;
+}

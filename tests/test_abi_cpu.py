@@ -1,0 +1,90 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/p2mt.h declares, pure-host index maths
+matches the reference's tables, and compute entry points fail loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+def test_header_symbols_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "p2mt.h")).read()
+    declared = set(re.findall(r"\b(p2mt_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"p2mt_status"}
+    assert len(declared) >= 45
+    lib = pkg.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export: " + name
+    # the ctypes table covers the whole header (so every test calls through the declared ABI)
+    assert declared == set(pkg._native.SIGNATURES.keys())
+
+
+def test_index_tables(pkg, golden):
+    """merkle_mountain_ranges.rs:280-301 and :307-327 through the product's ABI."""
+    for size, bitmap in golden["reference_vectors"]["heights_bitmap"]["pairs"]:
+        assert pkg.get_heights_bitmap_for_mmr_size(size) == (bitmap, 0)
+    assert pkg.get_heights_bitmap_for_mmr_size(0) == (0, 0)
+    for n, idx in golden["reference_vectors"]["mmr_index"]["pairs"]:
+        assert pkg.get_mmr_index(n) == idx
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.get_mmr_index(1 << 30)  # i32 overflow in the reference (:264)
+
+
+def test_index_maths_matches_oracle(pkg, oracle):
+    rng = np.random.default_rng(0)
+    for x in list(range(0, 300)) + [int(v) for v in rng.integers(0, 1 << 40, size=200)]:
+        assert pkg.get_heights_bitmap_for_mmr_size(x) == oracle.heights_bitmap(x)
+    for n in list(range(0, 300)) + [int(v) for v in rng.integers(0, 1 << 29, size=200)]:
+        assert pkg.get_mmr_index(n) == oracle.get_mmr_index(n)
+    lib = pkg.lib()
+    for L in (0, 1, 7, 8, 1023, 12345678):
+        for h in (0, 1, 5):
+            assert lib.p2mt_mmr_node_pos(L, h) == 2 * L - bin(L).count("1") + h
+    assert lib.p2mt_mmr_shard_first_pos(1 << 23, 3) == 2 * (3 << 23) - 2
+
+
+def test_host_side_tree_indexing(pkg, oracle, golden):
+    """get_merkle_proof / get_in_between_hashes are pure index arithmetic on a level-major tree: check them on
+    the reference's 16-leaf vector (levels taken from the golden fixture, no hashing involved)."""
+    g = golden["reference_vectors"]["tree16"]
+    levels = np.concatenate([np.asarray(l, dtype=np.uint64) for l in g["levels"]])
+    root = np.asarray(g["root"], dtype=np.uint64)
+    tree = pkg.MerkleTree(4, levels, root, 16)
+    for i in range(16):
+        assert np.array_equal(tree.get_merkle_proof(i), oracle.merkle_get_proof(levels, 16, i))
+        assert np.array_equal(tree.get_in_between_hashes(i), oracle.merkle_get_in_between_hashes(levels, root, 16, i))
+    with pytest.raises(pkg.P2mtPanic):
+        tree.get_merkle_proof(16)  # assert!(leaf_index < len) :56
+
+
+def test_no_cpu_fallback(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.P2mtError) as e:
+        pkg.MerkleTree.build([1, 2, 3, 4])
+    assert e.value.code == -3
+    with pytest.raises(pkg.P2mtError):
+        pkg.two_to_one([1, 2, 3, 4], [5, 6, 7, 8])
+    with pytest.raises(pkg.P2mtError):
+        pkg.MMR.new()
+
+
+def test_product_does_not_touch_oracle():
+    """The product path must never import/link anything under oracle/."""
+    pkg_dir = os.path.join(ROOT, "plonky2-merkle-trees_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and "oracle" not in text, (dirpath, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()

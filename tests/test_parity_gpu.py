@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed golden fixtures.
+Bit-exact everywhere (integer work).  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from conftest import splitmix_leaves
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+VARIANTS = [(0, 0), (0, 1), (1, 0), (1, 1)]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.init(0)
+    return p
+
+
+def edge_states():
+    e = [0, 1, P - 1, P, P + 1, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 1 << 63]
+    rows = [[v] * 12 for v in e]
+    rows += [[e[(i + j) % len(e)] for j in range(12)] for i in range(len(e))]
+    return np.array(rows, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_permutation_all_variants(pkg, oracle, variant):
+    pkg.set_variant(*variant)
+    try:
+        rng = np.random.default_rng(3)
+        states = np.concatenate([edge_states(), rng.integers(0, 1 << 64, size=(1500, 12), dtype=np.uint64),
+                                 np.arange(12, dtype=np.uint64)[None]])
+        got = pkg.poseidon_permute_batch(states)
+        exp = oracle.permute_batch(states)
+        assert np.array_equal(got, exp)
+        assert [int(x) for x in got[-1][:2]] == [0xd64e1e3efc5b8e9e, 0x53666633020aaa47]  # SURVEY A.2 KAT
+    finally:
+        pkg.set_variant(1, 0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_reference_golden_trees(pkg, golden, variant):
+    """simple_merkle_tree.rs:136-140, :181-190, :210-211 on the GPU."""
+    pkg.set_variant(*variant)
+    try:
+        for name in ("tree4", "tree16"):
+            g = golden["reference_vectors"][name]
+            t = pkg.MerkleTree.build(g["leaves"])
+            assert t.count_levels == len(g["levels"])
+            for lvl, exp in zip(t.tree, g["levels"]):
+                assert np.array_equal(lvl, np.asarray(exp, dtype=np.uint64))
+            assert np.array_equal(t.root, np.asarray(g["root"], dtype=np.uint64))
+        g = golden["reference_vectors"]["tree4"]
+        t = pkg.MerkleTree.build(g["leaves"])
+        assert np.array_equal(t.get_merkle_proof(0), np.asarray(g["proof_leaf0"], dtype=np.uint64))
+    finally:
+        pkg.set_variant(1, 0)
+
+
+def test_two_to_one_and_hash_modes(pkg, oracle):
+    rng = np.random.default_rng(4)
+    pairs = rng.integers(0, 1 << 64, size=(300, 8), dtype=np.uint64)
+    got = pkg.two_to_one_batch(pairs)
+    for i in range(0, 300, 7):
+        assert np.array_equal(got[i], oracle.two_to_one(pairs[i, :4], pairs[i, 4:]))
+    assert [int(x) for x in pkg.two_to_one([2890852870, 0, 0, 0], [156728478, 0, 0, 0])] == [
+        6678006133445961348, 15827935749738443865, 6295652393730592048, 1546515167911236130]  # reference :138
+    for length in (1, 2, 4, 5, 7, 8, 9, 12, 16, 17, 20, 64, 135):
+        rows = rng.integers(0, 1 << 64, size=(70, length), dtype=np.uint64)
+        rows[0] = np.arange(length, dtype=np.uint64)
+        a, b = pkg.hash_or_noop_batch(rows), pkg.hash_no_pad_batch(rows)
+        for i in range(0, 70, 9):
+            assert np.array_equal(a[i], oracle.hash_or_noop(rows[i]))
+            assert np.array_equal(b[i], oracle.hash_no_pad(rows[i]))
+    assert [int(x) for x in pkg.hash_no_pad(range(135))] == [4848071992462728551, 7985168359107384293,
+                                                             2979147297992328185, 11181256925898874940]  # A.5
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 10, 13])
+def test_merkle_tree_vs_oracle(pkg, oracle, log_n):
+    """config 1 shape (2^10) and neighbours: all levels, root, proofs, verify incl. negatives."""
+    n = 1 << log_n
+    leaves = splitmix_leaves(n, 0x5EED0001)
+    t = pkg.MerkleTree.build(leaves)
+    k, levels, root = oracle.merkle_build(leaves)
+    assert t.count_levels == k
+    assert np.array_equal(t._flat[:2 * n - 2], levels[:2 * n - 2])
+    assert np.array_equal(t.root, root)
+    idxs = sorted(set([0, 1, n // 2, n - 1]))
+    for i in idxs:
+        pr = t.get_merkle_proof(i)
+        assert np.array_equal(pr, oracle.merkle_get_proof(levels, n, i))
+        assert pkg.verify_merkle_proof(leaves[i], i, t.root, pr)
+        assert not pkg.verify_merkle_proof((int(leaves[i]) + 1) % P, i, t.root, pr)  # wrong leaf
+        assert not pkg.verify_merkle_proof(leaves[i], i ^ 1, t.root, pr)             # wrong index
+        assert not pkg.verify_merkle_proof(leaves[i], i, t.tree[0][0], pr)           # wrong root
+
+
+def test_merkle_tree_1024_golden(pkg):
+    t = pkg.MerkleTree.build(np.arange(1024, dtype=np.uint64))
+    assert [int(x) for x in t.root] == [14342627526773219473, 1605964016051269283, 13081912992221981033,
+                                        8024676129753453574]
+
+
+def test_merkle_build_panics(pkg):
+    for bad in ([1], [1, 2, 3], [], list(range(12))):
+        with pytest.raises(pkg.P2mtPanic):
+            pkg.MerkleTree.build(bad)
+
+
+@pytest.mark.parametrize("n", list(range(1, 34)) + [63, 64, 65, 100, 255, 256, 257, 1000, 4099])
+def test_mmr_elements_vs_oracle(pkg, oracle, n):
+    leaves = splitmix_leaves(n, 0x5EED0002 + n)
+    m = pkg.MMR.from_leaves(leaves)
+    om = oracle.mmr(leaves)
+    assert len(m) == len(om) == 2 * n - bin(n).count("1")
+    assert np.array_equal(m.elements, om.elements)
+    assert np.array_equal(m.get_peaks(), om.get_peaks())
+    assert np.array_equal(m.bagging_the_peaks(), om.bagging_the_peaks())
+
+
+def test_mmr_small_goldens(pkg):
+    m = pkg.MMR.from_leaves(np.arange(1000, dtype=np.uint64))
+    assert len(m) == 1994
+    assert [int(x) for x in m.bagging_the_peaks()] == [13493064156419223771, 13520521149426597726,
+                                                       15784220164657724348, 18117589472856137893]
+    pr = m.get_proof_normal_index(777)
+    assert pr.lefts.tolist() == [1, 0, 0, 1, 0, 0, 0]
+    assert pr.siblings[0].tolist() == [776, 0, 0, 0]
+    assert [int(x) for x in pr.siblings[-1]] == [12102538752217177721, 384056655516491996, 15456118281923553820,
+                                                 18216154410072501352]
+    m7 = pkg.MMR.from_leaves(range(1, 8))
+    assert [int(x) for x in m7.bagging_the_peaks()] == [9415449691735571594, 4029994303924475785,
+                                                        1480575162239463180, 1589836677903401482]
+
+
+def test_mmr_incremental_equals_bulk(pkg, oracle):
+    """add_leaf one by one, ragged extends and one bulk extend give the same elements (== the oracle's)."""
+    leaves = splitmix_leaves(777, 0x5EED0003)
+    om = oracle.mmr(leaves)
+    a = pkg.MMR.new()
+    for v in leaves[:70]:
+        a.add_leaf(int(v))
+    assert np.array_equal(a.elements, oracle.mmr(leaves[:70]).elements)
+    b = pkg.MMR.new()
+    cuts = [0, 1, 2, 5, 64, 65, 130, 500, 501, 777]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        b.extend(leaves[lo:hi])
+    assert np.array_equal(b.elements, om.elements)
+    b.extend([])  # empty extend is a no-op
+    assert len(b) == len(om)
+    b.reset()
+    assert len(b) == 0
+    b.extend(leaves)
+    assert np.array_equal(b.elements, om.elements)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 16, 31, 70, 1031])
+def test_mmr_proofs_vs_oracle(pkg, oracle, n):
+    """get_proof / verify for the leaf counts the reference's own tests use (mmr_plonky2_verifier.rs:153-209,
+    _1_recursion.rs:223-257), incl. the panic-on-wrong-leaf quirk (Q5)."""
+    leaves = splitmix_leaves(n, 0x5EED0004 + n)
+    m = pkg.MMR.from_leaves(leaves)
+    om = oracle.mmr(leaves)
+    root = m.bagging_the_peaks()
+    idxs = range(n) if n <= 70 else [0, 1, 100, 512, 1023, 1024, 1030]
+    for i in idxs:
+        pr = m.get_proof_normal_index(i)
+        opr = om.get_proof_normal_index(i)
+        assert pr.mmr_size == opr["mmr_size"]
+        assert np.array_equal(pr.siblings, opr["siblings"])
+        assert np.array_equal(pr.lefts, opr["lefts"])
+        assert np.array_equal(pr.peaks, opr["peaks"])
+        assert pr.verify(int(leaves[i]), root)
+        bad_root = root.copy()
+        bad_root[3] ^= np.uint64(1)
+        assert not pr.verify(int(leaves[i]), bad_root)
+        if len(pr.lefts):
+            with pytest.raises(pkg.P2mtPanic) as e:
+                pr.verify((int(leaves[i]) + 1) % P, root)
+            assert e.value.code == -5
+    # proofs for non-leaf / arbitrary mmr indices follow the reference's walk too
+    for idx in range(len(om)):
+        if n <= 31:
+            pr, opr = m.get_proof(idx), om.get_proof(idx)
+            assert np.array_equal(pr.siblings, opr["siblings"]) and np.array_equal(pr.lefts, opr["lefts"])
+    with pytest.raises(pkg.P2mtPanic):
+        m.get_proof(len(om))
+
+
+def test_mmr_empty_panics(pkg):
+    m = pkg.MMR.new()
+    assert len(m) == 0
+    with pytest.raises(pkg.P2mtPanic):
+        m.get_peaks()
+    with pytest.raises(pkg.P2mtPanic):
+        m.bagging_the_peaks()
+
+
+def test_config2_mmr_2pow20(pkg, oracle):
+    """BASELINE config 2: 2^20-leaf MMR build + get_proof for i in {0, 1, 777777, 2^20-1} + verify."""
+    n = 1 << 20
+    leaves = splitmix_leaves(n, 0x5EED0000 + 2)
+    m = pkg.MMR.from_leaves(leaves)
+    om = oracle.mmr(leaves)
+    assert len(m) == 2 * n - 1
+    assert np.array_equal(m.elements, om.elements)
+    root = m.bagging_the_peaks()
+    assert np.array_equal(root, om.bagging_the_peaks())
+    assert np.array_equal(root, m.copy_elements(len(m) - 1, 1)[0])  # single peak => root == last element (Q2)
+    for i in (0, 1, 777777, n - 1):
+        pr = m.get_proof_normal_index(i)
+        opr = om.get_proof_normal_index(i)
+        assert len(pr.lefts) == 20 and len(pr.peaks) == 1
+        assert np.array_equal(pr.siblings, opr["siblings"]) and np.array_equal(pr.lefts, opr["lefts"])
+        assert pr.lefts.tolist() == [(i >> b) & 1 for b in range(20)]  # leaf-index bits, LSB first (A.4)
+        assert pr.verify(int(leaves[i]), root)
+
+
+def test_batched_proofs_and_verify(pkg, oracle):
+    n = 5000
+    leaves = splitmix_leaves(n, 0x5EED0005)
+    m = pkg.MMR.from_leaves(leaves)
+    om = oracle.mmr(leaves)
+    idx = np.array([0, 1, 2, 4095, 4096, 4999, 777], dtype=np.uint64)
+    mmr_idx = np.array([pkg.get_mmr_index(int(i)) for i in idx], dtype=np.uint64)
+    sib, lefts, ns = m.get_proof_batch(mmr_idx, max_siblings=16)
+    for t, i in enumerate(idx):
+        opr = om.get_proof_normal_index(int(i))
+        assert ns[t] == len(opr["lefts"])
+        assert np.array_equal(sib[t, :ns[t]], opr["siblings"]) and np.array_equal(lefts[t, :ns[t]], opr["lefts"])
+    peaks, root = m.get_peaks(), m.bagging_the_peaks()
+    st = pkg.verify_proof_batch(sib, lefts, ns, peaks, leaves[idx.astype(np.int64)], root)
+    assert st.tolist() == [1] * len(idx)
+    wrong = leaves[idx.astype(np.int64)].copy()
+    wrong[2] = (int(wrong[2]) + 1) % P
+    st = pkg.verify_proof_batch(sib, lefts, ns, peaks, wrong, root)
+    assert st.tolist() == [1, 1, -5, 1, 1, 1, 1]
+    bad_root = root.copy(); bad_root[0] ^= np.uint64(2)
+    assert pkg.verify_proof_batch(sib, lefts, ns, peaks, leaves[idx.astype(np.int64)], bad_root).tolist() == [0] * 7
+
+
+def test_full_size_properties_2pow24(pkg):
+    """BASELINE headline size: properties that need no oracle run (it would take minutes on one core)."""
+    n = 1 << 24
+    leaves = splitmix_leaves(n, 0x5EED0000 + 24)
+    m = pkg.MMR.new()
+    m.reserve(n)
+    m.extend(leaves)
+    assert len(m) == 2 * n - 1
+    root = m.bagging_the_peaks()
+    assert np.array_equal(root, m.copy_elements(len(m) - 1, 1)[0])
+    # (1) 512 random internal nodes equal two_to_one(children) recomputed by the independent batch kernel
+    rng = np.random.default_rng(9)
+    hs = rng.integers(1, 24, size=512)
+    js = np.array([rng.integers(0, n >> h) for h in hs])
+    last = ((js + 1) << hs) - 1
+    pos = np.array([2 * int(L) - bin(int(L)).count("1") + int(h) for L, h in zip(last, hs)])
+    parents = np.stack([m.copy_elements(int(p), 1)[0] for p in pos])
+    lefts = np.stack([m.copy_elements(int(p) - (1 << int(h)), 1)[0] for p, h in zip(pos, hs)])
+    rights = np.stack([m.copy_elements(int(p) - 1, 1)[0] for p in pos])
+    assert np.array_equal(pkg.two_to_one_batch(np.concatenate([lefts, rights], axis=1)), parents)
+    # (2) leaf digests are the no-op pad at 2i - popcount(i)
+    for i in (0, 1, 12345678, n - 1):
+        assert m.copy_elements(2 * i - bin(i).count("1"), 1)[0].tolist() == [int(leaves[i]), 0, 0, 0]
+    # (3) 256 random proofs verify against the root (batched path), and a corrupted leaf is rejected
+    idx = rng.integers(0, n, size=256)
+    mmr_idx = np.array([pkg.get_mmr_index(int(i)) for i in idx], dtype=np.uint64)
+    sib, lf, ns = m.get_proof_batch(mmr_idx, max_siblings=24)
+    assert (ns == 24).all()
+    st = pkg.verify_proof_batch(sib, lf, ns, root[None], leaves[idx], root)
+    assert (st == 1).all()
+    # (4) the first 2^16 leaves' subtree equals an independently built 2^16 MMR (prefix property of post-order)
+    sub = pkg.MMR.from_leaves(leaves[:1 << 16])
+    assert np.array_equal(sub.elements, m.copy_elements(0, len(sub)))
+    # (5) determinism: rebuilding gives identical bytes
+    m2 = pkg.MMR.from_leaves(leaves)
+    assert np.array_equal(m2.bagging_the_peaks(), root)
