@@ -1,0 +1,125 @@
+"""GPU parity for the commit step (NTT / IFFT / coset LDE / wide-leaf sponge / Merkle cap /
+PolynomialBatch) against the oracle.  The oracle's conventions here are PARITY UNPINNED (no reference vector
+exists); values are exact field elements, so agreement is bit-exact."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.init(0)
+    return p
+
+
+def rand(shape, seed):
+    return np.random.default_rng(seed).integers(0, P, size=shape, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 9, 11, 12, 13, 15])
+def test_fft_ifft_vs_oracle(pkg, oracle, log_n):
+    n_polys = 5 if log_n < 13 else 2
+    a = rand((n_polys, 1 << log_n), 100 + log_n)
+    a[0, :] = np.arange(1, (1 << log_n) + 1, dtype=np.uint64)
+    f = pkg.fft(a)
+    for j in range(n_polys):
+        assert np.array_equal(f[j], oracle.fft(a[j]))
+    g = pkg.ifft(a)
+    for j in range(n_polys):
+        assert np.array_equal(g[j], oracle.ifft(a[j]))
+    assert np.array_equal(pkg.ifft(f), a)  # round trip
+
+
+def test_fft_survey_kat(pkg):
+    f = pkg.fft(np.arange(1, 9, dtype=np.uint64)[None])[0]
+    assert [int(x) for x in f] == [36, 18445622567621360637, 18445618169507741693, 1130298020461564,
+                                   18446744069414584317, 18445613771394122749, 1125899906842620, 1121501793223676]
+
+
+def test_fft_noncanonical_inputs(pkg, oracle):
+    a = np.array([[P, P + 1, 0xFFFFFFFFFFFFFFFF, 0, 1, P - 1, 7, 1 << 63]], dtype=np.uint64)
+    assert np.array_equal(pkg.fft(a)[0], oracle.fft(a[0]))
+
+
+@pytest.mark.parametrize("log_n,rate_bits", [(0, 3), (1, 3), (3, 3), (6, 3), (9, 3), (12, 3), (5, 1), (4, 0), (6, 4)])
+def test_coset_lde_vs_oracle(pkg, oracle, log_n, rate_bits):
+    c = rand((4, 1 << log_n), 200 + log_n)
+    c[0, :] = np.arange(1, (1 << log_n) + 1, dtype=np.uint64)
+    out = pkg.coset_lde(c, rate_bits)
+    for j in range(4):
+        assert np.array_equal(out[j], oracle.coset_lde(c[j], rate_bits))
+
+
+def test_large_fft_properties(pkg):
+    """2^20-point transforms (global stages + LDS tail): round trip, linearity and a direct evaluation."""
+    log_n = 20
+    a, b = rand((1, 1 << log_n), 31), rand((1, 1 << log_n), 32)
+    fa, fb = pkg.fft(a), pkg.fft(b)
+    assert np.array_equal(pkg.ifft(fa), a)
+    s = ((a.astype(object) + b.astype(object)) % P).astype(np.uint64)
+    fs = pkg.fft(s)
+    assert np.array_equal(fs, ((fa.astype(object) + fb.astype(object)) % P).astype(np.uint64))
+    assert int(fa[0, 0]) == int(sum(int(x) for x in a[0]) % P)  # f(1) = sum of coefficients
+
+
+@pytest.mark.parametrize("width", [1, 3, 4, 5, 8, 9, 16, 20, 135])
+@pytest.mark.parametrize("cap_height", [0, 2, 4])
+def test_merkle_cap_commit_vs_oracle(pkg, oracle, width, cap_height):
+    leaves = rand((64, width), 300 + width)
+    t = pkg.MerkleCapTree.new(leaves, cap_height)
+    digests, cap = oracle.merkle_cap_commit(leaves, cap_height)
+    assert np.array_equal(t.cap, cap)
+    assert np.array_equal(t.digests, digests)
+
+
+def test_merkle_cap_edge_shapes(pkg, oracle):
+    leaves = rand((16, 7), 77)
+    for cap_height in (4,):  # cap == leaf digests
+        t = pkg.MerkleCapTree.new(leaves, cap_height)
+        _, cap = oracle.merkle_cap_commit(leaves, cap_height)
+        assert np.array_equal(t.cap, cap) and t.digests.shape[0] == 0
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.MerkleCapTree.new(leaves, 5)
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.MerkleCapTree.new(rand((12, 3), 1), 2)
+
+
+def test_polynomial_batch_mini_kat(pkg):
+    """SURVEY A.5 mini from_coeffs."""
+    polys = np.array([[j + 1 + i for i in range(8)] for j in range(3)], dtype=np.uint64)
+    pb = pkg.PolynomialBatch.from_coeffs(polys, 3, 2)
+    assert [int(x) for x in pb.merkle_tree.leaves[1]] == [18446744069408729445, 18446744069408008845,
+                                                          18446744069407288245]
+    assert [int(x) for x in pb.merkle_tree.cap[0]] == [6767426713459994308, 4464047079632709065,
+                                                       16885200355009179906, 9438656522865686595]
+    assert [int(x) for x in pb.merkle_tree.cap[3]] == [13903821440632216401, 12504631715270832321,
+                                                       9898450178365270810, 7220911749143292772]
+
+
+# config 3 (d = 6) and config 4 outer circuit (d = 12) commit shapes: wires 135, Z/partial products 20, quotient 16
+@pytest.mark.parametrize("n_polys,log_n,is_values", [(135, 6, True), (20, 6, True), (16, 6, False), (2, 3, True),
+                                                     (135, 12, True), (20, 12, True), (16, 12, False)])
+def test_polynomial_batch_commit_vs_oracle(pkg, oracle, n_polys, log_n, is_values):
+    polys = rand((n_polys, 1 << log_n), 400 + n_polys + log_n)
+    pb = (pkg.PolynomialBatch.from_values if is_values else pkg.PolynomialBatch.from_coeffs)(polys)
+    leaves, digests, cap = oracle.polynomial_batch_commit(polys, is_values, 3, 4)
+    assert np.array_equal(pb.merkle_tree.cap, cap)
+    assert np.array_equal(pb.merkle_tree.leaves, leaves)
+    assert np.array_equal(pb.merkle_tree.digests, digests)
+    # without materialising leaves the cap is identical
+    pb2 = (pkg.PolynomialBatch.from_values if is_values else pkg.PolynomialBatch.from_coeffs)(polys, want_leaves=False)
+    assert np.array_equal(pb2.merkle_tree.cap, cap)
+    # a Merkle path re-hashed with the independent two_to_one batch kernel reaches the right cap entry
+    idx = 5 % leaves.shape[0]
+    path = pb.merkle_tree.prove(idx)
+    cur = pkg.hash_or_noop(leaves[idx])
+    i = idx
+    for sib in path:
+        cur = pkg.two_to_one(cur, sib) if i % 2 == 0 else pkg.two_to_one(sib, cur)
+        i >>= 1
+    assert np.array_equal(cur, cap[i])
