@@ -25,11 +25,17 @@ class ShardedMMR:
     def __init__(self, pkg, n_local, rank=0, world=1, dist=None):
         self.n_local, self.rank, self.world, self.dist = n_local, rank, world, dist
         self.k_local, self.g = _log2(n_local), _log2(world)
-        self.local = MMR()
-        self.local.reserve(n_local)
+        self._local = None        # device-resident shard, created on first use (needs a GPU)
         self.shard_roots = None   # (world, 4) after a build
         self.top_nodes = None     # (world-1, 4) level-major bottom-up
         self.root = None
+
+    @property
+    def local(self):
+        if self._local is None:
+            self._local = MMR()
+            self._local.reserve(self.n_local)
+        return self._local
 
     # ---- geometry (pure index maths)
     def first_pos(self, rank=None):
