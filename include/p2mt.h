@@ -50,10 +50,14 @@ int p2mt_device_count(void);            /* number of visible HIP devices (0 => n
 int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches (NULL = default stream) */
 int p2mt_sync(void);                    /* hipStreamSynchronize on the library stream */
 const char *p2mt_last_error(void);
-/* Kernel variant for the Poseidon permutation: mds 0 = v_mad_u64_u32, 1 = v_dot2_u32_u16;
- * partial 0 = spec-form partial rounds, 1 = sparse "fast" form.  All variants are bit-identical. */
+/* Kernel variant for the Poseidon permutation.  mds 2 (default) = issue-optimised path (constants folded into the
+ * MDS mad chains, carry-mask reduction, sticky rare-event flag + exact fallback); mds 0 / 1 = exact reference
+ * variants (v_mad_u64_u32 / v_dot2_u32_u16 MDS) with partial 0 = spec-form, 1 = sparse partial rounds.
+ * All variants are bit-identical. */
 int p2mt_set_variant(int mds, int partial);
 int p2mt_get_variant(int *mds, int *partial);
+/* Debug/test knob: make every wave of the mds=2 path take its exact fallback (results must not change). */
+int p2mt_debug_force_fallback(int on);
 /* HIP-event timer on the library stream (what bench.py uses for per-launch durations). */
 int p2mt_timer_start(void);
 int p2mt_timer_stop(float *elapsed_ms); /* records + synchronises the stop event */

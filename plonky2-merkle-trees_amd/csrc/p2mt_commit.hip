@@ -20,7 +20,7 @@
 //     coalesced 8-byte loads), so hashing never needs the transposed leaf-major matrix; the transpose to
 //     plonky2's leaf-major `leaves` is only produced when the caller asks for it.
 //   All of it is HBM/LDS-bound integer work: no MFMA.
-#include "poseidon.hip.h"
+#include "poseidon_fast.hip.h"
 #include "runtime.h"
 
 #include <map>
@@ -149,21 +149,35 @@ __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in
 // hash_or_noop of leaf i = column i of the poly-major matrix: lane i reads in[p * n_pts + i] (coalesced).
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__ in, size_t w, size_t n_pts,
-                                                         u64* __restrict__ digests) {
+                                                         u64* __restrict__ digests, p2mt::PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_pts) return;
   u64 s[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) s[k] = 0;
   if (w <= 4) {  // no permutation: zero-padded copy
-    for (size_t p = 0; p < w; ++p) s[p] = gl::canon(in[p * n_pts + i]);
+    for (size_t p = 0; p < w; ++p) s[p] = in[p * n_pts + i];
   } else {
-#pragma unroll 1
-    for (size_t off = 0; off < w; off += 8) {
+    auto run = [&](auto fast) -> u64 {
+      u64 sticky = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (off + k < w) s[k] = in[(off + k) * n_pts + i];
-      poseidon::permute<M, PR>(s);
+      for (int k = 0; k < 12; ++k) s[k] = 0;
+#pragma unroll 1
+      for (size_t off = 0; off < w; off += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (off + k < w) s[k] = in[(off + k) * n_pts + i];
+        if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute(s, ctx.rc);
+        else if constexpr (M == 2) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+        else poseidon::permute<M, PR>(s);
+      }
+      return sticky;
+    };
+    if constexpr (M == 2) {
+      const u64 sticky = run(std::true_type{}) | ctx.force_fallback;
+      if (__builtin_expect(sticky != 0, 0)) run(std::false_type{});
+    } else {
+      run(std::false_type{});
     }
   }
   ulonglong2* q = reinterpret_cast<ulonglong2*>(digests + 4 * i);
@@ -256,16 +270,18 @@ int ntt_dif_dev(u64* d_data, unsigned log_n, size_t n_polys, int inverse) {
 using p2mt::DevBuf;
 using p2mt::rt;
 
-#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                        \
-  do {                                                                                                 \
-    hipStream_t st_ = p2mt::rt().stream;                                                               \
-    switch (p2mt::rt().mds * 2 + p2mt::rt().partial) {                                                 \
-      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-    }                                                                                                  \
-    P2MT_LAUNCH_CHECK();                                                                               \
+#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                              \
+  do {                                                                                                       \
+    hipStream_t st_ = p2mt::rt().stream;                                                                     \
+    const p2mt::PermCtx ctx_ = p2mt::perm_ctx();                                                             \
+    switch (p2mt::rt().mds * 2 + (p2mt::rt().mds == 2 ? 0 : p2mt::rt().partial)) {                          \
+      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 3: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      default: hipLaunchKernelGGL((KERNEL<2, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+    }                                                                                                        \
+    P2MT_LAUNCH_CHECK();                                                                                     \
   } while (0)
 
 // =================================================================== fft_with_options / ifft_with_options

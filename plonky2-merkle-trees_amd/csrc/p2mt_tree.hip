@@ -8,7 +8,7 @@
 // One lane computes one node (poseidon.hip.h); a level of the tree is one launch.  The MMR is built
 // level-synchronously straight into its post-order positions: the node of height h whose last leaf is L
 // lives at 2L - popcount(L) + h, its right child at pos-1, its left child at pos-2^h.
-#include "poseidon.hip.h"
+#include "poseidon_fast.hip.h"
 #include "runtime.h"
 
 #include <string.h>
@@ -39,42 +39,97 @@ GL_DEV void store_hash(u64* p, const u64 (&h)[4]) {
 
 GL_DEV size_t node_pos(size_t last_leaf, unsigned h) { return 2 * last_leaf - (size_t)__popcll(last_leaf) + h; }
 
+using p2mt::PermCtx;
+constexpr int IMPL_FAST = 2;  // M == 2: poseidon_fast with exact fallback; M in {0,1}: exact variants of poseidon.hip.h
+
+// One permutation whose input can be re-materialised: `load` fills the state (it is called again if the fast
+// path raised its sticky flag, so that no copy of the input has to stay live in VGPRs).
+template <int M, int PR, typename Load>
+GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load) {
+  load(s);
+  if constexpr (M == IMPL_FAST) {
+    const u64 sticky = poseidon_fast::permute(s, ctx.rc) | ctx.force_fallback;
+    if (__builtin_expect(sticky != 0, 0)) {
+      load(s);
+      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+    }
+  } else {
+    poseidon::permute<M, PR>(s);
+  }
+}
+
+// two_to_one(l, r) with l/r produced by `load_lr`
+template <int M, int PR, typename LoadLR>
+GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr) {
+  u64 s[12];
+  permute_reloadable<M, PR>(s, ctx, [&](u64 (&st)[12]) {
+    u64 l[4], r[4];
+    load_lr(l, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      st[k] = l[k];
+      st[4 + k] = r[k];
+      st[8 + k] = 0;
+    }
+  });
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = gl::canon(s[k]);
+}
+
 // ---------------------------------------------------------------- stateless batch kernels
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+__global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
+                                                          PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   u64 s[12];
+  permute_reloadable<M, PR>(s, ctx, [&](u64 (&st)[12]) {
 #pragma unroll
-  for (int k = 0; k < 12; ++k) s[k] = in[12 * i + k];
-  poseidon::permute<M, PR>(s);
+    for (int k = 0; k < 12; ++k) st[k] = in[12 * i + k];
+  });
 #pragma unroll
   for (int k = 0; k < 12; ++k) out[12 * i + k] = gl::canon(s[k]);
 }
 
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n) {
+__global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
+                                                             PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  u64 l[4], r[4], o[4];
-  load_hash(in + 8 * i, l);
-  load_hash(in + 8 * i + 4, r);
-  poseidon::two_to_one<M, PR>(l, r, o);
+  u64 o[4];
+  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+    load_hash(in + 8 * i, l);
+    load_hash(in + 8 * i + 4, r);
+  });
   store_hash(out + 4 * i, o);
 }
 
 // hash_or_noop / hash_no_pad of `len`-element rows: overwrite-mode sponge, rate 8, one row per lane.
-template <int M, int PR>
-GL_DEV void sponge_row(const u64* __restrict__ row, size_t len, u64 (&o)[4]) {
+// `get(k)` returns element k of the row.  With the fast variant the whole row is redone exactly if any of its
+// permutations raised the sticky flag.
+template <int M, int PR, typename Get>
+GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
   u64 s[12];
+  auto run = [&](auto fast) -> u64 {
+    u64 sticky = 0;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) s[k] = 0;
+    for (int k = 0; k < 12; ++k) s[k] = 0;
 #pragma unroll 1
-  for (size_t off = 0; off < len; off += 8) {
+    for (size_t off = 0; off < len; off += 8) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (off + k < len) s[k] = row[off + k];
-    poseidon::permute<M, PR>(s);
+      for (int k = 0; k < 8; ++k)
+        if (off + k < len) s[k] = get(off + k);
+      if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute(s, ctx.rc);
+      else if constexpr (M == IMPL_FAST) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+      else poseidon::permute<M, PR>(s);
+    }
+    return sticky;
+  };
+  if constexpr (M == IMPL_FAST) {
+    const u64 sticky = run(std::true_type{}) | ctx.force_fallback;
+    if (__builtin_expect(sticky != 0, 0)) run(std::false_type{});
+  } else {
+    run(std::false_type{});
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = gl::canon(s[k]);
@@ -82,7 +137,7 @@ GL_DEV void sponge_row(const u64* __restrict__ row, size_t len, u64 (&o)[4]) {
 
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
-                                                      u64* __restrict__ out) {
+                                                      u64* __restrict__ out, PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   u64 o[4];
@@ -90,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = (size_t)k < len ? gl::canon(in[i * len + k]) : 0;
   } else {
-    sponge_row<M, PR>(in + i * len, len, o);
+    const u64* row = in + i * len;
+    sponge<M, PR>(len, ctx, o, [&](size_t k) { return row[k]; });
   }
   store_hash(out + 4 * i, o);
 }
@@ -106,13 +162,15 @@ __global__ __launch_bounds__(kBlock) void k_leaf_digests(const u64* __restrict__
 
 // next_level_hashes (:21-25): out[j] = two_to_one(in[2j], in[2j+1])
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out) {
+__global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+                                                         PermCtx ctx) {
   const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (j >= n_out) return;
-  u64 l[4], r[4], o[4];
-  load_hash(in + 8 * j, l);
-  load_hash(in + 8 * j + 4, r);
-  poseidon::two_to_one<M, PR>(l, r, o);
+  u64 o[4];
+  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+    load_hash(in + 8 * j, l);
+    load_hash(in + 8 * j + 4, r);
+  });
   store_hash(out + 4 * j, o);
 }
 
@@ -121,22 +179,26 @@ template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_verify_merkle_proof(const u64* __restrict__ leaves, const u64* __restrict__ idx,
                                                                 const u64* __restrict__ roots,
                                                                 const u64* __restrict__ hashes, size_t n_hashes, size_t m,
-                                                                uint8_t* __restrict__ result) {
+                                                                uint8_t* __restrict__ result, PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
   u64 cur[4] = {gl::canon(leaves[i]), 0, 0, 0};
   u64 index = idx[i];
 #pragma unroll 1
   for (size_t k = 0; k < n_hashes; ++k) {
-    u64 sib[4], l[4], r[4];
-    load_hash(hashes + 4 * (i * n_hashes + k), sib);
     const bool even = (index & 1) == 0;
+    u64 nxt[4];
+    two_to_one_r<M, PR>(ctx, nxt, [&](u64 (&l)[4], u64 (&r)[4]) {
+      u64 sib[4];
+      load_hash(hashes + 4 * (i * n_hashes + k), sib);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      l[t] = even ? cur[t] : sib[t];
-      r[t] = even ? sib[t] : cur[t];
-    }
-    poseidon::two_to_one<M, PR>(l, r, cur);
+      for (int t = 0; t < 4; ++t) {
+        l[t] = even ? cur[t] : sib[t];
+        r[t] = even ? sib[t] : cur[t];
+      }
+    });
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
     index >>= 1;
   }
   u64 root[4];
@@ -160,16 +222,77 @@ __global__ __launch_bounds__(kBlock) void k_mmr_leaves(const u64* __restrict__ l
 
 // the carry chain of add_leaf (:106-119), level-synchronous: all height-h nodes j in [j0, j1)
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_mmr_level(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1) {
+__global__ __launch_bounds__(kBlock) void k_mmr_level(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
+                                                      PermCtx ctx) {
   const size_t j = j0 + (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (j >= j1) return;
   const size_t last_leaf = ((j + 1) << h) - 1;
   const size_t pos = node_pos(last_leaf, h);
-  u64 l[4], r[4], o[4];
-  load_hash(elements + 4 * (pos - ((size_t)1 << h)), l);
-  load_hash(elements + 4 * (pos - 1), r);
-  poseidon::two_to_one<M, PR>(l, r, o);
+  u64 o[4];
+  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+    load_hash(elements + 4 * (pos - ((size_t)1 << h)), l);
+    load_hash(elements + 4 * (pos - 1), r);
+  });
   store_hash(elements + 4 * pos, o);
+}
+
+// Fused multi-level build of aligned tiles: one workgroup takes 2^kTileLog consecutive nodes of height h0 (raw
+// leaves when h0 == 0) and produces the next n_levels levels, handing digests from level to level through LDS
+// (ping-pong buffers, 48 KB) and writing every node once to its post-order slot.  HBM traffic is the
+// algorithmic minimum: 8 B read per leaf, 32 B written per node.  The caller stops a stage while every level
+// still fills whole waves (2^(kTileLog - n_levels) >= 64) except in the tiny top stages.
+constexpr unsigned kTileLog = 11;
+
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ leaves, size_t leaf_base,
+                                                     u64* __restrict__ elements, unsigned h0, unsigned n_levels,
+                                                     size_t tile0, PermCtx ctx) {
+  __shared__ __attribute__((aligned(16))) u64 buf0[4 << (kTileLog - 1)];
+  __shared__ __attribute__((aligned(16))) u64 buf1[4 << (kTileLog - 2)];
+  const size_t tile = tile0 + blockIdx.x;
+  {  // first level: children come from HBM (leaves: coalesced 16 B per lane; nodes: 32-B records)
+    const unsigned h = h0 + 1;
+    for (unsigned i = threadIdx.x; i < (1u << (kTileLog - 1)); i += kBlock) {
+      const size_t j = (tile << (kTileLog - 1)) + i;
+      const size_t pos = node_pos(((j + 1) << h) - 1, h);
+      u64 o[4];
+      if (h0 == 0) {
+        const u64* lp = leaves + (2 * j - leaf_base);  // 8-byte aligned only (leaf_base may be odd)
+        const u64 l[4] = {gl::canon(lp[0]), 0, 0, 0}, r[4] = {gl::canon(lp[1]), 0, 0, 0};
+        store_hash(elements + 4 * (pos - 2), l);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
+        store_hash(elements + 4 * (pos - 1), r);
+        two_to_one_r<M, PR>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+          ll[0] = gl::canon(lp[0]); ll[1] = ll[2] = ll[3] = 0;
+          rr[0] = gl::canon(lp[1]); rr[1] = rr[2] = rr[3] = 0;
+        });
+      } else {
+        two_to_one_r<M, PR>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+          load_hash(elements + 4 * (pos - ((size_t)1 << h)), ll);
+          load_hash(elements + 4 * (pos - 1), rr);
+        });
+      }
+      store_hash(elements + 4 * pos, o);
+      store_hash(buf0 + 4 * i, o);
+    }
+  }
+  __syncthreads();
+  for (unsigned lvl = 2; lvl <= n_levels; ++lvl) {
+    const unsigned h = h0 + lvl;
+    const u64* src = (lvl & 1) ? buf1 : buf0;
+    u64* dst = (lvl & 1) ? buf0 : buf1;
+    for (unsigned i = threadIdx.x; i < (1u << (kTileLog - lvl)); i += kBlock) {
+      const size_t j = (tile << (kTileLog - lvl)) + i;
+      const size_t pos = node_pos(((j + 1) << h) - 1, h);
+      u64 o[4];
+      two_to_one_r<M, PR>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+        load_hash(src + 8 * i, ll);
+        load_hash(src + 8 * i + 4, rr);
+      });
+      store_hash(elements + 4 * pos, o);
+      store_hash(dst + 4 * i, o);
+    }
+    __syncthreads();
+  }
 }
 
 struct PosList {
@@ -180,7 +303,7 @@ struct PosList {
 // get_peaks (:179-200) gather + bagging_the_peaks (:122-127): one lane (<= 32 permutations)
 template <int M, int PR>
 __global__ void k_mmr_peaks_root(const u64* __restrict__ elements, PosList pl, u64* __restrict__ peaks_out,
-                                 u64* __restrict__ root_out) {
+                                 u64* __restrict__ root_out, PermCtx ctx) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int i = 0; i < pl.n; ++i) {
     u64 h[4];
@@ -191,21 +314,21 @@ __global__ void k_mmr_peaks_root(const u64* __restrict__ elements, PosList pl, u
   if (pl.n == 1) {  // hash_or_noop of 4 elements: the peak itself (Quirk Q2)
     load_hash(peaks_out, o);
   } else {
-    sponge_row<M, PR>(peaks_out, (size_t)pl.n * 4, o);
+    sponge<M, PR>((size_t)pl.n * 4, ctx, o, [&](size_t k) { return peaks_out[k]; });
   }
   store_hash(root_out, o);
 }
 
 // bagging of caller-supplied peaks (MMR_proof::verify :248-249)
 template <int M, int PR>
-__global__ void k_bag_peaks(const u64* __restrict__ peaks, int n_peaks, u64* __restrict__ root_out) {
+__global__ void k_bag_peaks(const u64* __restrict__ peaks, int n_peaks, u64* __restrict__ root_out, PermCtx ctx) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   u64 o[4];
   if (n_peaks * 4 <= 4) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = k < n_peaks * 4 ? gl::canon(peaks[k]) : 0;
   } else {
-    sponge_row<M, PR>(peaks, (size_t)n_peaks * 4, o);
+    sponge<M, PR>((size_t)n_peaks * 4, ctx, o, [&](size_t k) { return peaks[k]; });
   }
   store_hash(root_out, o);
 }
@@ -274,22 +397,26 @@ __global__ __launch_bounds__(kBlock) void k_mmr_verify_batch(const u64* __restri
                                                              const u64* __restrict__ peaks, int n_peaks,
                                                              const u64* __restrict__ leaves, const u64* __restrict__ root,
                                                              const u64* __restrict__ bagged, size_t m,
-                                                             int8_t* __restrict__ status) {
+                                                             int8_t* __restrict__ status, PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
   u64 cur[4] = {gl::canon(leaves[i]), 0, 0, 0};
   const int ns = n_sib[i];
 #pragma unroll 1
   for (int k = 0; k < ns; ++k) {
-    u64 s[4], l[4], r[4];
-    load_hash(sib + 4 * (i * max_sib + k), s);
     const bool on_left = lefts[i * max_sib + k] != 0;
+    u64 nxt[4];
+    two_to_one_r<M, PR>(ctx, nxt, [&](u64 (&l)[4], u64 (&r)[4]) {
+      u64 s[4];
+      load_hash(sib + 4 * (i * max_sib + k), s);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      l[t] = on_left ? s[t] : cur[t];
-      r[t] = on_left ? cur[t] : s[t];
-    }
-    poseidon::two_to_one<M, PR>(l, r, cur);
+      for (int t = 0; t < 4; ++t) {
+        l[t] = on_left ? s[t] : cur[t];
+        r[t] = on_left ? cur[t] : s[t];
+      }
+    });
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
   }
   bool found = false;
   for (int p = 0; p < n_peaks; ++p) {
@@ -312,17 +439,19 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 
 }  // namespace
 
-// Launch KERNEL<mds, partial> for the runtime-selected variant.
-#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                        \
-  do {                                                                                                 \
-    hipStream_t st_ = p2mt::rt().stream;                                                               \
-    switch (p2mt::rt().mds * 2 + p2mt::rt().partial) {                                                 \
-      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__); break; \
-    }                                                                                                  \
-    P2MT_LAUNCH_CHECK();                                                                               \
+// Launch KERNEL<mds, partial> for the runtime-selected variant; the PermCtx is appended as the last argument.
+#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                              \
+  do {                                                                                                       \
+    hipStream_t st_ = p2mt::rt().stream;                                                                     \
+    const p2mt::PermCtx ctx_ = p2mt::perm_ctx();                                                             \
+    switch (p2mt::rt().mds * 2 + (p2mt::rt().mds == 2 ? 0 : p2mt::rt().partial)) {                          \
+      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 3: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      default: hipLaunchKernelGGL((KERNEL<2, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+    }                                                                                                        \
+    P2MT_LAUNCH_CHECK();                                                                                     \
   } while (0)
 
 namespace p2mt {
@@ -603,6 +732,13 @@ extern "C" int p2mt_mmr_reset(p2mt_mmr* m) {
   return P2MT_OK;
 }
 
+// generic level kernel over [j0, j1) of height h
+static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
+  if (j1 <= j0) return P2MT_OK;
+  P2MT_DISPATCH(k_mmr_level, grid_for(j1 - j0), kBlock, m->elements, h, j0, j1);
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
@@ -611,12 +747,48 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
   const size_t n0 = m->n_leaves, n1 = n0 + k;
   if (n1 < n0 || (n1 >> 40)) return p2mt::fail(P2MT_ERANGE, "MMR too large");
   P2MT_TRY(mmr_grow(m, mmr_len_for(n1)));
-  hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(k)), dim3(kBlock), 0, rt().stream, d_leaves, m->elements, n0, k);
-  P2MT_LAUNCH_CHECK();
-  // height-h node j is new iff it ends after leaf n0 and is complete iff it ends by n1: j in [n0>>h, n1>>h)
-  for (unsigned h = 1; (n1 >> h) > (n0 >> h); ++h) {
-    const size_t j0 = n0 >> h, j1 = n1 >> h;
-    P2MT_DISPATCH(k_mmr_level, grid_for(j1 - j0), kBlock, m->elements, h, j0, j1);
+  hipStream_t st = rt().stream;
+  // A height-h node j is new iff it ends after leaf n0 and complete iff it ends by n1: j in [n0>>h, n1>>h).
+  // Stages of fused tiles cover the aligned bulk; the ragged edges (and the thin top of the tree) use the
+  // one-level kernel.  Stage s starts at height h0 and fuses n_lev levels of 2^(h0+kTileLog)-leaf tiles.
+  unsigned h0 = 0;
+  bool first = true;
+  for (;;) {
+    const unsigned n_lev = first ? 5 : kTileLog;            // stage 1 stops while every level fills whole waves
+    const unsigned span_log = h0 + kTileLog;                 // leaves per tile
+    const size_t a = span_log < 63 ? (((n0 + (((size_t)1 << span_log) - 1)) >> span_log) << span_log) : n1;
+    const size_t b = span_log < 63 ? ((n1 >> span_log) << span_log) : 0;
+    const bool tiles = a < b;
+    if (first) {  // leaf digests outside the tiled range (tiles write their own)
+      const size_t lo_end = tiles ? a : n1;
+      if (lo_end > n0) {
+        hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(lo_end - n0)), dim3(kBlock), 0, st, d_leaves, m->elements, n0, lo_end - n0);
+        P2MT_LAUNCH_CHECK();
+      }
+      if (tiles && n1 > b) {
+        hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(n1 - b)), dim3(kBlock), 0, st, d_leaves + (b - n0), m->elements, b, n1 - b);
+        P2MT_LAUNCH_CHECK();
+      }
+    }
+    if (tiles) {
+      const size_t t0 = a >> span_log, t1 = b >> span_log;
+      P2MT_DISPATCH(k_mmr_tile, (unsigned)(t1 - t0), kBlock, (const u64*)d_leaves, n0, m->elements, h0, n_lev, t0);
+    }
+    bool any_left = false;
+    for (unsigned h = h0 + 1; h <= h0 + n_lev; ++h) {
+      const size_t j0 = n0 >> h, j1 = n1 >> h;
+      if (j1 <= j0) break;
+      any_left = true;
+      if (tiles) {
+        P2MT_TRY(launch_level(m, h, j0, a >> h));
+        P2MT_TRY(launch_level(m, h, b >> h, j1));
+      } else {
+        P2MT_TRY(launch_level(m, h, j0, j1));
+      }
+    }
+    h0 += n_lev;
+    first = false;
+    if (!any_left || (n1 >> (h0 + 1)) <= (n0 >> (h0 + 1))) break;
   }
   m->n_leaves = n1;
   return P2MT_OK;

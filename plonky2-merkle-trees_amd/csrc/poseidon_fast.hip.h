@@ -1,0 +1,164 @@
+// poseidon_fast.hip.h -- issue-optimised Poseidon permutation for gfx950 (the shipped hot path).
+//
+// Same function as poseidon.hip.h (bit-identical; tests/test_parity_gpu.py), restructured around the MEASURED
+// gfx950 issue costs (profiles/r01_valu_issue_rates_gfx950.txt): add/sub/xor/mov issue at ~4 wave-instr/CU/ns,
+// every other VALU op -- including v_mad_u64_u32 (32x32+64) -- at ~2.  The kernel is issue-bound, so the design
+// goal is simply the fewest issue units per hash:
+//   * MDS row = two 12-long v_mad_u64_u32 chains (32-bit halves x 6-bit constants).  The NEXT round's constant
+//     is folded in as the chains' initial addend (halves of the constant sit in SGPR pairs), so the per-round
+//     "add constants" layer disappears.
+//   * hi-chain += lo-chain >> 32 and the 96 -> 64 bit fold are two more mads:  x*1 + acc  and
+//     top*0xFFFFFFFF + (mid:lo)  (2^64 = 2^32 - 1 mod p), whose carry-out lands in an SGPR lane mask.
+//   * 128 -> 64 bit reduction after a field multiply: hl*0xFFFFFFFF + lo64 in one mad (carry mask c1),
+//     + (c1 ? EPS : 0) through v_cndmask + one x*1 mad, then - hh with v_sub_co/v_subbrev.
+//   * Events that need a further correction are RARE (probability <= 2^-22 per op: the 96->64 fold overflowing,
+//     the "- hh" borrowing).  Instead of paying fix-up instructions on every op, their lane masks are OR-ed
+//     (scalar pipe, s_or_b64) into a wave-uniform sticky flag; a wave whose flag is set (~0.5 % of waves)
+//     reloads its inputs and recomputes with the exact reference variant.  Results are therefore exact always.
+#pragma once
+#include "poseidon.hip.h"
+
+namespace poseidon_fast {
+
+using gl::u32;
+using gl::u64;
+
+// d = a * b + c, carry-out as a lane mask (SGPR pair)
+GL_DEV u64 mad_carry(u32 a, u32 b, u64 c, u64& carry) {
+  u64 d;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// d = a * 0xFFFFFFFF + c   (a * 2^64 folded: 2^64 = 2^32 - 1 mod p), carry-out as a lane mask
+GL_DEV u64 mad_eps_carry(u32 a, u64 c, u64& carry) {
+  u64 d;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(d), "=s"(carry) : "v"(a), "v"(c));
+  return d;
+}
+// d = a + c (32-bit a into a 64-bit pair) as one mad; caller guarantees no overflow
+GL_DEV u64 add32(u32 a, u64 c) {
+  u64 d, unused;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(unused) : "v"(a), "v"(c));
+  return d;
+}
+// acc += a * K, K an inline constant (all MDS entries are <= 41 < 64); forced mad: the compiler would otherwise
+// strength-reduce small constants into v_mov + v_lshl_add_u64 (3 issue units instead of 2)
+template <u32 K>
+GL_DEV void mac_const(u64& acc, u32 a) {
+  u64 unused;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "n"(K));
+}
+// mask ? 0xFFFFFFFF : 0
+GL_DEV u32 eps_if(u64 mask) {
+  u32 m;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(mask));
+  return m;
+}
+// (hi:lo) - h, borrow-out as a lane mask
+GL_DEV u64 sub32_borrow(u64 x, u32 h, u64& borrow) {
+  u32 lo, hi;
+  asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
+      : "=&v"(lo), "=v"(hi), "=&s"(borrow)
+      : "v"((u32)x), "v"((u32)(x >> 32)), "v"(h));
+  return ((u64)hi << 32) | lo;
+}
+
+// x = lo + hl*2^64 + hh*2^96 == lo + hl*EPS - hh.  Loose result; the rare borrow of "- hh" goes to `sticky`.
+GL_DEV u64 reduce128(u64 lo, u64 hi, u64& sticky) {
+  const u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 c1, b;
+  const u64 d1 = mad_eps_carry(hl, lo, c1);     // wrapped by 2^64 in lanes of c1
+  const u64 d2 = add32(eps_if(c1), d1);         // + EPS there; cannot wrap again (d1 < 2^64 - 2^33 when wrapped)
+  const u64 d3 = sub32_borrow(d2, hh, b);       // borrows only if d2 < hh < 2^32
+  sticky |= b;
+  return d3;
+}
+
+// 64 x 64 -> 128: four mads; the last high-word accumulation is an x*1 mad (2 units) instead of the
+// v_mov + v_lshl_add_u64 (3 units) the compiler would pick for  t3 + (t2 >> 32).
+GL_DEV void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 t0 = (u64)a0 * b0;
+  const u64 t1 = (u64)a0 * b1 + (t0 >> 32);
+  const u64 t2 = (u64)a1 * b0 + (u32)t1;
+  const u64 t3 = add32((u32)(t2 >> 32), (u64)a1 * b1 + (t1 >> 32));
+  lo = (t2 << 32) | (u32)t0;
+  hi = t3;
+}
+
+GL_DEV u64 mul(u64 a, u64 b, u64& sticky) {
+  u64 lo, hi;
+  mul_wide(a, b, lo, hi);
+  return reduce128(lo, hi, sticky);
+}
+
+GL_DEV u64 pow7(u64 x, u64& sticky) {
+  const u64 x2 = mul(x, x, sticky);
+  const u64 x4 = mul(x2, x2, sticky);
+  const u64 x3 = mul(x2, x, sticky);
+  return mul(x4, x3, sticky);
+}
+
+// out[r] = sum_c MDS[r][c] * s[c] + add[r]  (add = next round's constants, canonical; nullptr for the last round)
+template <bool ADD>
+GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  poseidon::static_for<0, 12>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    u64 al = 0, ah = 0;
+    if constexpr (ADD) {
+      const u64 c = add[r];
+      al = (u64)(u32)c;          // (c_lo, 0) and (c_hi, 0) are SGPR pairs: scalar pipe only
+      ah = (u64)(u32)(c >> 32);
+    }
+    poseidon::static_for<0, 12>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr u32 k = poseidon::mds_entry(r, c);
+      mac_const<k>(al, lo[c]);   // < 264 * 2^32 + 2^32
+      mac_const<k>(ah, hi[c]);
+    });
+    ah = add32((u32)(al >> 32), ah);                       // X = ah * 2^32 + (u32)al, < 2^74
+    const u64 val = ((u64)(u32)ah << 32) | (u32)al;
+    u64 cm;
+    s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);        // top * EPS + val; wraps with probability ~2^-22
+    sticky |= cm;
+  });
+}
+
+// Input: any u64 words.  Output: loose u64 words, valid iff the returned sticky mask is 0 for the whole wave.
+// `rc`: the 360 round constants in GLOBAL memory (kernel argument: base + immediate offsets let the compiler
+// fetch a whole round with wide s_load_dwordx8/x16; the __constant__ symbol would cost a PC-relative address
+// computation per element).
+GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
+  u64 sticky = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
+#pragma unroll 1
+  for (int r = 0; r < POSEIDON_HALF_FULL_ROUNDS; ++r) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
+    mds_layer<true>(s, rc + 12 * (r + 1), sticky);
+  }
+#pragma unroll 1
+  for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {
+    s[0] = pow7(s[0], sticky);
+    mds_layer<true>(s, rc + 12 * (r + 1), sticky);
+  }
+#pragma unroll 1
+  for (int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; r < POSEIDON_ROUNDS - 1; ++r) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
+    mds_layer<true>(s, rc + 12 * (r + 1), sticky);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
+  mds_layer<false>(s, nullptr, sticky);
+  return sticky;
+}
+
+}  // namespace poseidon_fast

@@ -10,12 +10,21 @@
 
 namespace p2mt {
 
+// What every hashing kernel needs besides its data: the round-constant table in global memory (wide scalar
+// loads) and a debug knob that forces the fast path's exact fallback (tests exercise both paths with it).
+struct PermCtx {
+  const uint64_t* rc;
+  uint64_t force_fallback;
+};
+
 struct Runtime {
   bool initialised = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  int mds = 1;      // v_dot2_u32_u16 MDS
-  int partial = 0;  // spec-form partial rounds
+  int mds = 2;      // 0 = v_mad_u64_u32 MDS, 1 = v_dot2_u32_u16 MDS (exact variants), 2 = issue-optimised fast path
+  int partial = 0;  // exact variants only: 0 = spec-form partial rounds, 1 = sparse form
+  uint64_t* d_rc = nullptr;  // 360 round constants, device global memory
+  int force_fallback = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   char err[512] = {0};
 };
@@ -24,6 +33,7 @@ Runtime& rt();
 int fail_hip(hipError_t e, const char* what, const char* file, int line);
 int fail(int code, const char* msg);
 int ensure_init();
+inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ull : 0ull}; }
 
 // RAII device scratch buffer
 struct DevBuf {

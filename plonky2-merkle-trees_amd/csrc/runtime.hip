@@ -1,5 +1,6 @@
 // runtime.hip -- process-global runtime of libp2mt_hip.so: device selection, stream, error text, HIP-event timer.
 #include "runtime.h"
+#include "poseidon_constants.h"  // host copy of the tables (P2MT_QUAL defaults to static const)
 
 #include <stdarg.h>
 #include <string.h>
@@ -55,6 +56,9 @@ extern "C" int p2mt_init(int device) {
   if (rt().ev_stop) (void)hipEventDestroy(rt().ev_stop);
   P2MT_HIP(hipEventCreate(&rt().ev_start));
   P2MT_HIP(hipEventCreate(&rt().ev_stop));
+  if (rt().d_rc) (void)hipFree(rt().d_rc);
+  P2MT_HIP(hipMalloc((void**)&rt().d_rc, sizeof(POSEIDON_RC)));
+  P2MT_HIP(hipMemcpy(rt().d_rc, POSEIDON_RC, sizeof(POSEIDON_RC), hipMemcpyHostToDevice));
   rt().initialised = true;
   return P2MT_OK;
 }
@@ -73,9 +77,14 @@ extern "C" int p2mt_sync(void) {
 extern "C" const char* p2mt_last_error(void) { return rt().err; }
 
 extern "C" int p2mt_set_variant(int mds, int partial) {
-  if (mds < 0 || mds > 1 || partial < 0 || partial > 1) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  if (mds < 0 || mds > 2 || partial < 0 || partial > 1) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_debug_force_fallback(int on) {
+  rt().force_fallback = on ? 1 : 0;
   return P2MT_OK;
 }
 

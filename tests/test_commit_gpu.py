@@ -89,6 +89,20 @@ def test_merkle_cap_edge_shapes(pkg, oracle):
         pkg.MerkleCapTree.new(rand((12, 3), 1), 2)
 
 
+def test_commit_all_poseidon_variants(pkg, oracle):
+    polys = rand((20, 64), 555)
+    _, _, cap = oracle.polynomial_batch_commit(polys, True, 3, 4)
+    try:
+        for v in [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]:
+            pkg.set_variant(*v)
+            assert np.array_equal(pkg.PolynomialBatch.from_values(polys).merkle_tree.cap, cap)
+        pkg.lib().p2mt_debug_force_fallback(1)
+        assert np.array_equal(pkg.PolynomialBatch.from_values(polys).merkle_tree.cap, cap)
+    finally:
+        pkg.lib().p2mt_debug_force_fallback(0)
+        pkg.set_variant(2, 0)
+
+
 def test_polynomial_batch_mini_kat(pkg):
     """SURVEY A.5 mini from_coeffs."""
     polys = np.array([[j + 1 + i for i in range(8)] for j in range(3)], dtype=np.uint64)

@@ -8,7 +8,8 @@ from conftest import splitmix_leaves
 
 pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
-VARIANTS = [(0, 0), (0, 1), (1, 0), (1, 1)]
+VARIANTS = [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]
+DEFAULT_VARIANT = (2, 0)
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +38,7 @@ def test_permutation_all_variants(pkg, oracle, variant):
         assert np.array_equal(got, exp)
         assert [int(x) for x in got[-1][:2]] == [0xd64e1e3efc5b8e9e, 0x53666633020aaa47]  # SURVEY A.2 KAT
     finally:
-        pkg.set_variant(1, 0)
+        pkg.set_variant(*DEFAULT_VARIANT)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -56,7 +57,43 @@ def test_reference_golden_trees(pkg, golden, variant):
         t = pkg.MerkleTree.build(g["leaves"])
         assert np.array_equal(t.get_merkle_proof(0), np.asarray(g["proof_leaf0"], dtype=np.uint64))
     finally:
-        pkg.set_variant(1, 0)
+        pkg.set_variant(*DEFAULT_VARIANT)
+
+
+def test_fast_path_fallback_is_exact(pkg, oracle):
+    """The shipped (mds=2) path has a rare-event fallback; forcing every wave through it must not change a bit,
+    and the primitives' rare cases are hit with crafted operands (products whose reduction borrows/wraps)."""
+    pkg.set_variant(2, 0)
+    lib = pkg.lib()
+    rng = np.random.default_rng(8)
+    states = np.concatenate([edge_states(), rng.integers(0, 1 << 64, size=(3000, 12), dtype=np.uint64)])
+    leaves = splitmix_leaves(5000, 0x5EED00AA)
+    try:
+        fast = pkg.poseidon_permute_batch(states)
+        m_fast = pkg.MMR.from_leaves(leaves).elements
+        lib.p2mt_debug_force_fallback(1)
+        slow = pkg.poseidon_permute_batch(states)
+        m_slow = pkg.MMR.from_leaves(leaves).elements
+    finally:
+        lib.p2mt_debug_force_fallback(0)
+    assert np.array_equal(fast, slow) and np.array_equal(fast, oracle.permute_batch(states))
+    assert np.array_equal(m_fast, m_slow) and np.array_equal(m_fast, oracle.mmr(leaves).elements)
+
+
+def test_fast_path_many_random_states(pkg, oracle):
+    """2^17 random permutations: at ~2^-22 per MDS row the sticky fallback fires for a few waves here."""
+    pkg.set_variant(2, 0)
+    rng = np.random.default_rng(21)
+    states = rng.integers(0, 1 << 64, size=(1 << 17, 12), dtype=np.uint64)
+    got = pkg.poseidon_permute_batch(states)
+    pkg.set_variant(0, 0)
+    try:
+        ref = pkg.poseidon_permute_batch(states)
+    finally:
+        pkg.set_variant(*DEFAULT_VARIANT)
+    assert np.array_equal(got, ref)
+    sel = rng.integers(0, 1 << 17, size=300)
+    assert np.array_equal(got[sel], oracle.permute_batch(states[sel]))
 
 
 def test_two_to_one_and_hash_modes(pkg, oracle):
@@ -188,6 +225,21 @@ def test_mmr_proofs_vs_oracle(pkg, oracle, n):
             assert np.array_equal(pr.siblings, opr["siblings"]) and np.array_equal(pr.lefts, opr["lefts"])
     with pytest.raises(pkg.P2mtPanic):
         m.get_proof(len(om))
+
+
+def test_mmr_tiled_build_ragged(pkg, oracle):
+    """Sizes and extend cuts that straddle the fused-tile boundaries (2^11 leaves, 2^16 leaves)."""
+    n = (1 << 17) + 4099
+    leaves = splitmix_leaves(n, 0x5EED0077)
+    om = oracle.mmr(leaves)
+    a = pkg.MMR.from_leaves(leaves)
+    assert np.array_equal(a.elements, om.elements)
+    b = pkg.MMR.new()
+    cuts = [0, 3, 2047, 2049, 6144, 65535, 65537, 70000, (1 << 17) - 1, (1 << 17) + 1, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        b.extend(leaves[lo:hi])
+    assert np.array_equal(b.elements, om.elements)
+    assert np.array_equal(b.bagging_the_peaks(), om.bagging_the_peaks())
 
 
 def test_mmr_empty_panics(pkg):
