@@ -62,7 +62,7 @@ GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load) {
 template <int M, int PR, typename LoadLR>
 GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr) {
   u64 s[12];
-  permute_reloadable<M, PR>(s, ctx, [&](u64 (&st)[12]) {
+  auto load = [&](u64 (&st)[12]) {
     u64 l[4], r[4];
     load_lr(l, r);
 #pragma unroll
@@ -71,7 +71,17 @@ GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr) {
       st[4 + k] = r[k];
       st[8 + k] = 0;
     }
-  });
+  };
+  if constexpr (M == IMPL_FAST) {  // capacity words are zero and only 4 output words are needed
+    load(s);
+    const u64 sticky = poseidon_fast::permute<true, 4>(s, ctx.rc) | ctx.force_fallback;
+    if (__builtin_expect(sticky != 0, 0)) {
+      load(s);
+      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+    }
+  } else {
+    permute_reloadable<M, PR>(s, ctx, load);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = gl::canon(s[k]);
 }
@@ -241,9 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_mmr_level(u64* __restrict__ elements
 // (ping-pong buffers, 48 KB) and writing every node once to its post-order slot.  HBM traffic is the
 // algorithmic minimum: 8 B read per leaf, 32 B written per node.  The caller stops a stage while every level
 // still fills whole waves (2^(kTileLog - n_levels) >= 64) except in the tiny top stages.
-constexpr unsigned kTileLog = 11;
-
-template <int M, int PR>
+template <int M, int PR, unsigned kTileLog>
 __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ leaves, size_t leaf_base,
                                                      u64* __restrict__ elements, unsigned h0, unsigned n_levels,
                                                      size_t tile0, PermCtx ctx) {
@@ -293,6 +301,72 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------- one wavefront per node (latency path)
+// Near the top of the tree a level has fewer nodes than the chip has lanes, and a lane-per-hash launch costs one
+// full single-hash latency (~65 us) whatever its size.  Here 12 lanes of a wave share ONE permutation: lane i owns
+// state word i, the twelve S-boxes of a full round run in parallel, and the MDS row of lane r is two mad chains
+// over the words broadcast with v_readlane (SGPR operands) against that lane's row of constants.  All 30 rounds
+// are unrolled with the lane's round constants preloaded, so a node takes ~3.5k instructions instead of ~28k.
+// Used for levels of <= 2^15 nodes; bit-identical to the lane-per-hash kernels (same primitives, same fallback).
+__global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
+                                                           PermCtx ctx) {
+  const unsigned lane = threadIdx.x & 63;
+  const size_t j = j0 + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (j >= j1) return;  // wave-uniform
+  const size_t pos = node_pos(((j + 1) << h) - 1, h);
+  const u64* lp = elements + 4 * (pos - ((size_t)1 << h));
+  const u64* rp = elements + 4 * (pos - 1);
+  const unsigned w = lane < 12 ? lane : 0;  // lanes >= 12 shadow lane 0 (results unused)
+
+  u64 x = lane < 4 ? lp[lane] : (lane < 8 ? rp[lane - 4] : 0);
+  u64 rcv[POSEIDON_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < POSEIDON_ROUNDS; ++r) rcv[r] = ctx.rc[12 * r + w];
+  u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
+#pragma unroll
+  for (int c = 0; c < 12; ++c) kk[c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - w) % 12] + ((w == 0 && c == 0) ? 8u : 0u);
+
+  u64 sticky = 0;
+  x = gl::add_c(x, rcv[0]);
+#pragma unroll
+  for (int r = 0; r < POSEIDON_ROUNDS; ++r) {
+    const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
+    const u64 y = poseidon_fast::pow7(x, sticky);
+    if (full || lane == 0) x = y;
+    const u32 xl = (u32)x, xh = (u32)(x >> 32);
+    u64 al = 0, ah = 0;
+    if (r + 1 < POSEIDON_ROUNDS) {  // next round's constant folded into the chains
+      al = (u64)(u32)rcv[r + 1];
+      ah = (u64)(u32)(rcv[r + 1] >> 32);
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const u32 sl = (u32)__builtin_amdgcn_readlane((int)xl, c), sh = (u32)__builtin_amdgcn_readlane((int)xh, c);
+      al += (u64)sl * kk[c];
+      ah += (u64)sh * kk[c];
+    }
+    ah = poseidon_fast::add32((u32)(al >> 32), ah);
+    const u64 val = ((u64)(u32)ah << 32) | (u32)al;
+    u64 cm;
+    x = poseidon_fast::mad_eps_carry((u32)(ah >> 32), val, cm);
+    sticky |= cm;
+  }
+  sticky |= ctx.force_fallback;
+  if (__builtin_expect(sticky != 0, 0)) {  // rare: lane 0 redoes the node with the exact lane-per-hash code
+    if (lane == 0) {
+      u64 s[12];
+      load_hash(lp, *reinterpret_cast<u64(*)[4]>(&s[0]));
+      load_hash(rp, *reinterpret_cast<u64(*)[4]>(&s[4]));
+      s[8] = s[9] = s[10] = s[11] = 0;
+      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+      u64 o[4] = {gl::canon(s[0]), gl::canon(s[1]), gl::canon(s[2]), gl::canon(s[3])};
+      store_hash(elements + 4 * pos, o);
+    }
+    return;
+  }
+  if (lane < 4) elements[4 * pos + lane] = gl::canon(x);
 }
 
 struct PosList {
@@ -732,10 +806,22 @@ extern "C" int p2mt_mmr_reset(p2mt_mmr* m) {
   return P2MT_OK;
 }
 
-// generic level kernel over [j0, j1) of height h
+// one level over [j0, j1) of height h: one wavefront per node while the level is small (latency-bound), one
+// lane per node otherwise
+constexpr size_t kWavePerNodeMax = (size_t)1 << 12;  // measured crossover vs the lane-per-node kernel: ~2^13 nodes
+constexpr size_t kMinTilesPerStage = 2048;           // a fused stage needs enough workgroups to fill 256 CUs
+
 static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
   if (j1 <= j0) return P2MT_OK;
-  P2MT_DISPATCH(k_mmr_level, grid_for(j1 - j0), kBlock, m->elements, h, j0, j1);
+  const size_t cnt = j1 - j0;
+  if (cnt <= kWavePerNodeMax && rt().mds == 2) {
+    const unsigned per_block = kBlock / 64;
+    hipLaunchKernelGGL(k_mmr_level_wave, dim3((unsigned)((cnt + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
+                       m->elements, h, j0, j1, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  P2MT_DISPATCH(k_mmr_level, grid_for(cnt), kBlock, m->elements, h, j0, j1);
   return P2MT_OK;
 }
 
@@ -749,17 +835,29 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
   P2MT_TRY(mmr_grow(m, mmr_len_for(n1)));
   hipStream_t st = rt().stream;
   // A height-h node j is new iff it ends after leaf n0 and complete iff it ends by n1: j in [n0>>h, n1>>h).
-  // Stages of fused tiles cover the aligned bulk; the ragged edges (and the thin top of the tree) use the
-  // one-level kernel.  Stage s starts at height h0 and fuses n_lev levels of 2^(h0+kTileLog)-leaf tiles.
+  // Stages of fused tiles (2^(h0+kTileLog)-leaf aligned blocks, n_lev levels each) cover the bulk while a level
+  // still has more nodes than the wave-per-node path likes; ragged edges and the thin top go level by level.
+  const unsigned kTileLog = rt().mds == 2 ? rt().tile_log : 11;  // 9, 10 or 11: 2^kTileLog inputs per workgroup (12 / 24 / 48 KB of LDS)
   unsigned h0 = 0;
-  bool first = true;
   for (;;) {
-    const unsigned n_lev = first ? 5 : kTileLog;            // stage 1 stops while every level fills whole waves
-    const unsigned span_log = h0 + kTileLog;                 // leaves per tile
-    const size_t a = span_log < 63 ? (((n0 + (((size_t)1 << span_log) - 1)) >> span_log) << span_log) : n1;
-    const size_t b = span_log < 63 ? ((n1 >> span_log) << span_log) : 0;
-    const bool tiles = a < b;
-    if (first) {  // leaf digests outside the tiled range (tiles write their own)
+    if ((n1 >> (h0 + 1)) <= (n0 >> (h0 + 1)) && h0 > 0) break;  // no node above h0
+    // levels this stage would fuse: stage 1 stops while every level fills whole waves (5 levels); later stages
+    // stop where the wave-per-node kernel takes over
+    unsigned n_lev = 0;
+    if (h0 == 0) {
+      n_lev = kTileLog - 6;  // last fused level still has 64 nodes per tile
+    } else {
+      // whole-wave levels only (>= 64 nodes per tile), and only while the level is too big for the wave-per-node path
+      while (n_lev < kTileLog - 6 && ((n1 >> (h0 + n_lev + 1)) - (n0 >> (h0 + n_lev + 1))) > kWavePerNodeMax) ++n_lev;
+    }
+    const unsigned span_log = h0 + kTileLog;  // log2(leaves per tile)
+    size_t a = n1, b = 0;
+    if (n_lev && span_log < 48) {
+      a = ((n0 + (((size_t)1 << span_log) - 1)) >> span_log) << span_log;
+      b = (n1 >> span_log) << span_log;
+    }
+    const bool tiles = n_lev && a < b && (h0 == 0 || ((b - a) >> span_log) >= kMinTilesPerStage);
+    if (h0 == 0) {  // leaf digests outside the tiled range (tiles write their own)
       const size_t lo_end = tiles ? a : n1;
       if (lo_end > n0) {
         hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(lo_end - n0)), dim3(kBlock), 0, st, d_leaves, m->elements, n0, lo_end - n0);
@@ -770,25 +868,33 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
         P2MT_LAUNCH_CHECK();
       }
     }
-    if (tiles) {
-      const size_t t0 = a >> span_log, t1 = b >> span_log;
-      P2MT_DISPATCH(k_mmr_tile, (unsigned)(t1 - t0), kBlock, (const u64*)d_leaves, n0, m->elements, h0, n_lev, t0);
+    if (!tiles) {  // no fused stage from here: one launch per remaining level
+      for (unsigned h = h0 + 1; (n1 >> h) > (n0 >> h); ++h) P2MT_TRY(launch_level(m, h, n0 >> h, n1 >> h));
+      break;
     }
-    bool any_left = false;
-    for (unsigned h = h0 + 1; h <= h0 + n_lev; ++h) {
-      const size_t j0 = n0 >> h, j1 = n1 >> h;
-      if (j1 <= j0) break;
-      any_left = true;
-      if (tiles) {
-        P2MT_TRY(launch_level(m, h, j0, a >> h));
-        P2MT_TRY(launch_level(m, h, b >> h, j1));
+    {
+      const unsigned grid = (unsigned)((b - a) >> span_log);
+      const size_t t0 = a >> span_log;
+      const p2mt::PermCtx ctx = p2mt::perm_ctx();
+#define P2MT_TILE(M, PR, TL) \
+  hipLaunchKernelGGL((k_mmr_tile<M, PR, TL>), dim3(grid), dim3(kBlock), 0, st, (const u64*)d_leaves, n0, m->elements, h0, n_lev, t0, ctx)
+      if (rt().mds == 2) {
+        if (kTileLog == 9) P2MT_TILE(2, 0, 9);
+        else if (kTileLog == 10) P2MT_TILE(2, 0, 10);
+        else P2MT_TILE(2, 0, 11);
+      } else if (rt().mds == 1) {
+        if (rt().partial) P2MT_TILE(1, 1, 11); else P2MT_TILE(1, 0, 11);
       } else {
-        P2MT_TRY(launch_level(m, h, j0, j1));
+        if (rt().partial) P2MT_TILE(0, 1, 11); else P2MT_TILE(0, 0, 11);
       }
+#undef P2MT_TILE
+      P2MT_LAUNCH_CHECK();
+    }
+    for (unsigned h = h0 + 1; h <= h0 + n_lev; ++h) {  // ragged edges of the fused levels
+      P2MT_TRY(launch_level(m, h, n0 >> h, a >> h));
+      P2MT_TRY(launch_level(m, h, b >> h, n1 >> h));
     }
     h0 += n_lev;
-    first = false;
-    if (!any_left || (n1 >> (h0 + 1)) <= (n0 >> (h0 + 1))) break;
   }
   m->n_leaves = n1;
   return P2MT_OK;

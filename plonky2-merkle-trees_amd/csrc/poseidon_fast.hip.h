@@ -48,6 +48,19 @@ GL_DEV void mac_const(u64& acc, u32 a) {
   u64 unused;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "n"(K));
 }
+// first link of a chain: d = a * K + init, init a wave-uniform 64-bit value (SGPR pair: no VGPR initialisation)
+template <u32 K>
+GL_DEV u64 mac_const_first(u32 a, u64 init_uniform) {
+  u64 d, unused;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(unused) : "v"(a), "n"(K), "s"(init_uniform));
+  return d;
+}
+template <u32 K>
+GL_DEV u64 mac_const_first0(u32 a) {
+  u64 d, unused;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(unused) : "v"(a), "n"(K));
+  return d;
+}
 // mask ? 0xFFFFFFFF : 0
 GL_DEV u32 eps_if(u64 mask) {
   u32 m;
@@ -99,8 +112,9 @@ GL_DEV u64 pow7(u64 x, u64& sticky) {
   return mul(x4, x3, sticky);
 }
 
-// out[r] = sum_c MDS[r][c] * s[c] + add[r]  (add = next round's constants, canonical; nullptr for the last round)
-template <bool ADD>
+// out[r] = sum_c MDS[r][c] * s[c] + add[r] for r < ROWS  (add = next round's constants, canonical; ADD = false
+// for the last round).  Rows >= ROWS are left untouched (two_to_one only needs 4 output words of the last layer).
+template <bool ADD, int ROWS = 12>
 GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
   u32 lo[12], hi[12];
 #pragma unroll
@@ -108,15 +122,19 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
     lo[i] = (u32)s[i];
     hi[i] = (u32)(s[i] >> 32);
   }
-  poseidon::static_for<0, 12>([&](auto rc) {
+  poseidon::static_for<0, ROWS>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
-    u64 al = 0, ah = 0;
+    constexpr u32 k0 = poseidon::mds_entry(r, 0);
+    u64 al, ah;
     if constexpr (ADD) {
-      const u64 c = add[r];
-      al = (u64)(u32)c;          // (c_lo, 0) and (c_hi, 0) are SGPR pairs: scalar pipe only
-      ah = (u64)(u32)(c >> 32);
+      const u64 c = add[r];  // (c_lo, 0) and (c_hi, 0) become SGPR pairs: scalar pipe only
+      al = mac_const_first<k0>(lo[0], (u64)(u32)c);
+      ah = mac_const_first<k0>(hi[0], (u64)(u32)(c >> 32));
+    } else {
+      al = mac_const_first0<k0>(lo[0]);
+      ah = mac_const_first0<k0>(hi[0]);
     }
-    poseidon::static_for<0, 12>([&](auto cc) {
+    poseidon::static_for<1, 12>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       constexpr u32 k = poseidon::mds_entry(r, c);
       mac_const<k>(al, lo[c]);   // < 264 * 2^32 + 2^32
@@ -134,12 +152,26 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
 // `rc`: the 360 round constants in GLOBAL memory (kernel argument: base + immediate offsets let the compiler
 // fetch a whole round with wide s_load_dwordx8/x16; the __constant__ symbol would cost a PC-relative address
 // computation per element).
+// CAP_ZERO: the caller guarantees s[8..11] == 0 on entry (two_to_one): their first S-box input is the round
+//   constant itself, so (rc[8+i])^7 is read precomputed from rc[360 + i].
+// OUT_ROWS: number of output words the caller needs (4 for a hash => the last MDS layer computes 4 rows).
+template <bool CAP_ZERO = false, int OUT_ROWS = 12>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
   u64 sticky = 0;
+  constexpr int kVar = CAP_ZERO ? 8 : 12;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
+  for (int i = 0; i < kVar; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
+  {  // round 0
+#pragma unroll
+    for (int i = 0; i < kVar; ++i) s[i] = pow7(s[i], sticky);
+    if constexpr (CAP_ZERO) {
+#pragma unroll
+      for (int i = 8; i < 12; ++i) s[i] = rc[360 + (i - 8)];
+    }
+    mds_layer<true>(s, rc + 12, sticky);
+  }
 #pragma unroll 1
-  for (int r = 0; r < POSEIDON_HALF_FULL_ROUNDS; ++r) {
+  for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
     mds_layer<true>(s, rc + 12 * (r + 1), sticky);
@@ -157,7 +189,7 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
-  mds_layer<false>(s, nullptr, sticky);
+  mds_layer<false, OUT_ROWS>(s, nullptr, sticky);
   return sticky;
 }
 

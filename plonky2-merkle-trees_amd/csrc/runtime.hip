@@ -3,6 +3,7 @@
 #include "poseidon_constants.h"  // host copy of the tables (P2MT_QUAL defaults to static const)
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace p2mt {
@@ -57,8 +58,21 @@ extern "C" int p2mt_init(int device) {
   P2MT_HIP(hipEventCreate(&rt().ev_start));
   P2MT_HIP(hipEventCreate(&rt().ev_stop));
   if (rt().d_rc) (void)hipFree(rt().d_rc);
-  P2MT_HIP(hipMalloc((void**)&rt().d_rc, sizeof(POSEIDON_RC)));
-  P2MT_HIP(hipMemcpy(rt().d_rc, POSEIDON_RC, sizeof(POSEIDON_RC), hipMemcpyHostToDevice));
+  {  // 360 round constants + (rc[8..11])^7: the first-round S-box outputs of two_to_one's zero capacity words
+    uint64_t table[364];
+    memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
+    for (int i = 0; i < 4; ++i) {
+      const unsigned __int128 p = 0xFFFFFFFF00000001ULL;
+      unsigned __int128 x = POSEIDON_RC[8 + i], x2 = x * x % p, x4 = x2 * x2 % p, x3 = x2 * x % p;
+      table[360 + i] = (uint64_t)(x4 * x3 % p);
+    }
+    P2MT_HIP(hipMalloc((void**)&rt().d_rc, sizeof(table)));
+    P2MT_HIP(hipMemcpy(rt().d_rc, table, sizeof(table), hipMemcpyHostToDevice));
+  }
+  if (const char* e = getenv("P2MT_TILE_LOG")) {
+    const int v = atoi(e);
+    if (v >= 9 && v <= 11) rt().tile_log = (unsigned)v;
+  }
   rt().initialised = true;
   return P2MT_OK;
 }
