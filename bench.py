@@ -3,16 +3,19 @@
 
 A "step" is one complete build of a 2^LOG-leaf MMR (default 2^24, the size BASELINE.json's metric is quoted
 on) from leaves already resident in HBM: reset + extend == 2^24 x MMR::add_leaf
-(/root/reference/src/mmr/merkle_mountain_ranges.rs:89-120) + the all-gather/top-levels combine when N > 1.
-Unit of work: one `two_to_one` Poseidon permutation; an N-leaf build performs N - popcount(N) of them.
+(/root/reference/src/mmr/merkle_mountain_ranges.rs:89-120) + bagging_the_peaks, + the all-gather/top-levels
+combine when N > 1.  Unit of work: one `two_to_one` Poseidon permutation; an N-leaf build performs
+N - popcount(N) of them.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (weak scaling: every rank builds its own 2^LOG shard)
+  python bench.py --workload commit                       (secondary metric: commit phase of one prove, ms)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -28,6 +31,15 @@ import __graft_entry__ as ge  # noqa: E402
 
 ALGO_BYTES_PER_HASH = 72.0   # 8 B leaf in + 2 x 32 B nodes out per two_to_one, N large
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+# Integer-issue roofline: VALU instructions per two_to_one of the shipped kernel, from
+# SQ_INSTS_VALU / hashes (profiles/r01_v3_*.txt), and the measured gfx950 issue rates
+# (profiles/r01_valu_issue_rates_gfx950.txt): ~2.05 wave-instr/CU/ns for v_mad_u64_u32-class ops, ~4.0 for
+# add/sub/xor/mov; the kernel's mix (about 85 % mad-class) caps at ~2.2 wave-instr/CU/ns.
+VALU_INSTR_PER_HASH = 16240.0
+ISSUE_PEAK_WAVE_INSTR_PER_S = 256 * 2.2e9
+# HBM bytes of ONE stage-1 launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see
+# profiles/; None until measured for the current kernel.
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = None
 
 
 def splitmix_leaves(n, seed):
@@ -35,7 +47,7 @@ def splitmix_leaves(n, seed):
     return f(n, seed)
 
 
-def cpu_baseline(target_seconds=12.0, max_log=22):
+def cpu_baseline_mmr(target_seconds=12.0, max_log=22):
     """Oracle (C restatement, `for leaf { add_leaf }`, 1 thread) on a bounded sample of the same workload."""
     from oracle_lib import Oracle
     o = Oracle()
@@ -57,13 +69,163 @@ def cpu_baseline(target_seconds=12.0, max_log=22):
             "_root": m.bagging_the_peaks(), "_log_n": log_n}
 
 
+def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
+    n = 1 << args.log_leaves
+    host_leaves = splitmix_leaves(n, 0x5EED0000 + 24 + 1000 * rank)
+    d_leaves = torch.from_numpy(host_leaves.view(np.int64)).cuda()
+    shard = pkg.ShardedMMR(pkg, n, rank, world, dist)
+
+    def step():
+        return shard.build_dev(d_leaves)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.p2mt_profile_enable(1)
+    pkg._native.check(lib.p2mt_timer_start())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        root = step()
+    region_ms = C.c_float(0)
+    pkg._native.check(lib.p2mt_timer_stop(C.byref(region_ms)))
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = C.c_float(0), C.c_int(0)
+    pkg._native.check(lib.p2mt_profile_read(C.byref(kern_ms), C.byref(kern_n)))
+    lib.p2mt_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    hashes_per_rank = n - bin(n).count("1")
+    total_hashes = hashes_per_rank * world + (world - 1)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = total_hashes / (ms_per_step * 1e-3)
+    if rank != 0:
+        return None
+    mds, partial = C.c_int(), C.c_int()
+    lib.p2mt_get_variant(C.byref(mds), C.byref(partial))
+    tile_log = int(os.environ.get("P2MT_TILE_LOG", "10"))
+    # dominant kernel: the fused stage-1 tile launch (levels 1 .. tile_log-6 of every 2^tile_log-leaf tile)
+    fused_levels = tile_log - 6
+    hashes_in_launch = n - (n >> fused_levels)
+    launch_ms = kern_ms.value / max(kern_n.value, 1)
+    algo_bytes = hashes_in_launch * ALGO_BYTES_PER_HASH
+    achieved_gbs = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    in_kernel_rate = hashes_in_launch / (launch_ms * 1e-3) if launch_ms > 0 else 0.0
+    out = {
+        "metric": "Poseidon hashes/s (MMR build, 2^%d leaves per GPU)" % args.log_leaves,
+        "value": value, "unit": "Poseidon hashes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 (Goldilocks, integer VALU)", "data": "synthetic",
+        "config": {"workload": "mmr::merkle_mountain_ranges build, 2^%d leaves per GPU, device-resident leaves"
+                               % args.log_leaves,
+                   "leaves_per_gpu": n, "hashes_per_step": total_hashes,
+                   "poseidon_variant": {"mds": mds.value, "partial": partial.value}, "tile_log": tile_log,
+                   "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS,
+                     "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH,
+                     "kernel": "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (fused_levels, tile_log),
+                     "launch_ms": launch_ms, "launches_timed": kern_n.value,
+                     "algorithmic_bytes_per_launch": algo_bytes, "hashes_per_launch": hashes_in_launch,
+                     "note": "Poseidon is integer-issue bound (see issue_roofline): ~16k VALU instructions per "
+                             "72 algorithmic bytes, so the HBM fraction is ~1-2 % by construction (SURVEY.md 8d)"},
+        "issue_roofline": {"bound": "valu-issue", "unit": "wave-instr/s",
+                           "achieved": in_kernel_rate * VALU_INSTR_PER_HASH / 64.0,
+                           "peak": ISSUE_PEAK_WAVE_INSTR_PER_S,
+                           "frac": in_kernel_rate * VALU_INSTR_PER_HASH / 64.0 / ISSUE_PEAK_WAVE_INSTR_PER_S,
+                           "valu_instr_per_hash": VALU_INSTR_PER_HASH, "in_kernel_hashes_per_s": in_kernel_rate},
+        "device_ms_per_step": region_ms.value / args.steps,
+        "root": [int(x) for x in root],
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline_mmr()
+        # parity check of the sample: GPU build of the same prefix must give the oracle's root
+        sub = pkg.MMR.from_leaves(host_leaves[:1 << cb["_log_n"]])
+        assert np.array_equal(sub.bagging_the_peaks(), cb["_root"]), "GPU root != oracle root on the CPU sample"
+        cb = {k: v for k, v in cb.items() if not k.startswith("_")}
+        cb["gpu_over_cpu"] = value / cb["value"]
+        out["cpu_baseline"] = cb
+    return out
+
+
+def run_commit(args, torch, pkg, lib):
+    """Secondary metric (ms/proof, commit phase only): the three PolynomialBatch commits of one prove at the
+    outer-circuit shape of config 4 (135 / 20 / 16 polynomials, 2^12 -> 2^15, cap height 4) and at config 3's
+    (2^6 -> 2^9).  NOT a full plonky2 prove (no witness generation, quotient evaluation or FRI)."""
+    res = {}
+    for name, log_n in (("config4_outer_d12", 12), ("config3_d6", 6)):
+        n = 1 << log_n
+        shapes = [(135, True), (20, True), (16, False)]
+        rng = np.random.default_rng(5)
+        bufs = []
+        for w, is_values in shapes:
+            host = rng.integers(0, pkg.GOLDILOCKS_FIELD_ORDER, size=(w, n), dtype=np.uint64)
+            bufs.append((torch.from_numpy(host.view(np.int64)).cuda(), host, w, is_values))
+        cap = torch.zeros(16 * 4, dtype=torch.int64, device="cuda")
+        dig = torch.zeros(((n << 3) * 2) * 4, dtype=torch.int64, device="cuda")
+
+        def one_prove():
+            for d_polys, _, w, is_values in bufs:
+                pkg._native.check(lib.p2mt_polynomial_batch_commit_dev(
+                    pkg._native.ptr(d_polys), int(is_values), w, log_n, 3, 4, None, pkg._native.ptr(dig),
+                    pkg._native.ptr(cap)))
+
+        for _ in range(args.warmup):
+            one_prove()
+        torch.cuda.synchronize()
+        lib.p2mt_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_prove()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        kern_ms, kern_n = C.c_float(0), C.c_int(0)
+        pkg._native.check(lib.p2mt_profile_read(C.byref(kern_ms), C.byref(kern_n)))
+        lib.p2mt_profile_enable(0)
+        lde_bytes = sum(w * n * 8 * (1 + 8) for _, _, w, _ in bufs)  # read coeffs once, write the x8 LDE once
+        lde_ms = kern_ms.value / args.steps
+        entry = {"ms_per_proof_commit_phase": ms, "lde_kernels_ms": lde_ms,
+                 "lde_algorithmic_GBps": lde_bytes / (lde_ms * 1e-3) / 1e9 if lde_ms > 0 else None}
+        if not args.no_cpu_baseline:
+            from oracle_lib import Oracle
+            o = Oracle()
+            t0 = time.perf_counter()
+            caps = [o.polynomial_batch_commit(host, is_values, 3, 4)[2] for _, host, _, is_values in bufs]
+            entry["cpu_port_ms_1core"] = (time.perf_counter() - t0) * 1e3
+            pb = pkg.PolynomialBatch.from_coeffs(bufs[2][1], want_leaves=False)
+            assert np.array_equal(pb.merkle_tree.cap, caps[2]), "GPU cap != oracle cap"
+        res[name] = entry
+    main = res["config4_outer_d12"]
+    return {"metric": "ms/proof, commit phase only (3 x PolynomialBatch: 135/20/16 polys, 2^12 -> 2^15, cap 4)",
+            "value": main["ms_per_proof_commit_phase"], "unit": "ms", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main["ms_per_proof_commit_phase"], "higher_is_better": False,
+            "scaling": "replicas only", "vs_baseline": None, "dtype": "u64 (Goldilocks)", "data": "synthetic",
+            "config": {"workload": "commit phase of mmr_plonky2_verifier_1_recursion outer prove (synthetic wire "
+                                   "matrix); NOT a full plonky2 prove"},
+            "roofline": {"bound": "hbm", "achieved": main["lde_algorithmic_GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s",
+                         "frac": (main["lde_algorithmic_GBps"] or 0) / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_coset_lde (x8 coset LDE, 72 B per coefficient)"},
+            "details": res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-leaves", type=int, default=24, help="leaves per GPU = 2^this")
-    ap.add_argument("--variant", default=None, help="mds,partial (e.g. 1,0) Poseidon kernel variant")
+    ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
+    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,75 +250,11 @@ def main():
     if args.variant:
         pkg.set_variant(*[int(x) for x in args.variant.split(",")])
     lib = pkg.lib()
-    import ctypes as C
-    mds, partial = C.c_int(), C.c_int()
-    lib.p2mt_get_variant(C.byref(mds), C.byref(partial))
-
-    n = 1 << args.log_leaves
-    host_leaves = splitmix_leaves(n, 0x5EED0000 + 24 + 1000 * rank)
-    d_leaves = torch.from_numpy(host_leaves.view(np.int64)).cuda()
-    from plonky2_merkle_trees_amd import distributed as pdist
-    shard = pdist.ShardedMMR(pkg, n, rank, world, dist)
-
-    def step():
-        return shard.build_dev(d_leaves)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    pkg._native.check(lib.p2mt_timer_start())
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        root = step()
-    kernel_ms = C.c_float(0)
-    pkg._native.check(lib.p2mt_timer_stop(C.byref(kernel_ms)))
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    hashes_per_rank = n - bin(n).count("1")
-    total_hashes = hashes_per_rank * world + (world - 1)
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = total_hashes / (ms_per_step * 1e-3)
-
-    if rank == 0:
-        # HIP-event time of this rank's launches over the timed region (library stream)
-        dev_ms_per_step = kernel_ms.value / args.steps
-        achieved_gbs = hashes_per_rank * ALGO_BYTES_PER_HASH / (dev_ms_per_step * 1e-3) / 1e9
-        out = {
-            "metric": "Poseidon hashes/s (MMR build, 2^%d leaves per GPU)" % args.log_leaves,
-            "value": value, "unit": "Poseidon hashes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (Goldilocks, integer VALU)", "data": "synthetic",
-            "config": {"workload": "mmr::merkle_mountain_ranges build, 2^%d leaves per GPU, device-resident leaves"
-                                   % args.log_leaves,
-                       "leaves_per_gpu": n, "hashes_per_step": total_hashes,
-                       "poseidon_variant": {"mds": mds.value, "partial": partial.value},
-                       "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_mmr_level (all levels of one build)", "device_ms_per_step": dev_ms_per_step,
-                         "algorithmic_bytes_per_hash": ALGO_BYTES_PER_HASH,
-                         "note": "Poseidon is integer-issue bound (~1e3 64-bit modmuls per 72 B); see DESIGN.md"},
-            "root": [int(x) for x in root],
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline()
-            # parity check of the sample: GPU build of the same prefix must give the oracle's root
-            sub = pkg.MMR.from_leaves(host_leaves[:1 << cb["_log_n"]])
-            assert np.array_equal(sub.bagging_the_peaks(), cb["_root"]), "GPU root != oracle root on the CPU sample"
-            cb = {k: v for k, v in cb.items() if not k.startswith("_")}
-            cb["gpu_over_cpu"] = value / cb["value"]
-            out["cpu_baseline"] = cb
+    if args.workload == "commit":
+        out = run_commit(args, torch, pkg, lib) if rank == 0 else None
+    else:
+        out = run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist)
+    if rank == 0 and out is not None:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -58,6 +58,10 @@ int p2mt_set_variant(int mds, int partial);
 int p2mt_get_variant(int *mds, int *partial);
 /* Debug/test knob: make every wave of the mds=2 path take its exact fallback (results must not change). */
 int p2mt_debug_force_fallback(int on);
+/* Per-launch HIP-event timing of the dominant kernels (the fused MMR tile stage; the LDE / leaf-sponge kernels of
+ * the commit step): enable, run, then read the summed duration and the number of launches recorded. */
+int p2mt_profile_enable(int on);
+int p2mt_profile_read(float *total_ms, int *launches);
 /* HIP-event timer on the library stream (what bench.py uses for per-launch durations). */
 int p2mt_timer_start(void);
 int p2mt_timer_stop(float *elapsed_ms); /* records + synchronises the stop event */

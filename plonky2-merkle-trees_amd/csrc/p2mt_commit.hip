@@ -370,8 +370,7 @@ static int log2_strict(size_t n) {
 }
 
 // digests level 0 must already be in d_level0 (n HashOuts).  Builds levels 1.. and the cap.
-static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u64* d_digests_out, u64* d_cap_out,
-                                DevBuf& scratch) {
+static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u64* d_digests_out, u64* d_cap_out) {
   const int k = log2_strict(n);
   // level-major digests: level j has n >> j entries, levels 0 .. k-cap_height-1; the next row is the cap
   if ((unsigned)k == cap_height) {
@@ -381,8 +380,8 @@ static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u6
   u64* cur = d_level0;
   size_t cur_n = n;
   u64* next_store = d_digests_out ? d_digests_out + 4 * n : nullptr;
-  if (!d_digests_out) P2MT_TRY(scratch.alloc(n * 32));  // ping-pong rows when the caller does not want digests
-  u64* ping = scratch.as<u64>();
+  u64* ping = nullptr;  // ping-pong rows when the caller does not want digests
+  if (!d_digests_out) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchPing, n * 32, (void**)&ping));
   for (unsigned level = 0; level < (unsigned)k - cap_height; ++level) {
     const bool last = level + 1 == (unsigned)k - cap_height;
     u64* dst = last ? d_cap_out : (d_digests_out ? next_store : ping + (level & 1 ? 0 : 4 * (n / 2)));
@@ -400,17 +399,10 @@ extern "C" int p2mt_merkle_cap_commit_dev(const uint64_t* d_leaves, size_t n, si
   const int k = log2_strict(n);
   if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree::new: n must be a power of two >= 2^cap_height");
   if (!d_leaves || !d_cap_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
-  DevBuf lvl0, scratch;
   u64* d_level0 = d_digests_out;
-  if (!d_level0 || (unsigned)k == cap_height) {
-    P2MT_TRY(lvl0.alloc(n * 32));
-    d_level0 = lvl0.as<u64>();
-  }
+  if (!d_level0 || (unsigned)k == cap_height) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, n * 32, (void**)&d_level0));
   P2MT_TRY(p2mt::launch_hash_rows_dev(d_leaves, n, width, 1, d_level0));
-  P2MT_TRY(merkle_levels_to_cap(d_level0, n, cap_height, (unsigned)k == cap_height ? nullptr : d_digests_out, d_cap_out,
-                                scratch));
-  P2MT_HIP(hipStreamSynchronize(rt().stream));
-  return P2MT_OK;
+  return merkle_levels_to_cap(d_level0, n, cap_height, (unsigned)k == cap_height ? nullptr : d_digests_out, d_cap_out);
 }
 
 static size_t digests_count(size_t n, unsigned cap_height) {
@@ -449,36 +441,36 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
   if (cap_height > log_big) return p2mt::fail(P2MT_EINVAL, "cap_height exceeds tree height");
   const size_t n = (size_t)1 << log_n, big = (size_t)1 << log_big;
   hipStream_t st = rt().stream;
-  DevBuf coeffs, lde, lvl0, scratch;
   const u64* d_coeffs = d_polys;
   if (is_values) {  // IFFT: DIF with inverse roots, then bit-reversal + 1/n
-    P2MT_TRY(coeffs.alloc(n_polys * n * 8 * 2));
-    u64* work = coeffs.as<u64>() + n_polys * n;
+    u64* buf;
+    P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8 * 2, (void**)&buf));
+    u64* work = buf + n_polys * n;
     P2MT_HIP(hipMemcpyAsync(work, d_polys, n_polys * n * 8, hipMemcpyDeviceToDevice, st));
     P2MT_TRY(ntt_dif_dev(work, log_n, n_polys, 1));
     const u64 n_inv = h_pow((u64)n % gl::P, gl::P - 2);
-    hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(n_polys * n)), dim3(kBlock), 0, st, (const u64*)work, coeffs.as<u64>(),
-                       log_n, n_polys, n_inv);
+    hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(n_polys * n)), dim3(kBlock), 0, st, (const u64*)work, buf, log_n, n_polys,
+                       n_inv);
     P2MT_LAUNCH_CHECK();
-    d_coeffs = coeffs.as<u64>();
+    d_coeffs = buf;
   }
-  P2MT_TRY(lde.alloc(n_polys * big * 8));
-  P2MT_TRY(coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde.as<u64>()));
+  u64* lde;
+  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
+  {
+    const int slot = p2mt::prof_begin();
+    P2MT_TRY(coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
+    p2mt::prof_end(slot);
+  }
   if (d_leaves_out) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
-                       (const u64*)lde.as<u64>(), d_leaves_out, n_polys, big);
+                       (const u64*)lde, d_leaves_out, n_polys, big);
     P2MT_LAUNCH_CHECK();
   }
   const bool cap_is_leaves = cap_height == log_big;
   u64* d_level0 = (d_digests_out && !cap_is_leaves) ? d_digests_out : nullptr;
-  if (!d_level0) {
-    P2MT_TRY(lvl0.alloc(big * 32));
-    d_level0 = lvl0.as<u64>();
-  }
-  P2MT_DISPATCH(k_hash_columns, grid_for(big), kBlock, (const u64*)lde.as<u64>(), n_polys, big, d_level0);
-  P2MT_TRY(merkle_levels_to_cap(d_level0, big, cap_height, cap_is_leaves ? nullptr : d_digests_out, d_cap_out, scratch));
-  P2MT_HIP(hipStreamSynchronize(st));  // scratch buffers die with this call
-  return P2MT_OK;
+  if (!d_level0) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, big * 32, (void**)&d_level0));
+  P2MT_DISPATCH(k_hash_columns, grid_for(big), kBlock, (const u64*)lde, n_polys, big, d_level0);
+  return merkle_levels_to_cap(d_level0, big, cap_height, cap_is_leaves ? nullptr : d_digests_out, d_cap_out);
 }
 
 extern "C" int p2mt_polynomial_batch_commit(const uint64_t* polys, int is_values, size_t n_polys, unsigned log_n,

@@ -321,26 +321,21 @@ __global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ ele
   const unsigned w = lane < 12 ? lane : 0;  // lanes >= 12 shadow lane 0 (results unused)
 
   u64 x = lane < 4 ? lp[lane] : (lane < 8 ? rp[lane - 4] : 0);
-  u64 rcv[POSEIDON_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < POSEIDON_ROUNDS; ++r) rcv[r] = ctx.rc[12 * r + w];
   u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
 #pragma unroll
   for (int c = 0; c < 12; ++c) kk[c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - w) % 12] + ((w == 0 && c == 0) ? 8u : 0u);
 
   u64 sticky = 0;
-  x = gl::add_c(x, rcv[0]);
-#pragma unroll
-  for (int r = 0; r < POSEIDON_ROUNDS; ++r) {
-    const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
+  const u64* rcw = ctx.rc + w;     // this lane's column of the round-constant table
+  u64 c_next = rcw[12];            // constant of round r+1, fetched one round ahead (hidden under the S-box)
+  x = gl::add_c(x, rcw[0]);
+  // one round: S-box (every lane in a full round, lane 0 in a partial one), then this lane's MDS row with the
+  // next round's constant folded into the two mad chains
+  auto round = [&](bool full, bool add, u64 c_fold) {
     const u64 y = poseidon_fast::pow7(x, sticky);
     if (full || lane == 0) x = y;
     const u32 xl = (u32)x, xh = (u32)(x >> 32);
-    u64 al = 0, ah = 0;
-    if (r + 1 < POSEIDON_ROUNDS) {  // next round's constant folded into the chains
-      al = (u64)(u32)rcv[r + 1];
-      ah = (u64)(u32)(rcv[r + 1] >> 32);
-    }
+    u64 al = add ? (u64)(u32)c_fold : 0, ah = add ? (u64)(u32)(c_fold >> 32) : 0;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
       const u32 sl = (u32)__builtin_amdgcn_readlane((int)xl, c), sh = (u32)__builtin_amdgcn_readlane((int)xh, c);
@@ -352,7 +347,15 @@ __global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ ele
     u64 cm;
     x = poseidon_fast::mad_eps_carry((u32)(ah >> 32), val, cm);
     sticky |= cm;
+  };
+#pragma unroll 1
+  for (int r = 0; r < POSEIDON_ROUNDS - 1; ++r) {
+    const u64 c_fold = c_next;
+    if (r + 2 < POSEIDON_ROUNDS) c_next = rcw[12 * (r + 2)];
+    const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
+    round(full, true, c_fold);
   }
+  round(true, false, 0);
   sticky |= ctx.force_fallback;
   if (__builtin_expect(sticky != 0, 0)) {  // rare: lane 0 redoes the node with the exact lane-per-hash code
     if (lane == 0) {
@@ -876,6 +879,7 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
       const unsigned grid = (unsigned)((b - a) >> span_log);
       const size_t t0 = a >> span_log;
       const p2mt::PermCtx ctx = p2mt::perm_ctx();
+      const int prof_slot = h0 == 0 ? p2mt::prof_begin() : -1;  // stage 1 is the dominant launch
 #define P2MT_TILE(M, PR, TL) \
   hipLaunchKernelGGL((k_mmr_tile<M, PR, TL>), dim3(grid), dim3(kBlock), 0, st, (const u64*)d_leaves, n0, m->elements, h0, n_lev, t0, ctx)
       if (rt().mds == 2) {
@@ -889,6 +893,7 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
       }
 #undef P2MT_TILE
       P2MT_LAUNCH_CHECK();
+      p2mt::prof_end(prof_slot);
     }
     for (unsigned h = h0 + 1; h <= h0 + n_lev; ++h) {  // ragged edges of the fused levels
       P2MT_TRY(launch_level(m, h, n0 >> h, a >> h));

@@ -27,6 +27,11 @@ struct Runtime {
   int force_fallback = 0;
   unsigned tile_log = 10;    // fused MMR stage: 2^tile_log inputs per workgroup (env P2MT_TILE_LOG = 9|10|11)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  // per-kernel HIP-event profiling of the dominant launches (p2mt_profile_*): pairs recorded around each launch
+  bool profile = false;
+  static constexpr int kMaxProf = 256;
+  hipEvent_t prof_ev[2 * kMaxProf] = {};
+  int prof_n = 0;
   char err[512] = {0};
 };
 
@@ -34,7 +39,15 @@ Runtime& rt();
 int fail_hip(hipError_t e, const char* what, const char* file, int line);
 int fail(int code, const char* msg);
 int ensure_init();
+// record an event on the library stream if profiling is on (slot = 2*i for start, 2*i+1 for stop)
+int prof_begin();
+void prof_end(int slot);
 inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ull : 0ull}; }
+
+// Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
+// synchronisation) on the steady-state path; all users run on the one library stream, in order.
+enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchCount };
+int scratch_get(int slot, size_t bytes, void** out);
 
 // RAII device scratch buffer
 struct DevBuf {

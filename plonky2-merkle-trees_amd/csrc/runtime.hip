@@ -24,6 +24,43 @@ int fail(int code, const char* msg) {
   return code;
 }
 
+int scratch_get(int slot, size_t bytes, void** out) {
+  static void* ptr[kScratchCount] = {};
+  static size_t cap[kScratchCount] = {};
+  if (bytes == 0) bytes = 8;
+  if (bytes > cap[slot]) {
+    if (ptr[slot]) {
+      (void)hipStreamSynchronize(rt().stream);  // earlier kernels may still read the old buffer
+      (void)hipFree(ptr[slot]);
+      ptr[slot] = nullptr;
+      cap[slot] = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(&ptr[slot], want) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(P2MT_ENOMEM, "hipMalloc(scratch) failed");
+    }
+    cap[slot] = want;
+  }
+  *out = ptr[slot];
+  return P2MT_OK;
+}
+
+int prof_begin() {
+  Runtime& r = rt();
+  if (!r.profile || r.prof_n >= Runtime::kMaxProf) return -1;
+  const int i = r.prof_n++;
+  if (!r.prof_ev[2 * i]) {
+    if (hipEventCreate(&r.prof_ev[2 * i]) != hipSuccess || hipEventCreate(&r.prof_ev[2 * i + 1]) != hipSuccess) return -1;
+  }
+  (void)hipEventRecord(r.prof_ev[2 * i], r.stream);
+  return i;
+}
+
+void prof_end(int slot) {
+  if (slot >= 0) (void)hipEventRecord(rt().prof_ev[2 * slot + 1], rt().stream);
+}
+
 int ensure_init() {
   if (rt().initialised) return P2MT_OK;
   return p2mt_init(rt().device);
@@ -105,6 +142,29 @@ extern "C" int p2mt_debug_force_fallback(int on) {
 extern "C" int p2mt_get_variant(int* mds, int* partial) {
   if (mds) *mds = rt().mds;
   if (partial) *partial = rt().partial;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_profile_enable(int on) {
+  rt().profile = on != 0;
+  rt().prof_n = 0;
+  return P2MT_OK;
+}
+
+// Sum and count of the HIP-event durations recorded around the dominant kernel launches since the last
+// p2mt_profile_enable(1); synchronises the stream.
+extern "C" int p2mt_profile_read(float* total_ms, int* launches) {
+  P2MT_TRY(p2mt::ensure_init());
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  float sum = 0;
+  for (int i = 0; i < rt().prof_n; ++i) {
+    float ms = 0;
+    P2MT_HIP(hipEventElapsedTime(&ms, rt().prof_ev[2 * i], rt().prof_ev[2 * i + 1]));
+    sum += ms;
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = rt().prof_n;
+  rt().prof_n = 0;
   return P2MT_OK;
 }
 
