@@ -1,0 +1,181 @@
+// p2mt.hpp -- C++ host-side mirror of the reference's public Rust API over the C ABI (p2mt.h).
+//
+// The reference is compiled code (Rust) and this image has no Rust toolchain, so the host side above the C ABI
+// is written in C++ with the reference's names, argument meaning and error behaviour:
+//   src/simple_merkle_tree/simple_merkle_tree.rs : MerkleTree::{build, get_merkle_proof, get_in_between_hashes},
+//                                                  verify_merkle_proof
+//   src/mmr/merkle_mountain_ranges.rs            : MMR::{new_, add_leaf, bagging_the_peaks, get_peaks, get_proof,
+//                                                  get_proof_normal_index, get_subtree_proof_elm}, MMR_proof::verify,
+//                                                  get_mmr_index, get_heights_bitmap_for_mmr_size
+// Where the reference panics (assert!/unwrap/log2_strict) this throws p2mt::panic carrying the status code.
+// Getters take `this` by const reference instead of consuming `self` (Quirk Q7: callers no longer clone).
+// All hashing happens in libp2mt_hip.so on the GPU; this header only moves buffers.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "p2mt.h"
+
+namespace p2mt {
+
+using GoldilocksField = std::uint64_t;  // transparent u64, canonical on output
+constexpr std::uint64_t GOLDILOCKS_FIELD_ORDER = P2MT_GOLDILOCKS_FIELD_ORDER;  // src/mmr/common.rs:3
+
+struct HashOut {
+  std::array<std::uint64_t, 4> elements{};
+  bool operator==(const HashOut& o) const { return elements == o.elements; }
+  bool operator!=(const HashOut& o) const { return !(*this == o); }
+};
+static_assert(sizeof(HashOut) == 32, "HashOut must be the 32-byte record of the C ABI");
+
+struct panic : std::runtime_error {
+  int code;
+  panic(int c, const std::string& m) : std::runtime_error("p2mt panic (" + std::to_string(c) + "): " + m), code(c) {}
+};
+inline void check(int rc) {
+  if (rc != P2MT_OK) throw panic(rc, p2mt_last_error());
+}
+
+// ---------------------------------------------------------------- simple_merkle_tree.rs
+struct MerkleTree {
+  std::size_t count_levels = 0;
+  std::vector<std::vector<HashOut>> tree;  // levels 0 .. count_levels-1
+  HashOut root;
+
+  static MerkleTree build(const std::vector<GoldilocksField>& leaves) {  // :28-51
+    const std::size_t n = leaves.size();
+    std::vector<HashOut> flat(n >= 2 ? 2 * n - 2 : 1);
+    MerkleTree t;
+    check(p2mt_merkle_build_pow2(leaves.data(), n, flat[0].elements.data(), t.root.elements.data()));
+    for (std::size_t cnt = n, off = 0; cnt >= 2; off += cnt, cnt /= 2) {
+      t.tree.emplace_back(flat.begin() + off, flat.begin() + off + cnt);
+      ++t.count_levels;
+    }
+    return t;
+  }
+
+  std::vector<HashOut> get_merkle_proof(std::size_t leaf_index) const {  // :55-74
+    if (tree.empty() || leaf_index >= tree[0].size()) throw panic(P2MT_EINVAL, "assert!(leaf_index < self.tree[0].len())");
+    std::vector<HashOut> proof;
+    std::size_t idx = leaf_index;
+    for (std::size_t i = 0; i < count_levels; ++i, idx /= 2) proof.push_back(tree[i][idx ^ 1]);
+    return proof;
+  }
+
+  std::vector<HashOut> get_in_between_hashes(std::size_t leaf_index) const {  // :76-86
+    if (tree.empty() || leaf_index >= tree[0].size()) throw panic(P2MT_EINVAL, "assert!(leaf_index < self.tree[0].len())");
+    std::vector<HashOut> hashes;
+    std::size_t idx = leaf_index / 2;
+    for (std::size_t i = 1; i < count_levels; ++i, idx /= 2) hashes.push_back(tree[i][idx]);
+    hashes.push_back(root);
+    return hashes;
+  }
+};
+
+inline bool verify_merkle_proof(GoldilocksField leaf, std::size_t leaf_index, const HashOut& root,
+                                const std::vector<HashOut>& hashes) {  // :91-109
+  const std::uint64_t idx = leaf_index;
+  std::uint8_t ok = 0;
+  check(p2mt_verify_merkle_proof_batch(&leaf, &idx, root.elements.data(),
+                                       hashes.empty() ? nullptr : hashes[0].elements.data(), hashes.size(), 1, &ok));
+  return ok != 0;
+}
+
+// ---------------------------------------------------------------- merkle_mountain_ranges.rs
+inline std::pair<std::uint64_t, std::size_t> get_heights_bitmap_for_mmr_size(std::size_t mmr_size) {  // :39-81
+  std::size_t rem = 0;
+  const std::uint64_t bm = p2mt_get_heights_bitmap_for_mmr_size(mmr_size, &rem);
+  return {bm, rem};
+}
+
+inline std::size_t get_mmr_index(std::size_t leaf_normal_index) {  // :257-270
+  const std::int64_t r = p2mt_get_mmr_index(leaf_normal_index);
+  if (r < 0) throw panic((int)r, "get_mmr_index: i32 overflow (n >= 2^30)");
+  return (std::size_t)r;
+}
+
+struct MMR_proof {  // :15-23
+  std::size_t mmr_size = 0;
+  std::vector<std::pair<HashOut, bool>> merkle_proof;  // (sibling, sibling_on_left)
+  std::vector<HashOut> peaks;
+
+  bool verify(GoldilocksField leaf, const HashOut& root) const {  // :232-252 (panics at :245 if not among peaks)
+    std::vector<HashOut> sib(merkle_proof.size());
+    std::vector<std::uint8_t> lefts(merkle_proof.size());
+    for (std::size_t i = 0; i < merkle_proof.size(); ++i) {
+      sib[i] = merkle_proof[i].first;
+      lefts[i] = merkle_proof[i].second ? 1 : 0;
+    }
+    int result = 0;
+    check(p2mt_mmr_proof_verify(sib.empty() ? nullptr : sib[0].elements.data(), lefts.data(), (int)sib.size(),
+                                peaks.empty() ? nullptr : peaks[0].elements.data(), (int)peaks.size(), leaf,
+                                root.elements.data(), &result));
+    return result != 0;
+  }
+};
+
+class MMR {  // struct MMR { elements: Vec<HashOut> }, device-resident (:8-12)
+ public:
+  MMR() { check(p2mt_mmr_create(&h_)); }
+  ~MMR() { p2mt_mmr_destroy(h_); }
+  MMR(const MMR&) = delete;
+  MMR& operator=(const MMR&) = delete;
+  MMR(MMR&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+
+  static MMR new_() { return MMR(); }  // MMR::new (:84-86)
+  static MMR from_leaves(const std::vector<GoldilocksField>& leaves) {
+    MMR m;
+    m.extend(leaves);
+    return m;
+  }
+
+  void add_leaf(GoldilocksField leaf) { check(p2mt_mmr_extend(h_, &leaf, 1)); }  // :89-120
+  void extend(const std::vector<GoldilocksField>& leaves) { check(p2mt_mmr_extend(h_, leaves.data(), leaves.size())); }
+  void reserve(std::size_t n_leaves) { check(p2mt_mmr_reserve(h_, n_leaves)); }
+
+  std::size_t len() const { return p2mt_mmr_len(h_); }
+  std::size_t num_leaves() const { return p2mt_mmr_num_leaves(h_); }
+  std::vector<HashOut> elements() const {
+    std::vector<HashOut> out(len());
+    if (!out.empty()) check(p2mt_mmr_copy_elements(h_, 0, out.size(), out[0].elements.data()));
+    return out;
+  }
+
+  HashOut bagging_the_peaks() const {  // :122-127
+    HashOut r;
+    check(p2mt_mmr_root(h_, r.elements.data()));
+    return r;
+  }
+  std::vector<HashOut> get_peaks() const {  // :179-200
+    std::vector<HashOut> p(P2MT_MAX_PROOF_LEN);
+    int n = 0;
+    check(p2mt_mmr_peaks(h_, p[0].elements.data(), &n));
+    p.resize(n);
+    return p;
+  }
+  MMR_proof get_proof(std::size_t mmr_index) const {  // :209-223
+    std::vector<HashOut> sib(P2MT_MAX_PROOF_LEN), peaks(P2MT_MAX_PROOF_LEN);
+    std::vector<std::uint8_t> lefts(P2MT_MAX_PROOF_LEN);
+    int ns = 0, np = 0;
+    MMR_proof pr;
+    check(p2mt_mmr_proof(h_, mmr_index, sib[0].elements.data(), lefts.data(), &ns, peaks[0].elements.data(), &np,
+                         &pr.mmr_size));
+    for (int i = 0; i < ns; ++i) pr.merkle_proof.emplace_back(sib[i], lefts[i] != 0);
+    pr.peaks.assign(peaks.begin(), peaks.begin() + np);
+    return pr;
+  }
+  MMR_proof get_proof_normal_index(std::size_t normal_index) const { return get_proof(get_mmr_index(normal_index)); }  // :203-205
+  std::vector<std::pair<HashOut, bool>> get_subtree_proof_elm(std::size_t mmr_index) const {  // :147-176
+    return get_proof(mmr_index).merkle_proof;
+  }
+  p2mt_mmr* handle() const { return h_; }
+
+ private:
+  p2mt_mmr* h_ = nullptr;
+};
+
+}  // namespace p2mt

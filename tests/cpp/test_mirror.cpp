@@ -1,0 +1,123 @@
+// The reference's own unit tests, re-expressed against the C++ mirror (include/p2mt.hpp).  Runs on a GPU box.
+//   simple_merkle_tree.rs:117-309  (5 tests), merkle_mountain_ranges.rs:278-374 (4 tests)
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../include/p2mt.hpp"
+
+using namespace p2mt;
+#define REQUIRE(x) do { if (!(x)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); std::exit(1); } } while (0)
+
+static HashOut H(std::uint64_t a, std::uint64_t b, std::uint64_t c, std::uint64_t d) { return HashOut{{a, b, c, d}}; }
+
+static const std::vector<GoldilocksField> k16 = {
+    14786323743454721611ull, 976503040092093812ull,  4644130751253292674ull,  6522877527545910706ull,
+    11021172818651636092ull, 12048403458499719587ull, 11457874926809001558ull, 14982007443548219923ull,
+    4546369223935415035ull,  7205140577604465038ull, 4644130751253292674ull,  4208177174652750506ull,
+    16147116534354400672ull, 18147003476480002882ull, 14133393155459789216ull, 9890944065319669426ull};
+
+static void test_build_merkle_tree_4_leaves() {  // :119-144, values printed at :136-140
+  MerkleTree t = MerkleTree::build({2890852870ull, 156728478ull, 2876514289ull, 984286162ull});
+  REQUIRE(t.count_levels == 2);
+  REQUIRE(t.tree[0][0] == H(2890852870ull, 0, 0, 0) && t.tree[0][3] == H(984286162ull, 0, 0, 0));
+  REQUIRE(t.tree[1][0] == H(6678006133445961348ull, 15827935749738443865ull, 6295652393730592048ull, 1546515167911236130ull));
+  REQUIRE(t.tree[1][1] == H(6698018865469624861ull, 12486244005715193285ull, 11330639022572315007ull, 6059804404595156248ull));
+  REQUIRE(t.root == H(13451271846715771774ull, 4069913004933160254ull, 14528216580130305557ull, 9716424959297545638ull));
+}
+
+static void test_build_merkle_tree_16_leaves() {  // :146-194
+  MerkleTree t = MerkleTree::build(k16);
+  REQUIRE(t.count_levels == 4);
+  REQUIRE(t.tree[3][1] == H(14079844864384152521ull, 6499705357519308869ull, 16026207645313349904ull, 15079809878245341298ull));
+  REQUIRE(t.root == H(2659148958598424285ull, 16496267010313658247ull, 12216516055477211974ull, 15749220035779350537ull));
+}
+
+static void test_merkle_proof_small_tree() {  // :196-212 (the asserted values)
+  MerkleTree t = MerkleTree::build({2890852870ull, 156728478ull, 2876514289ull, 984286162ull});
+  auto p = t.get_merkle_proof(0);
+  REQUIRE(p[0] == H(156728478ull, 0, 0, 0));
+  REQUIRE(p[1] == H(6698018865469624861ull, 12486244005715193285ull, 11330639022572315007ull, 6059804404595156248ull));
+}
+
+static void test_verify_merkle_proof_16() {  // :236-308 incl. the negative cases
+  MerkleTree t = MerkleTree::build(k16);
+  for (std::size_t i = 0; i < 16; ++i) REQUIRE(verify_merkle_proof(k16[i], i, t.root, t.get_merkle_proof(i)));
+  auto p0 = t.get_merkle_proof(0), p1 = t.get_merkle_proof(1);
+  REQUIRE(!verify_merkle_proof(k16[1], 0, t.root, p0));        // wrong leaf
+  REQUIRE(!verify_merkle_proof(k16[0], 1, t.root, p0));        // wrong index
+  REQUIRE(!verify_merkle_proof(k16[0], 0, t.root, p1));        // wrong proof
+  REQUIRE(!verify_merkle_proof(k16[0], 0, t.tree[0][0], p0));  // wrong root
+  bool threw = false;
+  try { MerkleTree::build({1, 2, 3}); } catch (const panic&) { threw = true; }  // log2_strict panic :30
+  REQUIRE(threw);
+}
+
+static void test_heights_bitmap() {  // merkle_mountain_ranges.rs:279-303
+  const std::pair<std::size_t, std::uint64_t> tv[] = {{1, 1}, {3, 2}, {4, 3}, {7, 4}, {10, 6}, {15, 8}, {22, 12}, {25, 14},
+                                                      {26, 15}, {31, 16}, {32, 17}, {34, 18}, {35, 19}, {38, 20}, {41, 22}, {42, 23}};
+  for (auto& v : tv) {
+    REQUIRE(get_heights_bitmap_for_mmr_size(v.first).first == v.second);
+    REQUIRE(get_heights_bitmap_for_mmr_size(v.first).second == 0);
+  }
+}
+
+static void test_get_mmr_index() {  // :305-329
+  const std::size_t tv[][2] = {{0, 0}, {1, 1}, {2, 3}, {3, 4}, {4, 7}, {5, 8}, {6, 10}, {7, 11}, {8, 15}, {9, 16}, {10, 18},
+                               {11, 19}, {12, 22}, {13, 23}, {14, 25}, {15, 26}};
+  for (auto& v : tv) REQUIRE(get_mmr_index(v[0]) == v[1]);
+}
+
+static std::vector<GoldilocksField> random_leaves(std::size_t n, unsigned seed) {
+  std::mt19937_64 rng(seed);
+  std::uniform_int_distribution<std::uint64_t> d(0, GOLDILOCKS_FIELD_ORDER - 1);  // gen_range(0..GOLDILOCKS_FIELD_ORDER)
+  std::vector<GoldilocksField> v(n);
+  for (auto& x : v) x = d(rng);
+  return v;
+}
+
+static void test_mmr_add_leaf() {  // :331-341: 100 leaves one by one
+  MMR mmr = MMR::new_();
+  auto leaves = random_leaves(100, 1);
+  for (auto l : leaves) mmr.add_leaf(l);
+  REQUIRE(mmr.len() == 197);  // 2*100 - popcount(100)
+  MMR bulk = MMR::from_leaves(leaves);
+  REQUIRE(mmr.elements() == bulk.elements());
+}
+
+static void test_get_proof() {  // :343-374 (the reference prints; here the result is asserted)
+  auto leaves = random_leaves(16, 2);
+  MMR mmr = MMR::new_();
+  for (auto l : leaves) mmr.add_leaf(l);
+  const std::size_t standard_index = 4, leaf_index = 7;
+  MMR_proof proof = mmr.get_proof(leaf_index);
+  HashOut root = mmr.bagging_the_peaks();
+  REQUIRE(proof.mmr_size == 31 && proof.peaks.size() == 1 && proof.merkle_proof.size() == 4);
+  REQUIRE(proof.verify(leaves[standard_index], root));
+  REQUIRE(mmr.get_proof_normal_index(standard_index).merkle_proof == proof.merkle_proof);
+  bool threw = false;
+  try { proof.verify(leaves[standard_index + 1], root); } catch (const panic& e) { threw = e.code == P2MT_ENOTPEAK; }  // :245
+  REQUIRE(threw);
+  // every leaf of MMRs with 3, 7, 31, 70 leaves (mmr_plonky2_verifier.rs:153-193, native part :113-117)
+  for (std::size_t n : {3u, 7u, 31u, 70u}) {
+    auto lv = random_leaves(n, 10 + (unsigned)n);
+    MMR m = MMR::from_leaves(lv);
+    HashOut r = m.bagging_the_peaks();
+    for (std::size_t i = 0; i < n; ++i) REQUIRE(m.get_proof_normal_index(i).verify(lv[i], r));
+  }
+}
+
+int main() {
+  if (p2mt_device_count() == 0) { std::fprintf(stderr, "no GPU: the product has no CPU fallback\n"); return 77; }
+  check(p2mt_init(0));
+  test_build_merkle_tree_4_leaves();
+  test_build_merkle_tree_16_leaves();
+  test_merkle_proof_small_tree();
+  test_verify_merkle_proof_16();
+  test_heights_bitmap();
+  test_get_mmr_index();
+  test_mmr_add_leaf();
+  test_get_proof();
+  std::puts("cpp mirror: 8 reference tests passed");
+  return 0;
+}
