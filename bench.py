@@ -100,7 +100,7 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
     pkg._native.check(lib.p2mt_profile_read(C.byref(kern_ms), C.byref(kern_n)))
     lib.p2mt_profile_enable(0)
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -227,6 +227,10 @@ def main():
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
     ap.add_argument("--workload", default="mmr", choices=["mmr", "commit"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --single-device exist only to exercise the N>1 code "
+                         "path on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="test only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -238,15 +242,19 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     pkg = ge.load_package()
-    pkg.init(local_rank)
+    pkg.init(dev_index)
     if args.variant:
         pkg.set_variant(*[int(x) for x in args.variant.split(",")])
     lib = pkg.lib()

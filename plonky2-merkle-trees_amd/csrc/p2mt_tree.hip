@@ -310,14 +310,10 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
 // over the words broadcast with v_readlane (SGPR operands) against that lane's row of constants.  All 30 rounds
 // are unrolled with the lane's round constants preloaded, so a node takes ~3.5k instructions instead of ~28k.
 // Used for levels of <= 2^15 nodes; bit-identical to the lane-per-hash kernels (same primitives, same fallback).
-__global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
-                                                           PermCtx ctx) {
+// out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
+GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
+                            const PermCtx& ctx) {
   const unsigned lane = threadIdx.x & 63;
-  const size_t j = j0 + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (j >= j1) return;  // wave-uniform
-  const size_t pos = node_pos(((j + 1) << h) - 1, h);
-  const u64* lp = elements + 4 * (pos - ((size_t)1 << h));
-  const u64* rp = elements + 4 * (pos - 1);
   const unsigned w = lane < 12 ? lane : 0;  // lanes >= 12 shadow lane 0 (results unused)
 
   u64 x = lane < 4 ? lp[lane] : (lane < 8 ? rp[lane - 4] : 0);
@@ -365,11 +361,28 @@ __global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ ele
       s[8] = s[9] = s[10] = s[11] = 0;
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
       u64 o[4] = {gl::canon(s[0]), gl::canon(s[1]), gl::canon(s[2]), gl::canon(s[3])};
-      store_hash(elements + 4 * pos, o);
+      store_hash(out, o);
     }
     return;
   }
-  if (lane < 4) elements[4 * pos + lane] = gl::canon(x);
+  if (lane < 4) out[lane] = gl::canon(x);
+}
+
+// MMR level (post-order, in place): node j of height h
+__global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
+                                                           PermCtx ctx) {
+  const size_t j = j0 + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (j >= j1) return;  // wave-uniform
+  const size_t pos = node_pos(((j + 1) << h) - 1, h);
+  two_to_one_wave(elements + 4 * (pos - ((size_t)1 << h)), elements + 4 * (pos - 1), elements + 4 * pos, ctx);
+}
+
+// level-major tree level: out[j] = two_to_one(in[2j], in[2j+1])
+__global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+                                                              PermCtx ctx) {
+  const size_t j = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (j >= n_out) return;  // wave-uniform
+  two_to_one_wave(in + 8 * j, in + 8 * j + 4, out + 4 * j, ctx);
 }
 
 struct PosList {
@@ -541,6 +554,13 @@ int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, 
 }
 int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
   if (n_out == 0) return P2MT_OK;
+  if (n_out <= ((size_t)1 << 12) && rt().mds == 2) {  // small level: one wavefront per node (latency path)
+    const unsigned per_block = kBlock / 64;
+    hipLaunchKernelGGL(k_merkle_level_wave, dim3((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
+                       rt().stream, d_in, d_out, n_out, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
   P2MT_DISPATCH(k_merkle_level, grid_for(n_out), kBlock, d_in, d_out, n_out);
   return P2MT_OK;
 }
