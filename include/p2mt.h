@@ -137,6 +137,13 @@ int p2mt_mmr_proof_verify_batch(const uint64_t *siblings /*[m][max_siblings][4]*
                                 const uint64_t *leaves /*[m]*/, const uint64_t *root, size_t m,
                                 int8_t *status_out /*[m]*/);
 
+/* On-disk checkpoint of the MMR state (the reference keeps `elements` only in memory and has no serde).
+ * File = 32-byte header {magic "P2MTMMR1", u64 n_leaves, u64 n_elements, u64 xor-fold checksum of the payload}
+ * followed by `elements` as little-endian u64 x 4 records in post-order -- byte-identical to the reference's
+ * Vec<HashOut<GoldilocksField>> contents.  load replaces the handle's state; extend continues from it. */
+int p2mt_mmr_save(const p2mt_mmr *m, const char *path);
+int p2mt_mmr_load(p2mt_mmr *m, const char *path);
+
 /* ------------------------------------------------------------------ multi-GPU sharded build
  * Rank r of `world` (both powers of two) owns leaves [r*n_local, (r+1)*n_local) of a 2^k-leaf MMR and
  * builds that perfect subtree locally with p2mt_mmr_extend*.  After an all-gather of the `world`

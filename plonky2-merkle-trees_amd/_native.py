@@ -61,6 +61,8 @@ SIGNATURES = {
     "p2mt_mmr_len": (C.c_size_t, [voidp]),
     "p2mt_mmr_elements_dev": (voidp, [voidp]),
     "p2mt_mmr_copy_elements": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_mmr_save": (C.c_int, [voidp, C.c_char_p]),
+    "p2mt_mmr_load": (C.c_int, [voidp, C.c_char_p]),
     "p2mt_mmr_peaks": (C.c_int, [voidp, voidp, intp]),
     "p2mt_mmr_root": (C.c_int, [voidp, voidp]),
     "p2mt_mmr_proof": (C.c_int, [voidp, C.c_size_t, voidp, voidp, intp, voidp, intp, sizep]),

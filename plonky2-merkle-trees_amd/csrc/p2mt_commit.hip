@@ -20,7 +20,7 @@
 //     coalesced 8-byte loads), so hashing never needs the transposed leaf-major matrix; the transpose to
 //     plonky2's leaf-major `leaves` is only produced when the caller asks for it.
 //   All of it is HBM/LDS-bound integer work: no MFMA.
-#include "poseidon_fast.hip.h"
+#include "poseidon_quad.hip.h"
 #include "runtime.h"
 
 #include <map>
@@ -183,6 +183,52 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__
   ulonglong2* q = reinterpret_cast<ulonglong2*>(digests + 4 * i);
   q[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
   q[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
+}
+
+// The same leaf sponge on four lanes per column (latency path for <= 2^16 leaves): lane q of a quad owns state words
+// 3q..3q+2, so of each 8-word chunk it loads the (up to 3) words it owns.
+__global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restrict__ in, size_t w, size_t n_pts,
+                                                              u64* __restrict__ digests, p2mt::PermCtx ctx) {
+  const size_t col = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 2;
+  if (col >= n_pts) return;  // quad-uniform
+  poseidon_quad::Lane ln;
+  poseidon_quad::lane_init(ln, ctx.rc);
+  u64 x[3] = {0, 0, 0};
+  u64 sticky = ctx.force_fallback;
+#pragma unroll 1
+  for (size_t off = 0; off < w; off += 8) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const u32 wd = 3 * ln.q + i;
+      if (wd < 8 && off + wd < w) x[i] = in[(off + wd) * n_pts + col];
+    }
+    sticky |= poseidon_quad::permute(x, ln);
+  }
+  u64* out = digests + 4 * col;
+  if (__builtin_expect(sticky != 0, 0)) {  // rare: lane 0 of the quad redoes the column with the exact code
+    if (ln.q == 0) {
+      u64 s[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) s[k] = 0;
+#pragma unroll 1
+      for (size_t off = 0; off < w; off += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (off + k < w) s[k] = in[(off + k) * n_pts + col];
+        poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[k] = gl::canon(s[k]);
+    }
+    return;
+  }
+  if (ln.q == 0) {
+    out[0] = gl::canon(x[0]);
+    out[1] = gl::canon(x[1]);
+    out[2] = gl::canon(x[2]);
+  } else if (ln.q == 1) {
+    out[3] = gl::canon(x[0]);
+  }
 }
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -469,7 +515,13 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
   const bool cap_is_leaves = cap_height == log_big;
   u64* d_level0 = (d_digests_out && !cap_is_leaves) ? d_digests_out : nullptr;
   if (!d_level0) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, big * 32, (void**)&d_level0));
-  P2MT_DISPATCH(k_hash_columns, grid_for(big), kBlock, (const u64*)lde, n_polys, big, d_level0);
+  if (n_polys > 4 && big <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_hash_columns_quad, dim3(grid_for(4 * big)), dim3(kBlock), 0, st, (const u64*)lde, n_polys, big,
+                       d_level0, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+  } else {
+    P2MT_DISPATCH(k_hash_columns, grid_for(big), kBlock, (const u64*)lde, n_polys, big, d_level0);
+  }
   return merkle_levels_to_cap(d_level0, big, cap_height, cap_is_leaves ? nullptr : d_digests_out, d_cap_out);
 }
 

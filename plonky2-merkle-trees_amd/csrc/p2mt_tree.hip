@@ -8,7 +8,7 @@
 // One lane computes one node (poseidon.hip.h); a level of the tree is one launch.  The MMR is built
 // level-synchronously straight into its post-order positions: the node of height h whose last leaf is L
 // lives at 2L - popcount(L) + h, its right child at pos-1, its left child at pos-2^h.
-#include "poseidon_fast.hip.h"
+#include "poseidon_quad.hip.h"
 #include "runtime.h"
 
 #include <string.h>
@@ -385,6 +385,57 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restr
   two_to_one_wave(in + 8 * j, in + 8 * j + 4, out + 4 * j, ctx);
 }
 
+// ---------------------------------------------------------------- four lanes per node (poseidon_quad.hip.h)
+// out[0..4) = two_to_one(lp, rp) computed by the calling quad (all four lanes call it with the same pointers)
+GL_DEV void two_to_one_quad(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
+                            const poseidon_quad::Lane& ln, const PermCtx& ctx) {
+  u64 x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const u32 w = 3 * ln.q + i;
+    x[i] = w < 4 ? lp[w] : (w < 8 ? rp[w - 4] : 0);
+  }
+  const u64 sticky = poseidon_quad::permute(x, ln) | ctx.force_fallback;
+  if (__builtin_expect(sticky != 0, 0)) {  // rare: the quad's lane 0 redoes the node with the exact code
+    if (ln.q == 0) {
+      u64 s[12];
+      load_hash(lp, *reinterpret_cast<u64(*)[4]>(&s[0]));
+      load_hash(rp, *reinterpret_cast<u64(*)[4]>(&s[4]));
+      s[8] = s[9] = s[10] = s[11] = 0;
+      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+      u64 o[4] = {gl::canon(s[0]), gl::canon(s[1]), gl::canon(s[2]), gl::canon(s[3])};
+      store_hash(out, o);
+    }
+    return;
+  }
+  if (ln.q == 0) {
+    out[0] = gl::canon(x[0]);
+    out[1] = gl::canon(x[1]);
+    out[2] = gl::canon(x[2]);
+  } else if (ln.q == 1) {
+    out[3] = gl::canon(x[0]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mmr_level_quad(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
+                                                           PermCtx ctx) {
+  const size_t j = j0 + (((size_t)blockIdx.x * kBlock + threadIdx.x) >> 2);
+  if (j >= j1) return;  // quad-uniform
+  poseidon_quad::Lane ln;
+  poseidon_quad::lane_init(ln, ctx.rc);
+  const size_t pos = node_pos(((j + 1) << h) - 1, h);
+  two_to_one_quad(elements + 4 * (pos - ((size_t)1 << h)), elements + 4 * (pos - 1), elements + 4 * pos, ln, ctx);
+}
+
+__global__ __launch_bounds__(kBlock) void k_merkle_level_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+                                                              PermCtx ctx) {
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 2;
+  if (j >= n_out) return;  // quad-uniform
+  poseidon_quad::Lane ln;
+  poseidon_quad::lane_init(ln, ctx.rc);
+  two_to_one_quad(in + 8 * j, in + 8 * j + 4, out + 4 * j, ln, ctx);
+}
+
 struct PosList {
   u64 pos[P2MT_MAX_PROOF_LEN];
   int n;
@@ -558,6 +609,12 @@ int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
     const unsigned per_block = kBlock / 64;
     hipLaunchKernelGGL(k_merkle_level_wave, dim3((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
                        rt().stream, d_in, d_out, n_out, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  if (n_out <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_merkle_level_quad, dim3(grid_for(4 * n_out)), dim3(kBlock), 0, rt().stream, d_in, d_out, n_out,
+                       p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
@@ -832,7 +889,8 @@ extern "C" int p2mt_mmr_reset(p2mt_mmr* m) {
 // one level over [j0, j1) of height h: one wavefront per node while the level is small (latency-bound), one
 // lane per node otherwise
 constexpr size_t kWavePerNodeMax = (size_t)1 << 12;  // measured crossover vs the lane-per-node kernel: ~2^13 nodes
-constexpr size_t kMinTilesPerStage = 2048;           // a fused stage needs enough workgroups to fill 256 CUs
+constexpr size_t kMinTilesPerStage = 2048;
+constexpr size_t kQuadPerNodeMax = (size_t)1 << 16;   // four lanes per node: latency path for 2^12 < nodes <= 2^16           // a fused stage needs enough workgroups to fill 256 CUs
 
 static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
   if (j1 <= j0) return P2MT_OK;
@@ -841,6 +899,12 @@ static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
     const unsigned per_block = kBlock / 64;
     hipLaunchKernelGGL(k_mmr_level_wave, dim3((unsigned)((cnt + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
                        m->elements, h, j0, j1, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  if (cnt <= kQuadPerNodeMax && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_mmr_level_quad, dim3(grid_for(4 * cnt)), dim3(kBlock), 0, rt().stream, m->elements, h, j0, j1,
+                       p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
@@ -950,6 +1014,68 @@ extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t co
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_HIP(hipMemcpyAsync(out, m->elements + 4 * first, count * 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+// ---------------------------------------------------------------- checkpoint
+namespace {
+struct CkptHeader {
+  char magic[8];
+  uint64_t n_leaves, n_elements, checksum;
+};
+uint64_t fold_checksum(const uint64_t* p, size_t n_words) {
+  uint64_t acc = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < n_words; ++i) acc = (acc ^ p[i]) * 0x100000001B3ull + (acc >> 29);
+  return acc;
+}
+}  // namespace
+
+extern "C" int p2mt_mmr_save(const p2mt_mmr* m, const char* path) {
+  if (!m || !path) return p2mt::fail(P2MT_EINVAL, "null argument");
+  const size_t len = mmr_len_for(m->n_leaves);
+  std::vector<uint64_t> host(4 * len);
+  if (len) P2MT_TRY(p2mt_mmr_copy_elements(m, 0, len, host.data()));
+  CkptHeader h;
+  memcpy(h.magic, "P2MTMMR1", 8);
+  h.n_leaves = m->n_leaves;
+  h.n_elements = len;
+  h.checksum = fold_checksum(host.data(), host.size());
+  FILE* f = fopen(path, "wb");
+  if (!f) return p2mt::fail(P2MT_EINVAL, "mmr_save: cannot open file for writing");
+  const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (host.empty() || fwrite(host.data(), 8, host.size(), f) == host.size());
+  if (fclose(f) != 0 || !ok) return p2mt::fail(P2MT_EINVAL, "mmr_save: short write");
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_load(p2mt_mmr* m, const char* path) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m || !path) return p2mt::fail(P2MT_EINVAL, "null argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return p2mt::fail(P2MT_EINVAL, "mmr_load: cannot open file");
+  CkptHeader h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "P2MTMMR1", 8) != 0) {
+    fclose(f);
+    return p2mt::fail(P2MT_EINVAL, "mmr_load: not a P2MTMMR1 checkpoint");
+  }
+  if (h.n_elements != mmr_len_for(h.n_leaves) || (h.n_leaves >> 40)) {
+    fclose(f);
+    return p2mt::fail(P2MT_EINVAL, "mmr_load: header inconsistent (n_elements != 2N - popcount(N))");
+  }
+  std::vector<uint64_t> host(4 * h.n_elements);
+  const bool ok = host.empty() || fread(host.data(), 8, host.size(), f) == host.size();
+  const bool trailing = fgetc(f) != EOF;
+  fclose(f);
+  if (!ok || trailing) return p2mt::fail(P2MT_EINVAL, "mmr_load: truncated or oversized payload");
+  if (fold_checksum(host.data(), host.size()) != h.checksum) return p2mt::fail(P2MT_EINVAL, "mmr_load: checksum mismatch");
+  for (size_t i = 0; i < host.size(); ++i)
+    if (host[i] >= gl::P) return p2mt::fail(P2MT_EINVAL, "mmr_load: non-canonical field element");
+  m->n_leaves = 0;
+  P2MT_TRY(mmr_grow(m, h.n_elements));
+  if (h.n_elements) {
+    P2MT_HIP(hipMemcpyAsync(m->elements, host.data(), host.size() * 8, hipMemcpyHostToDevice, rt().stream));
+    P2MT_HIP(hipStreamSynchronize(rt().stream));
+  }
+  m->n_leaves = h.n_leaves;
   return P2MT_OK;
 }
 

@@ -1,0 +1,101 @@
+// poseidon_quad.hip.h -- the Poseidon permutation on FOUR lanes (one DPP quad) per hash.
+//
+// Third layout of the same function (bit-identical to poseidon.hip.h / poseidon_fast.hip.h), for batches that are
+// too small to fill the chip one-hash-per-lane (2^12 .. 2^16 items: every launch there costs a full single-hash
+// latency of ~60 us) and too big for one-wavefront-per-node.  Lane q of a quad owns state words 3q, 3q+1, 3q+2:
+//   * S-boxes: 3 per lane in a full round (4x shorter), word 0's in a partial round;
+//   * MDS: every word is broadcast inside the quad with v_mov_b32_dpp quad_perm:[s,s,s,s] (full-rate moves, no
+//     LDS), then each lane runs the two mad chains of ITS three rows against per-lane row constants in VGPRs;
+//   * the next round's constants are folded into the chains and prefetched one round ahead, carries and rare
+//     events are handled exactly as in poseidon_fast (sticky mask -> exact fallback by the quad's lane 0).
+// ~5.6 k instructions per wave for 16 hashes: 0.35x the latency of the one-hash-per-lane kernel at 0.73x its
+// throughput, so it is used only where latency, not issue rate, is the bound.
+#pragma once
+#include "poseidon_fast.hip.h"
+
+namespace poseidon_quad {
+
+using gl::u32;
+using gl::u64;
+
+// value of lane SRC of this lane's quad
+template <int SRC>
+GL_DEV u32 quad_bcast(u32 v) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)v, SRC * 0x55, 0xf, 0xf, true);
+}
+
+struct Lane {
+  u32 q;          // lane index inside the quad
+  u32 k[3][12];   // k[i][c] = MDS[3q + i][c]
+  const u64* rc;  // round-constant table + 3q: rc[12 r + i] is this lane's constant for word 3q+i of round r
+};
+
+GL_DEV void lane_init(Lane& ln, const u64* __restrict__ rc_table) {
+  ln.q = threadIdx.x & 3;
+  ln.rc = rc_table + 3 * ln.q;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const u32 r = 3 * ln.q + i;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) ln.k[i][c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - r) % 12] + ((r == 0 && c == 0) ? 8u : 0u);
+  }
+}
+
+// One permutation of the state spread over the quad: x[i] = word 3q+i.  Input: any u64; output: loose u64, valid
+// iff the returned sticky mask is zero for the whole wave.
+GL_DEV u64 permute(u64 (&x)[3], const Lane& ln) {
+  u64 sticky = 0;
+  u64 cn[3];  // constants of round r+1, fetched one round ahead
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    x[i] = gl::add_c(x[i], ln.rc[i]);
+    cn[i] = ln.rc[12 + i];
+  }
+  auto round = [&](bool full, bool add, const u64 (&cf)[3]) {
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) x[i] = poseidon_fast::pow7(x[i], sticky);
+    } else {
+      const u64 y = poseidon_fast::pow7(x[0], sticky);
+      if (ln.q == 0) x[0] = y;
+    }
+    u32 lo[12], hi[12];
+    poseidon::static_for<0, 3>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const u32 l = (u32)x[i], h = (u32)(x[i] >> 32);
+      lo[0 + i] = quad_bcast<0>(l); hi[0 + i] = quad_bcast<0>(h);
+      lo[3 + i] = quad_bcast<1>(l); hi[3 + i] = quad_bcast<1>(h);
+      lo[6 + i] = quad_bcast<2>(l); hi[6 + i] = quad_bcast<2>(h);
+      lo[9 + i] = quad_bcast<3>(l); hi[9 + i] = quad_bcast<3>(h);
+    });
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      u64 al = add ? (u64)(u32)cf[i] : 0, ah = add ? (u64)(u32)(cf[i] >> 32) : 0;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        al += (u64)lo[c] * ln.k[i][c];
+        ah += (u64)hi[c] * ln.k[i][c];
+      }
+      ah = poseidon_fast::add32((u32)(al >> 32), ah);
+      const u64 val = ((u64)(u32)ah << 32) | (u32)al;
+      u64 cm;
+      x[i] = poseidon_fast::mad_eps_carry((u32)(ah >> 32), val, cm);
+      sticky |= cm;
+    }
+  };
+#pragma unroll 1
+  for (int r = 0; r < POSEIDON_ROUNDS - 1; ++r) {
+    const u64 cf[3] = {cn[0], cn[1], cn[2]};
+    if (r + 2 < POSEIDON_ROUNDS) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) cn[i] = ln.rc[12 * (r + 2) + i];
+    }
+    const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
+    round(full, true, cf);
+  }
+  const u64 zero[3] = {0, 0, 0};
+  round(true, false, zero);
+  return sticky;
+}
+
+}  // namespace poseidon_quad

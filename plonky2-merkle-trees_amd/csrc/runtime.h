@@ -25,6 +25,7 @@ struct Runtime {
   int partial = 0;  // exact variants only: 0 = spec-form partial rounds, 1 = sparse form
   uint64_t* d_rc = nullptr;  // 360 round constants, device global memory
   int force_fallback = 0;
+  int use_quad = 1;          // four-lanes-per-hash kernels for 2^12 < items <= 2^16 (env P2MT_QUAD=0 disables)
   unsigned tile_log = 10;    // fused MMR stage: 2^tile_log inputs per workgroup (env P2MT_TILE_LOG = 9|10|11)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // per-kernel HIP-event profiling of the dominant launches (p2mt_profile_*): pairs recorded around each launch

@@ -110,6 +110,7 @@ extern "C" int p2mt_init(int device) {
     const int v = atoi(e);
     if (v >= 9 && v <= 11) rt().tile_log = (unsigned)v;
   }
+  if (const char* e = getenv("P2MT_QUAD")) rt().use_quad = atoi(e) != 0;
   rt().initialised = true;
   return P2MT_OK;
 }

@@ -7,6 +7,7 @@ plus the bulk constructors the reference lacks (from_leaves / extend, SURVEY.md 
 in HBM behind an opaque handle; all hashing happens in the HIP library.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -134,6 +135,16 @@ class MMR:
         out = np.zeros((count, 4), np.uint64)
         N.check(N.lib().p2mt_mmr_copy_elements(self._h, first, count, N.ptr(out)))
         return out
+
+    def save(self, path):
+        """checkpoint: header + `elements` as LE u64x4 records (post-order)"""
+        N.check(N.lib().p2mt_mmr_save(self._h, os.fsencode(path)))
+
+    @staticmethod
+    def load(path):
+        m = MMR()
+        N.check(N.lib().p2mt_mmr_load(m._h, os.fsencode(path)))
+        return m
 
     def get_proof_batch(self, mmr_indices, max_siblings=N.MAX_PROOF_LEN):
         idx = N.as_u64(mmr_indices).reshape(-1)

@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (*.so are git-ignored): build them once (hipcc cross-compiles
+    gfx950 without a GPU; a few minutes).  The GPU box receives the prebuilt files with the snapshot."""
+    import subprocess
+    lib = os.path.join(ROOT, "plonky2-merkle-trees_amd", "libp2mt_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "plonky2-merkle-trees_amd", "csrc"), "-j4"])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle_lib import Oracle

@@ -92,12 +92,16 @@ def test_merkle_cap_edge_shapes(pkg, oracle):
 def test_commit_all_poseidon_variants(pkg, oracle):
     polys = rand((20, 64), 555)
     _, _, cap = oracle.polynomial_batch_commit(polys, True, 3, 4)
+    big = rand((9, 4096), 556)  # 2^15 leaves: quad-lane sponge + quad/wave cap levels
+    _, _, cap_big = oracle.polynomial_batch_commit(big, False, 3, 4)
     try:
         for v in [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]:
             pkg.set_variant(*v)
             assert np.array_equal(pkg.PolynomialBatch.from_values(polys).merkle_tree.cap, cap)
+        assert np.array_equal(pkg.PolynomialBatch.from_coeffs(big, want_leaves=False).merkle_tree.cap, cap_big)
         pkg.lib().p2mt_debug_force_fallback(1)
         assert np.array_equal(pkg.PolynomialBatch.from_values(polys).merkle_tree.cap, cap)
+        assert np.array_equal(pkg.PolynomialBatch.from_coeffs(big, want_leaves=False).merkle_tree.cap, cap_big)
     finally:
         pkg.lib().p2mt_debug_force_fallback(0)
         pkg.set_variant(2, 0)

@@ -67,17 +67,23 @@ def test_fast_path_fallback_is_exact(pkg, oracle):
     lib = pkg.lib()
     rng = np.random.default_rng(8)
     states = np.concatenate([edge_states(), rng.integers(0, 1 << 64, size=(3000, 12), dtype=np.uint64)])
-    leaves = splitmix_leaves(5000, 0x5EED00AA)
+    # 2^17 + 4099 leaves: exercises the fused tiles, the lane-, quad- and wave-per-node level kernels
+    leaves = splitmix_leaves((1 << 17) + 4099, 0x5EED00AA)
+    tree_leaves = splitmix_leaves(1 << 15, 0x5EED00AB)
     try:
         fast = pkg.poseidon_permute_batch(states)
         m_fast = pkg.MMR.from_leaves(leaves).elements
+        t_fast = pkg.MerkleTree.build(tree_leaves)
         lib.p2mt_debug_force_fallback(1)
         slow = pkg.poseidon_permute_batch(states)
         m_slow = pkg.MMR.from_leaves(leaves).elements
+        t_slow = pkg.MerkleTree.build(tree_leaves)
     finally:
         lib.p2mt_debug_force_fallback(0)
     assert np.array_equal(fast, slow) and np.array_equal(fast, oracle.permute_batch(states))
     assert np.array_equal(m_fast, m_slow) and np.array_equal(m_fast, oracle.mmr(leaves).elements)
+    assert np.array_equal(t_fast._flat, t_slow._flat) and np.array_equal(t_fast.root, t_slow.root)
+    assert np.array_equal(t_fast.root, oracle.merkle_build(tree_leaves)[2])
 
 
 def test_fast_path_many_random_states(pkg, oracle):
@@ -240,6 +246,32 @@ def test_mmr_tiled_build_ragged(pkg, oracle):
         b.extend(leaves[lo:hi])
     assert np.array_equal(b.elements, om.elements)
     assert np.array_equal(b.bagging_the_peaks(), om.bagging_the_peaks())
+
+
+def test_mmr_checkpoint_roundtrip(pkg, oracle, tmp_path):
+    """save -> load -> extend continues exactly where the saved MMR stopped; corrupted files are rejected."""
+    leaves = splitmix_leaves(3000, 0x5EED0099)
+    a = pkg.MMR.from_leaves(leaves[:1777])
+    path = str(tmp_path / "mmr.ckpt")
+    a.save(path)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"P2MTMMR1" and len(raw) == 32 + len(a) * 32
+    assert np.array_equal(np.frombuffer(raw[32:], dtype="<u8").reshape(-1, 4), oracle.mmr(leaves[:1777]).elements)
+    b = pkg.MMR.load(path)
+    assert b.num_leaves == 1777 and np.array_equal(b.elements, a.elements)
+    b.extend(leaves[1777:])
+    assert np.array_equal(b.elements, oracle.mmr(leaves).elements)
+    bad = bytearray(raw)
+    bad[100] ^= 1
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.MMR.load(path)
+    open(path, "wb").write(raw[:-8])
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.MMR.load(path)
+    e = pkg.MMR.new()
+    e.save(path)
+    assert len(pkg.MMR.load(path)) == 0
 
 
 def test_mmr_empty_panics(pkg):
