@@ -37,9 +37,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 # add/sub/xor/mov; the kernel's mix (about 85 % mad-class) caps at ~2.2 wave-instr/CU/ns.
 VALU_INSTR_PER_HASH = 16240.0
 ISSUE_PEAK_WAVE_INSTR_PER_S = 256 * 2.2e9
-# HBM bytes of ONE stage-1 launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), see
-# profiles/; None until measured for the current kernel.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = None
+# HBM bytes of ONE stage-1 launch (tile_log 10, 2^24 leaves) from the PMC passes in
+# profiles/r01_v3_mmr_build_2p24.txt: FETCH_SIZE 75.0 MB x2 (gfx950 streaming-read correction) + WRITE_SIZE 1346.9 MB.
+# Counters cannot be read live from inside the process, so this is the committed measurement; it is reported only
+# for the configuration it was measured on.
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {(10, 24): 150.1e6 + 1346.9e6}
 
 
 def splitmix_leaves(n, seed):
@@ -115,7 +117,9 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
     tile_log = int(os.environ.get("P2MT_TILE_LOG", "10"))
     # dominant kernel: the fused stage-1 tile launch (levels 1 .. tile_log-6 of every 2^tile_log-leaf tile)
     fused_levels = tile_log - 6
-    hashes_in_launch = n - (n >> fused_levels)
+    # (with the chunked two-stream build there are several stage-1 launches per step; hashes are split evenly)
+    launches_per_step = max(kern_n.value, 1) / float(args.steps)
+    hashes_in_launch = (n - (n >> fused_levels)) / launches_per_step
     launch_ms = kern_ms.value / max(kern_n.value, 1)
     algo_bytes = hashes_in_launch * ALGO_BYTES_PER_HASH
     achieved_gbs = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
@@ -132,7 +136,8 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                    "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS,
-                     "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH,
+                     "traffic": (MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((tile_log, args.log_leaves)) or 0)
+                     / launches_per_step or None,
                      "kernel": "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (fused_levels, tile_log),
                      "launch_ms": launch_ms, "launches_timed": kern_n.value,
                      "algorithmic_bytes_per_launch": algo_bytes, "hashes_per_launch": hashes_in_launch,

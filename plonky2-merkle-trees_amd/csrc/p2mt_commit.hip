@@ -132,6 +132,131 @@ __global__ __launch_bounds__(kBlock) void k_coset_lde(const u64* __restrict__ co
   for (unsigned q = threadIdx.x; q < n; q += kBlock) o[q] = buf[q];
 }
 
+// ---------------------------------------------------------------- register-blocked 2^12 coset LDE
+// The streaming version of k_coset_lde for n = 4096 (the d = 12 circuits of config 4).  Each of the 256 threads
+// keeps 16 points in registers and the transform is three radix-16 passes (4096 = 16 x 16 x 16), so the data
+// crosses LDS three times instead of twelve and there are 5 barriers instead of 13:
+//   pass A  thread t: points t + 256 k; DIF-16 over k with the 16th roots of unity as compile-time constants
+//           (zeta16 = w_4096^256 = 2^156), then slot r *= w_4096^(t * brev4(r));       -> LDS [r][t]
+//   pass B  thread (r, u): points [r][u + 16 v]; DIF-16 over v, slot r' *= w_4096^(16 u brev4(r'))  -> LDS [r][r'][u]
+//   pass C  thread (r, r'): 16 contiguous points; DIF-16 over u; results are DIF position 256 r + 16 r' + r'',
+//           transposed through LDS so the global stores are contiguous.
+// The result is the same exact field values as the radix-2 DIF of lds_dif (same DFT factorisation).  Arithmetic is
+// "loose" u64 with single-fix add/sub whose (astronomically rare) second carry, and the multiply's rare borrow,
+// go to a sticky wave flag; a flagged workgroup redoes its transform with the exact radix-2 code.
+// Algorithmic traffic: 8 B read + 64 B written per coefficient (72 B); ~180 VALU instructions per coefficient.
+namespace lde12 {
+
+constexpr unsigned kRowA = 256 + 16;  // [r][t] rows padded by 16 words: lanes 16 apart land in disjoint banks
+constexpr unsigned kRowC = 17;        // [r][r'][u] rows of 16 padded to 17: conflict-free ds_read_b64 at stride 136 B
+
+GL_DEV u64 add_l(u64 a, u64 b, u64& sticky) {
+  u32 lo, hi;
+  u64 c1, c2;
+  asm("v_add_co_u32_e64 %0, %2, %3, %5\n\tv_addc_co_u32_e64 %1, %2, %4, %6, %2"
+      : "=&v"(lo), "=v"(hi), "=&s"(c1)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)));
+  const u64 s = ((u64)hi << 32) | lo;
+  const u64 r = poseidon_fast::mad_carry(poseidon_fast::eps_if(c1), 1u, s, c2);  // + EPS where it wrapped
+  sticky |= c2;
+  return r;
+}
+GL_DEV u64 sub_l(u64 a, u64 b, u64& sticky) {
+  u32 lo, hi;
+  u64 b1, b2;
+  asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\tv_subb_co_u32_e64 %1, %2, %4, %6, %2"
+      : "=&v"(lo), "=v"(hi), "=&s"(b1)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)));
+  const u64 d = ((u64)hi << 32) | lo;
+  const u64 r = poseidon_fast::sub32_borrow(d, poseidon_fast::eps_if(b1), b2);  // - EPS where it wrapped
+  sticky |= b2;
+  return r;
+}
+
+// powers of zeta16 = 2^156 (plonky2's primitive 16th root of unity)
+constexpr u64 kZeta16[8] = {0x1ull, 0xefffffff00000001ull, 0xfffffffeff000001ull, 0xffffffff00000ull,
+                            0x1000000000000ull, 0x1000ull, 0xfffffeff00000101ull, 0xffffffef00000001ull};
+constexpr unsigned brev4(unsigned r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// in-register DIF over 16 points (natural slots in, bit-reversed slots out), twiddles zeta16^(e << s)
+GL_DEV void dif16(u64 (&x)[16], u64& sticky) {
+  poseidon::static_for<0, 4>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int half = 8 >> s;
+    poseidon::static_for<0, 8>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int blk = b / half, e = b % half;
+      constexpr int i0 = blk * 2 * half + e, i1 = i0 + half;
+      const u64 a0 = x[i0], a1 = x[i1];
+      x[i0] = add_l(a0, a1, sticky);
+      const u64 d = sub_l(a0, a1, sticky);
+      if constexpr ((e << s) == 0) x[i1] = d;
+      else x[i1] = poseidon_fast::mul(d, kZeta16[e << s], sticky);
+    });
+  });
+}
+
+}  // namespace lde12
+
+__global__ __launch_bounds__(kBlock) void k_coset_lde12(const u64* __restrict__ coeffs, unsigned rate_bits,
+                                                        const u64* __restrict__ coset_pow, const u64* __restrict__ tw_full,
+                                                        const u64* __restrict__ tw_half, u64* __restrict__ out) {
+  using namespace lde12;
+  __shared__ __attribute__((aligned(16))) u64 buf[16 * kRowA];  // 34 KB; also holds the 256 x 17 layout (4352 words)
+  const unsigned t = threadIdx.x;
+  const unsigned poly = blockIdx.x >> rate_bits, j = blockIdx.x & ((1u << rate_bits) - 1);
+  const u64* c = coeffs + ((size_t)poly << 12);
+  const u64* cp = coset_pow + ((size_t)j << 12);
+  u64* o = out + ((size_t)poly << (12 + rate_bits)) + ((size_t)brev32(j, rate_bits) << 12);
+  u64 sticky = 0;
+  u64 x[16];
+  // ---- pass A
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = poseidon_fast::mul(c[t + 256 * k], cp[t + 256 * k], sticky);
+  dif16(x, sticky);
+  poseidon::static_for<1, 16>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    x[r] = poseidon_fast::mul(x[r], tw_full[t * brev4(r)], sticky);
+  });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[r * kRowA + t] = x[r];
+  __syncthreads();
+  // ---- pass B: thread (r, u)
+  const unsigned rr = t >> 4, u = t & 15;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) x[v] = buf[rr * kRowA + u + 16 * v];
+  __syncthreads();
+  dif16(x, sticky);
+  poseidon::static_for<1, 16>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    x[r] = poseidon_fast::mul(x[r], tw_full[16 * u * brev4(r)], sticky);
+  });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[((rr * 16 + r) * kRowC) + u] = x[r];  // [r][r'][u], rows of 17
+  __syncthreads();
+  // ---- pass C: thread (r, r') = t
+#pragma unroll
+  for (int v = 0; v < 16; ++v) x[v] = buf[t * kRowC + v];
+  __syncthreads();
+  dif16(x, sticky);
+  // results of thread t are DIF positions 16 t + r'': transpose through LDS for contiguous stores
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[t * kRowC + r] = gl::canon(x[r]);
+  __syncthreads();
+  if (__builtin_expect(__syncthreads_or(sticky != 0), 0)) {  // rare: the whole workgroup redoes it exactly
+    for (unsigned m = t; m < 4096; m += kBlock) buf[m] = cmul(c[m], cp[m]);
+    __syncthreads();
+    lds_dif(buf, 12, 0, tw_half);
+    for (unsigned q = t; q < 4096; q += kBlock) o[q] = buf[q];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned q = i * 256 + t;
+    o[q] = buf[(q >> 4) * kRowC + (q & 15)];
+  }
+}
+
 // ---------------------------------------------------------------- leaves
 // Poly-major [w][n_pts] -> leaf-major [n_pts][w] through a 32x32 LDS tile (+1 pad: conflict-free column reads).
 __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in, u64* __restrict__ out, size_t w,
@@ -274,6 +399,22 @@ int get_twiddles(unsigned log_n, int inverse, const u64** out) {
   return P2MT_OK;
 }
 
+// w^i for i in [0, n): the register-blocked kernels index it with products t * o that exceed n/2
+int get_full_twiddles(unsigned log_n, const u64** out) {
+  static std::map<unsigned, u64*> full;
+  auto it = full.find(log_n);
+  if (it == full.end()) {
+    const size_t count = (size_t)1 << log_n;
+    u64* d = nullptr;
+    if (hipMalloc((void**)&d, count * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
+    hipLaunchKernelGGL(k_powers, dim3(grid_for(count)), dim3(kBlock), 0, p2mt::rt().stream, d, h_root_of_unity(log_n), count);
+    P2MT_LAUNCH_CHECK();
+    it = full.emplace(log_n, d).first;
+  }
+  *out = it->second;
+  return P2MT_OK;
+}
+
 int get_coset_pows(unsigned log_n, unsigned rate_bits, u64 shift, const u64** out) {
   auto key = std::make_tuple(log_n, rate_bits, shift);
   auto it = tables().coset_pows.find(key);
@@ -370,8 +511,17 @@ static int coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigne
   const u64 *tw, *cp;
   P2MT_TRY(get_twiddles(log_n, 0, &tw));
   P2MT_TRY(get_coset_pows(log_n, rate_bits, shift, &cp));
-  hipLaunchKernelGGL(k_coset_lde, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,
-                     d_coeffs, log_n, rate_bits, cp, tw, d_out);
+  const int slot = p2mt::prof_begin();  // the LDE is the HBM-streaming kernel of the commit step
+  if (log_n == 12 && rt().use_lde12) {
+    const u64* twf;
+    P2MT_TRY(get_full_twiddles(12, &twf));
+    hipLaunchKernelGGL(k_coset_lde12, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
+                       rate_bits, cp, twf, tw, d_out);
+  } else {
+    hipLaunchKernelGGL(k_coset_lde, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,
+                       d_coeffs, log_n, rate_bits, cp, tw, d_out);
+  }
+  p2mt::prof_end(slot);
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
@@ -502,11 +652,7 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
   }
   u64* lde;
   P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
-  {
-    const int slot = p2mt::prof_begin();
-    P2MT_TRY(coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
-    p2mt::prof_end(slot);
-  }
+  P2MT_TRY(coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
   if (d_leaves_out) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
                        (const u64*)lde, d_leaves_out, n_polys, big);

@@ -912,31 +912,27 @@ static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
   return P2MT_OK;
 }
 
-extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
-  P2MT_TRY(p2mt::ensure_init());
-  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
-  if (k == 0) return P2MT_OK;
-  if (!d_leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
-  const size_t n0 = m->n_leaves, n1 = n0 + k;
-  if (n1 < n0 || (n1 >> 40)) return p2mt::fail(P2MT_ERANGE, "MMR too large");
-  P2MT_TRY(mmr_grow(m, mmr_len_for(n1)));
+// All new nodes of height 1..cap whose leaves lie in [lo, hi), plus the leaf digests of [lo, hi), on rt().stream.
+// `d_leaves[0]` is leaf `leaf_base`.  A height-h node j is new iff it ends after leaf lo and complete iff it ends by
+// hi: j in [lo>>h, hi>>h).  Stages of fused tiles (2^(h0+kTileLog)-leaf aligned blocks, n_lev levels each) cover the
+// bulk while a level still has more nodes than the quad/wave-per-node paths like; ragged edges and the thin top go
+// level by level.
+static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size_t n0, size_t n1, unsigned cap) {
+  if (n1 <= n0) return P2MT_OK;
   hipStream_t st = rt().stream;
-  // A height-h node j is new iff it ends after leaf n0 and complete iff it ends by n1: j in [n0>>h, n1>>h).
-  // Stages of fused tiles (2^(h0+kTileLog)-leaf aligned blocks, n_lev levels each) cover the bulk while a level
-  // still has more nodes than the wave-per-node path likes; ragged edges and the thin top go level by level.
-  const unsigned kTileLog = rt().mds == 2 ? rt().tile_log : 11;  // 9, 10 or 11: 2^kTileLog inputs per workgroup (12 / 24 / 48 KB of LDS)
+  const unsigned kTileLog = rt().mds == 2 ? rt().tile_log : 11;  // 2^kTileLog inputs per workgroup (12 / 24 / 48 KB of LDS)
   unsigned h0 = 0;
   for (;;) {
-    if ((n1 >> (h0 + 1)) <= (n0 >> (h0 + 1)) && h0 > 0) break;  // no node above h0
-    // levels this stage would fuse: stage 1 stops while every level fills whole waves (5 levels); later stages
-    // stop where the wave-per-node kernel takes over
+    if (h0 > 0 && (h0 >= cap || (n1 >> (h0 + 1)) <= (n0 >> (h0 + 1)))) break;  // no node above h0 (or not ours)
+    // levels this stage would fuse: stage 1 stops while every level fills whole waves; later stages also stop where
+    // the quad/wave-per-node kernels take over
     unsigned n_lev = 0;
     if (h0 == 0) {
       n_lev = kTileLog - 6;  // last fused level still has 64 nodes per tile
     } else {
-      // whole-wave levels only (>= 64 nodes per tile), and only while the level is too big for the wave-per-node path
       while (n_lev < kTileLog - 6 && ((n1 >> (h0 + n_lev + 1)) - (n0 >> (h0 + n_lev + 1))) > kWavePerNodeMax) ++n_lev;
     }
+    if (h0 + n_lev > cap) n_lev = cap > h0 ? cap - h0 : 0;
     const unsigned span_log = h0 + kTileLog;  // log2(leaves per tile)
     size_t a = n1, b = 0;
     if (n_lev && span_log < 48) {
@@ -947,16 +943,18 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
     if (h0 == 0) {  // leaf digests outside the tiled range (tiles write their own)
       const size_t lo_end = tiles ? a : n1;
       if (lo_end > n0) {
-        hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(lo_end - n0)), dim3(kBlock), 0, st, d_leaves, m->elements, n0, lo_end - n0);
+        hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(lo_end - n0)), dim3(kBlock), 0, st, d_leaves + (n0 - leaf_base),
+                           m->elements, n0, lo_end - n0);
         P2MT_LAUNCH_CHECK();
       }
       if (tiles && n1 > b) {
-        hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(n1 - b)), dim3(kBlock), 0, st, d_leaves + (b - n0), m->elements, b, n1 - b);
+        hipLaunchKernelGGL(k_mmr_leaves, dim3(grid_for(n1 - b)), dim3(kBlock), 0, st, d_leaves + (b - leaf_base), m->elements,
+                           b, n1 - b);
         P2MT_LAUNCH_CHECK();
       }
     }
     if (!tiles) {  // no fused stage from here: one launch per remaining level
-      for (unsigned h = h0 + 1; (n1 >> h) > (n0 >> h); ++h) P2MT_TRY(launch_level(m, h, n0 >> h, n1 >> h));
+      for (unsigned h = h0 + 1; h <= cap && (n1 >> h) > (n0 >> h); ++h) P2MT_TRY(launch_level(m, h, n0 >> h, n1 >> h));
       break;
     }
     {
@@ -965,7 +963,7 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
       const p2mt::PermCtx ctx = p2mt::perm_ctx();
       const int prof_slot = h0 == 0 ? p2mt::prof_begin() : -1;  // stage 1 is the dominant launch
 #define P2MT_TILE(M, PR, TL) \
-  hipLaunchKernelGGL((k_mmr_tile<M, PR, TL>), dim3(grid), dim3(kBlock), 0, st, (const u64*)d_leaves, n0, m->elements, h0, n_lev, t0, ctx)
+  hipLaunchKernelGGL((k_mmr_tile<M, PR, TL>), dim3(grid), dim3(kBlock), 0, st, d_leaves, leaf_base, m->elements, h0, n_lev, t0, ctx)
       if (rt().mds == 2) {
         if (kTileLog == 9) P2MT_TILE(2, 0, 9);
         else if (kTileLog == 10) P2MT_TILE(2, 0, 10);
@@ -985,6 +983,21 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
     }
     h0 += n_lev;
   }
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  if (k == 0) return P2MT_OK;
+  if (!d_leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  const size_t n0 = m->n_leaves, n1 = n0 + k;
+  if (n1 < n0 || (n1 >> 40)) return p2mt::fail(P2MT_ERANGE, "MMR too large");
+  P2MT_TRY(mmr_grow(m, mmr_len_for(n1)));
+  // (A chunked two-stream variant -- bulk tile kernels on one stream, each chunk's latency-bound upper levels on
+  // another -- was measured and removed: 8 chunk launches of 2048 workgroups lose more to partial-wave tails on
+  // the 1280 resident slots than the hidden ~0.5 ms of upper-level latency gains; 10.5 ms against 8.5 ms.)
+  P2MT_TRY(build_levels(m, d_leaves, n0, n0, n1, 63));
   m->n_leaves = n1;
   return P2MT_OK;
 }

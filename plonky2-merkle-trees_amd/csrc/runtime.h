@@ -26,6 +26,7 @@ struct Runtime {
   uint64_t* d_rc = nullptr;  // 360 round constants, device global memory
   int force_fallback = 0;
   int use_quad = 1;          // four-lanes-per-hash kernels for 2^12 < items <= 2^16 (env P2MT_QUAD=0 disables)
+  int use_lde12 = 1;         // register-blocked 2^12 LDE kernel (env P2MT_LDE12=0 selects the generic radix-2 one)
   unsigned tile_log = 10;    // fused MMR stage: 2^tile_log inputs per workgroup (env P2MT_TILE_LOG = 9|10|11)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // per-kernel HIP-event profiling of the dominant launches (p2mt_profile_*): pairs recorded around each launch
@@ -49,6 +50,13 @@ inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ul
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
 enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
+
+// RAII: run a scope on another stream, restore the library stream afterwards
+struct StreamScope {
+  hipStream_t saved;
+  explicit StreamScope(hipStream_t s) : saved(rt().stream) { rt().stream = s; }
+  ~StreamScope() { rt().stream = saved; }
+};
 
 // RAII device scratch buffer
 struct DevBuf {

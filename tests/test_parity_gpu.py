@@ -362,3 +362,31 @@ def test_full_size_properties_2pow24(pkg):
     # (5) determinism: rebuilding gives identical bytes
     m2 = pkg.MMR.from_leaves(leaves)
     assert np.array_equal(m2.bagging_the_peaks(), root)
+
+
+def test_config5_shard_size_2pow26(pkg):
+    """A 2^26-leaf build on one GPU (4.3 GB of nodes; config 5 shards 2^23 per GPU, this is 8x that): 64-bit
+    positions, grid sizes and the staging policy at a size no oracle run can cover -- checked through properties."""
+    n = 1 << 26
+    leaves = splitmix_leaves(n, 0x5EED0000 + 26)
+    m = pkg.MMR.new()
+    m.reserve(n)
+    m.extend(leaves)
+    assert len(m) == 2 * n - 1
+    root = m.bagging_the_peaks()
+    assert np.array_equal(root, m.copy_elements(len(m) - 1, 1)[0])
+    # the two halves are themselves 2^25-leaf MMRs whose roots are the children of the root
+    half = pkg.MMR.from_leaves(leaves[n // 2:])
+    right = half.bagging_the_peaks()
+    assert np.array_equal(right, m.copy_elements(len(m) - 2, 1)[0])
+    left = m.copy_elements(len(m) - 1 - (1 << 26), 1)[0]
+    assert np.array_equal(pkg.two_to_one(left, right), root)
+    # proofs from both ends and the middle verify (26 siblings, bits of the index)
+    idx = np.array([0, 1, n // 2 - 1, n // 2, n - 2, n - 1, 12345678], dtype=np.uint64)
+    mmr_idx = np.array([2 * int(i) - bin(int(i)).count("1") for i in idx], dtype=np.uint64)  # get_mmr_index panics >= 2^30 only
+    sib, lf, ns = m.get_proof_batch(mmr_idx, max_siblings=26)
+    assert (ns == 26).all()
+    for t, i in enumerate(idx):
+        assert lf[t].tolist() == [(int(i) >> b) & 1 for b in range(26)]
+    st = pkg.verify_proof_batch(sib, lf, ns, root[None], leaves[idx.astype(np.int64)], root)
+    assert (st == 1).all()
