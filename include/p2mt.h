@@ -81,6 +81,16 @@ int p2mt_hash_or_noop_batch_dev(const uint64_t *d_in, size_t n, size_t len, uint
 int p2mt_hash_no_pad_batch(const uint64_t *in /*[n][len]*/, size_t n, size_t len, uint64_t *out /*[n][4]*/);
 int p2mt_hash_no_pad_batch_dev(const uint64_t *d_in, size_t n, size_t len, uint64_t *d_out);
 
+/* Witness fill for PoseidonGate rows (what plonky2's PoseidonGenerator computes for every hash the verifier
+ * circuits add: mmr_plonky2_verifier.rs:46-54,81; mmr_plonky2_verifier_1_recursion.rs:44-52), batched over rows.
+ * inputs [n][12], swaps [n] (0/1); wires_out is WIRE-MAJOR [135][n] -- the column layout of the prover's wire
+ * polynomials.  Wire map (plonky2 gates/poseidon.rs, from recall -- parity unpinned): 0-11 inputs, 12-23 outputs,
+ * 24 swap, 25-28 delta, 29-64 first-half full-round S-box inputs (rounds 1-3), 65-86 partial-round S-box inputs,
+ * 87-134 second-half full-round S-box inputs. */
+int p2mt_poseidon_gate_witness_batch(const uint64_t *inputs, const uint8_t *swaps, size_t n, uint64_t *wires_out);
+int p2mt_poseidon_gate_witness_batch_dev(const uint64_t *d_inputs, const uint8_t *d_swaps, size_t n,
+                                         uint64_t *d_wires_out);
+
 /* ------------------------------------------------------------------ simple_merkle_tree.rs
  * MerkleTree::build (simple_merkle_tree.rs:28-51).  n must be a power of two >= 2 (else P2MT_EINVAL:
  * log2_strict panic :30 / usize underflow :38).  levels_out is level-major and matches

@@ -52,6 +52,12 @@ void oracle_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]
 void oracle_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);
 void oracle_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);
 
+/* PoseidonGate witness row [parity unpinned: plonky2 gates/poseidon.rs wire layout from recall, SURVEY.md B.2]:
+ * out[0..12) inputs, [12..24) outputs, [24] swap, [25..29) delta_i = swap*(in[i+4]-in[i]),
+ * [29..65) S-box inputs of first-half full rounds 1..3, [65..87) lane-0 S-box inputs of the 22 partial rounds,
+ * [87..135) S-box inputs of the second-half full rounds 0..3.  The permutation runs on the swapped state. */
+void oracle_poseidon_gate_witness(const uint64_t in[12], int swap, uint64_t out[135]);
+
 /* ---- simple_merkle_tree.rs ---- */
 /* levels_out: level-major, level i has n>>i HashOuts, levels 0..k-1 => (2n-2) HashOuts.
  * Returns count_levels (= log2 n), or -1 where the reference panics (n not a power of two, n < 2). */

@@ -44,6 +44,39 @@ void oracle_poseidon_permute(uint64_t s[12]) {
   }
 }
 
+/* Witness of one PoseidonGate row (plonky2 @3b21b87 gates/poseidon.rs, absent; layout from recall -- PARITY
+ * UNPINNED).  This is what the PoseidonGenerator fills for every hash_n_to_hash_no_pad / two_to_one the circuits
+ * of /root/reference/src/mmr/mmr_plonky2_verifier.rs:46-54,81 and mmr_plonky2_verifier_1_recursion.rs:44-52 add.
+ * The partial-round wires hold lane 0's S-box input, which is identical in the spec form used here and in the
+ * sparse form plonky2 evaluates (checked in tools/poseidon_spec.py). */
+void oracle_poseidon_gate_witness(const uint64_t in[12], int swap, uint64_t out[135]) {
+  uint64_t s[12];
+  for (int i = 0; i < 12; ++i) out[i] = s[i] = gl_canon(in[i]);
+  out[24] = swap ? 1 : 0;
+  for (int i = 0; i < 4; ++i) {
+    uint64_t delta = swap ? gl_sub(s[i + 4], s[i]) : 0;
+    out[25 + i] = delta;
+    uint64_t l = gl_add(s[i], delta), r = gl_sub(s[i + 4], delta);
+    s[i] = l;
+    s[i + 4] = r;
+  }
+  for (int r = 0; r < POSEIDON_ROUNDS; ++r) {
+    for (int i = 0; i < 12; ++i) s[i] = gl_add(s[i], POSEIDON_RC[12 * r + i]);
+    if (r < 4) {
+      if (r >= 1) for (int i = 0; i < 12; ++i) out[29 + 12 * (r - 1) + i] = s[i];
+      for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+    } else if (r < 26) {
+      out[65 + (r - 4)] = s[0];
+      s[0] = sbox7(s[0]);
+    } else {
+      for (int i = 0; i < 12; ++i) out[87 + 12 * (r - 26) + i] = s[i];
+      for (int i = 0; i < 12; ++i) s[i] = sbox7(s[i]);
+    }
+    mds_layer(s);
+  }
+  for (int i = 0; i < 12; ++i) out[12 + i] = s[i];
+}
+
 /* Hasher::two_to_one: perm([l, r, 0,0,0,0])[0..4] */
 void oracle_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) {
   uint64_t s[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};

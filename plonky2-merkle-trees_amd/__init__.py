@@ -7,7 +7,7 @@ name carries a hyphen).
 """
 from . import _native
 from ._native import P2mtError, P2mtPanic, lib
-from .hashing import (hash_no_pad, hash_no_pad_batch, hash_or_noop, hash_or_noop_batch, poseidon_permute_batch,
+from .hashing import (poseidon_gate_witness_batch, hash_no_pad, hash_no_pad_batch, hash_or_noop, hash_or_noop_batch, poseidon_permute_batch,
                       two_to_one, two_to_one_batch)
 from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_batch
 from . import commit, distributed

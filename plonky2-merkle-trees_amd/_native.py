@@ -44,6 +44,8 @@ SIGNATURES = {
     "p2mt_hash_or_noop_batch_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
     "p2mt_hash_no_pad_batch": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
     "p2mt_hash_no_pad_batch_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_poseidon_gate_witness_batch": (C.c_int, [voidp, voidp, C.c_size_t, voidp]),
+    "p2mt_poseidon_gate_witness_batch_dev": (C.c_int, [voidp, voidp, C.c_size_t, voidp]),
     "p2mt_merkle_build_pow2": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
     "p2mt_merkle_build_pow2_dev": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
     "p2mt_merkle_get_proof": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),

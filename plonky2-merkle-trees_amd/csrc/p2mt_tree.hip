@@ -161,6 +161,52 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in
   store_hash(out + 4 * i, o);
 }
 
+// ---------------------------------------------------------------- PoseidonGate witness rows
+// One row per lane, exact spec-form arithmetic (this is a throughput kernel for batches of proofs; a single proof's
+// rows form a dependent chain and belong on the host).  Stores are wire-major, so consecutive lanes write
+// consecutive addresses of each of the 135 wire columns.
+__global__ __launch_bounds__(kBlock) void k_poseidon_gate_witness(const u64* __restrict__ in, const uint8_t* __restrict__ swaps,
+                                                                  size_t n, u64* __restrict__ wires) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    s[k] = gl::canon(in[12 * i + k]);
+    wires[(size_t)k * n + i] = s[k];
+  }
+  const bool swap = swaps[i] != 0;
+  wires[(size_t)24 * n + i] = swap ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u64 delta = swap ? gl::canon(gl::sub_c(s[k + 4], s[k])) : 0;
+    wires[(size_t)(25 + k) * n + i] = delta;
+    const u64 l = gl::canon(gl::add_c(s[k], delta)), r = gl::canon(gl::sub_c(s[k + 4], delta));
+    s[k] = l;
+    s[k + 4] = r;
+  }
+#pragma unroll 1
+  for (int r = 0; r < POSEIDON_ROUNDS; ++r) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = gl::canon(gl::add_c(s[k], POSEIDON_RC[12 * r + k]));
+    if (r < 4 || r >= 26) {
+      if (r >= 1) {
+        const int base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) wires[(size_t)(base + k) * n + i] = s[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) s[k] = gl::pow7(s[k]);
+    } else {
+      wires[(size_t)(65 + (r - 4)) * n + i] = s[0];
+      s[0] = gl::pow7(s[0]);
+    }
+    poseidon::mds_mad64(s);
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) wires[(size_t)(12 + k) * n + i] = gl::canon(s[k]);
+}
+
 // ---------------------------------------------------------------- simple_merkle_tree.rs
 // level0[i] = hash_or_noop([leaf]) = [leaf, 0, 0, 0]  (:33; no permutation, Quirk Q1)
 __global__ __launch_bounds__(kBlock) void k_leaf_digests(const u64* __restrict__ leaves, u64* __restrict__ level0, size_t n) {
@@ -698,6 +744,34 @@ extern "C" int p2mt_hash_or_noop_batch_dev(const uint64_t* d_in, size_t n, size_
 extern "C" int p2mt_hash_no_pad_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
   P2MT_TRY(p2mt::ensure_init());
   return p2mt::launch_hash_rows_dev(d_in, n, len, 0, d_out);
+}
+
+extern "C" int p2mt_poseidon_gate_witness_batch_dev(const uint64_t* d_inputs, const uint8_t* d_swaps, size_t n,
+                                                    uint64_t* d_wires_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!d_inputs || !d_swaps || !d_wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  hipLaunchKernelGGL(k_poseidon_gate_witness, dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_inputs, d_swaps, n,
+                     d_wires_out);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_poseidon_gate_witness_batch(const uint64_t* inputs, const uint8_t* swaps, size_t n, uint64_t* wires_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!inputs || !swaps || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bs, bo;
+  P2MT_TRY(bi.alloc(n * 96));
+  P2MT_TRY(bs.alloc(n));
+  P2MT_TRY(bo.alloc(n * 135 * 8));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(bi.p, inputs, n * 96, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bs.p, swaps, n, hipMemcpyHostToDevice, st));
+  P2MT_TRY(p2mt_poseidon_gate_witness_batch_dev(bi.as<u64>(), bs.as<uint8_t>(), n, bo.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(wires_out, bo.p, n * 135 * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
 }
 
 // =================================================================== simple_merkle_tree.rs

@@ -45,3 +45,17 @@ def hash_or_noop(x):
 
 def hash_no_pad(x):
     return hash_no_pad_batch(N.as_u64(x).reshape(1, -1))[0]
+
+
+POSEIDON_GATE_WIRES = 135
+
+
+def poseidon_gate_witness_batch(inputs, swaps):
+    """Wire values of n PoseidonGate rows, wire-major (135, n): the PoseidonGenerator's output for every hash the
+    MMR-verifier circuits add (mmr_plonky2_verifier.rs:46-54,81). Layout from recall of plonky2 (parity unpinned)."""
+    x = N.as_u64(inputs).reshape(-1, 12)
+    sw = np.ascontiguousarray(np.asarray(swaps, dtype=np.uint8)).reshape(-1)
+    assert sw.size == x.shape[0]
+    out = np.zeros((POSEIDON_GATE_WIRES, x.shape[0]), np.uint64)
+    N.check(N.lib().p2mt_poseidon_gate_witness_batch(N.ptr(x), N.ptr(sw), x.shape[0], N.ptr(out)))
+    return out

@@ -47,6 +47,7 @@ class Oracle:
         lib.oracle_gl_primitive_root_of_unity.argtypes = [C.c_uint]
         lib.oracle_poseidon_permute.argtypes = [_u64p]
         lib.oracle_two_to_one.argtypes = [_u64p, _u64p, _u64p]
+        lib.oracle_poseidon_gate_witness.argtypes = [_u64p, C.c_int, _u64p]
         lib.oracle_hash_no_pad.argtypes = [_u64p, C.c_size_t, _u64p]
         lib.oracle_hash_or_noop.argtypes = [_u64p, C.c_size_t, _u64p]
         lib.oracle_merkle_build.argtypes = [_u64p, C.c_size_t, _u64p, _u64p]
@@ -98,6 +99,11 @@ class Oracle:
         for row in s:
             self.lib.oracle_poseidon_permute(_ptr(row))
         return s
+
+    def poseidon_gate_witness(self, state, swap):
+        s, out = _arr(state).copy(), np.zeros(135, np.uint64)
+        self.lib.oracle_poseidon_gate_witness(_ptr(s), int(swap), _ptr(out))
+        return out
 
     def two_to_one(self, l, r):
         l, r, out = _arr(l), _arr(r), np.zeros(4, np.uint64)

@@ -255,3 +255,23 @@ def test_polynomial_batch_commit_mini(oracle):
     vals = np.stack([oracle.fft(p) for p in polys])
     l2, d2, c2 = oracle.polynomial_batch_commit(vals, True, 3, 2)
     assert np.array_equal(l2, leaves) and np.array_equal(c2, cap) and np.array_equal(d2, digests)
+
+
+def test_poseidon_gate_witness_consistency(oracle):
+    """[parity unpinned layout] internal consistency of the PoseidonGate witness row against the pinned permutation:
+    outputs == permute(swapped inputs); every recorded S-box input reproduces the next recorded value."""
+    import random
+    rnd = random.Random(2)
+    for swap in (0, 1):
+        st = [rnd.randrange(P) for _ in range(12)]
+        w = [int(x) for x in oracle.poseidon_gate_witness(st, swap)]
+        assert w[:12] == st and w[24] == swap
+        sw = st[4:8] + st[:4] + st[8:] if swap else st
+        assert w[25:29] == [((st[i + 4] - st[i]) % P) * swap for i in range(4)]
+        assert w[12:24] == [int(x) for x in oracle.permute(sw)]
+    # hash semantics the circuits rely on: two_to_one(l, r) = outputs[0..4] of the row with inputs [l, r, 0...] and
+    # swap = 0; with swap = 1 it is two_to_one(r, l) (pick_hash's two options, mmr_plonky2_verifier.rs:46-54)
+    l, r = [rnd.randrange(P) for _ in range(4)], [rnd.randrange(P) for _ in range(4)]
+    w0 = oracle.poseidon_gate_witness(l + r + [0] * 4, 0)
+    w1 = oracle.poseidon_gate_witness(l + r + [0] * 4, 1)
+    assert np.array_equal(w0[12:16], oracle.two_to_one(l, r)) and np.array_equal(w1[12:16], oracle.two_to_one(r, l))

@@ -390,3 +390,21 @@ def test_config5_shard_size_2pow26(pkg):
         assert lf[t].tolist() == [(int(i) >> b) & 1 for b in range(26)]
     st = pkg.verify_proof_batch(sib, lf, ns, root[None], leaves[idx.astype(np.int64)], root)
     assert (st == 1).all()
+
+
+def test_poseidon_gate_witness_rows(pkg, oracle):
+    """Witness fill for PoseidonGate rows (wire-major) vs the oracle [wire layout parity unpinned]."""
+    rng = np.random.default_rng(17)
+    n = 700
+    x = np.concatenate([edge_states(), rng.integers(0, 1 << 64, size=(n - len(edge_states()), 12), dtype=np.uint64)])
+    sw = rng.integers(0, 2, size=n).astype(np.uint8)
+    w = pkg.poseidon_gate_witness_batch(x, sw)
+    assert w.shape == (135, n)
+    for i in list(range(0, n, 23)) + [n - 1]:
+        assert np.array_equal(w[:, i], oracle.poseidon_gate_witness(x[i], sw[i])), i
+    # outputs column block == the batch permutation of the swapped inputs (independent kernel)
+    xs = x.copy() % np.uint64(P)
+    swapped = xs.copy()
+    m = sw.astype(bool)
+    swapped[m, 0:4], swapped[m, 4:8] = xs[m, 4:8], xs[m, 0:4]
+    assert np.array_equal(w[12:24].T, pkg.poseidon_permute_batch(swapped))
