@@ -319,7 +319,6 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restr
   poseidon_quad::Lane ln;
   poseidon_quad::lane_init(ln, ctx.rc);
   u64 x[3] = {0, 0, 0};
-  u64 sticky = ctx.force_fallback;
 #pragma unroll 1
   for (size_t off = 0; off < w; off += 8) {
 #pragma unroll
@@ -327,26 +326,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restr
       const u32 wd = 3 * ln.q + i;
       if (wd < 8 && off + wd < w) x[i] = in[(off + wd) * n_pts + col];
     }
-    sticky |= poseidon_quad::permute(x, ln);
+    poseidon_quad::permute(x, ln);
   }
   u64* out = digests + 4 * col;
-  if (__builtin_expect(sticky != 0, 0)) {  // rare: lane 0 of the quad redoes the column with the exact code
-    if (ln.q == 0) {
-      u64 s[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) s[k] = 0;
-#pragma unroll 1
-      for (size_t off = 0; off < w; off += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (off + k < w) s[k] = in[(off + k) * n_pts + col];
-        poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) out[k] = gl::canon(s[k]);
-    }
-    return;
-  }
   if (ln.q == 0) {
     out[0] = gl::canon(x[0]);
     out[1] = gl::canon(x[1]);
@@ -470,6 +452,48 @@ using p2mt::rt;
     }                                                                                                        \
     P2MT_LAUNCH_CHECK();                                                                                     \
   } while (0)
+
+// =================================================================== test hook for the field primitives
+namespace {
+__global__ __launch_bounds__(kBlock) void k_debug_field_op(int op, const u64* __restrict__ a, const u64* __restrict__ b, size_t n,
+                                                           u64* __restrict__ out, uint8_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const unsigned lane = threadIdx.x & 63;
+  u64 sticky = 0, r = 0;
+  switch (op) {
+    case 0: r = poseidon_fast::exact::reduce128(a[i], b[i]); break;
+    case 1: r = poseidon_fast::exact::fold96((u32)(b[i] & 0x3FF), a[i]); break;
+    case 2: r = poseidon_fast::reduce128(a[i], b[i], sticky); break;
+    case 3: r = poseidon_fast::exact::mul(a[i], b[i]); break;
+    case 4: r = lde12::add_l(a[i], b[i], sticky); break;
+    default: r = lde12::sub_l(a[i], b[i], sticky); break;
+  }
+  out[i] = gl::canon(r);
+  flag[i] = (uint8_t)((sticky >> lane) & 1);
+}
+}  // namespace
+
+extern "C" int p2mt_debug_field_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* flag_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!a || !b || !out || !flag_out || op < 0 || op > 5) return p2mt::fail(P2MT_EINVAL, "bad argument");
+  DevBuf ba, bb, bo, bf;
+  P2MT_TRY(ba.alloc(n * 8));
+  P2MT_TRY(bb.alloc(n * 8));
+  P2MT_TRY(bo.alloc(n * 8));
+  P2MT_TRY(bf.alloc(n));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(ba.p, a, n * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bb.p, b, n * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_debug_field_op, dim3(grid_for(n)), dim3(kBlock), 0, st, op, (const u64*)ba.as<u64>(),
+                     (const u64*)bb.as<u64>(), n, bo.as<u64>(), bf.as<uint8_t>());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(flag_out, bf.p, n, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}
 
 // =================================================================== fft_with_options / ifft_with_options
 extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_polys, int inverse) {

@@ -355,7 +355,8 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
 // state word i, the twelve S-boxes of a full round run in parallel, and the MDS row of lane r is two mad chains
 // over the words broadcast with v_readlane (SGPR operands) against that lane's row of constants.  All 30 rounds
 // are unrolled with the lane's round constants preloaded, so a node takes ~3.5k instructions instead of ~28k.
-// Used for levels of <= 2^15 nodes; bit-identical to the lane-per-hash kernels (same primitives, same fallback).
+// Used for levels of <= 2^12 nodes; bit-identical to the lane-per-hash kernels.  Exact arithmetic (no sticky flag):
+// a flagged wave redoing its node serially would set the duration of the whole (latency-bound) launch.
 // out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
 GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
                             const PermCtx& ctx) {
@@ -367,14 +368,13 @@ GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ 
 #pragma unroll
   for (int c = 0; c < 12; ++c) kk[c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - w) % 12] + ((w == 0 && c == 0) ? 8u : 0u);
 
-  u64 sticky = 0;
   const u64* rcw = ctx.rc + w;     // this lane's column of the round-constant table
   u64 c_next = rcw[12];            // constant of round r+1, fetched one round ahead (hidden under the S-box)
   x = gl::add_c(x, rcw[0]);
   // one round: S-box (every lane in a full round, lane 0 in a partial one), then this lane's MDS row with the
   // next round's constant folded into the two mad chains
   auto round = [&](bool full, bool add, u64 c_fold) {
-    const u64 y = poseidon_fast::pow7(x, sticky);
+    const u64 y = poseidon_fast::exact::pow7(x);
     if (full || lane == 0) x = y;
     const u32 xl = (u32)x, xh = (u32)(x >> 32);
     u64 al = add ? (u64)(u32)c_fold : 0, ah = add ? (u64)(u32)(c_fold >> 32) : 0;
@@ -386,9 +386,7 @@ GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ 
     }
     ah = poseidon_fast::add32((u32)(al >> 32), ah);
     const u64 val = ((u64)(u32)ah << 32) | (u32)al;
-    u64 cm;
-    x = poseidon_fast::mad_eps_carry((u32)(ah >> 32), val, cm);
-    sticky |= cm;
+    x = poseidon_fast::exact::fold96((u32)(ah >> 32), val);
   };
 #pragma unroll 1
   for (int r = 0; r < POSEIDON_ROUNDS - 1; ++r) {
@@ -398,19 +396,6 @@ GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ 
     round(full, true, c_fold);
   }
   round(true, false, 0);
-  sticky |= ctx.force_fallback;
-  if (__builtin_expect(sticky != 0, 0)) {  // rare: lane 0 redoes the node with the exact lane-per-hash code
-    if (lane == 0) {
-      u64 s[12];
-      load_hash(lp, *reinterpret_cast<u64(*)[4]>(&s[0]));
-      load_hash(rp, *reinterpret_cast<u64(*)[4]>(&s[4]));
-      s[8] = s[9] = s[10] = s[11] = 0;
-      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
-      u64 o[4] = {gl::canon(s[0]), gl::canon(s[1]), gl::canon(s[2]), gl::canon(s[3])};
-      store_hash(out, o);
-    }
-    return;
-  }
   if (lane < 4) out[lane] = gl::canon(x);
 }
 
@@ -434,26 +419,14 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restr
 // ---------------------------------------------------------------- four lanes per node (poseidon_quad.hip.h)
 // out[0..4) = two_to_one(lp, rp) computed by the calling quad (all four lanes call it with the same pointers)
 GL_DEV void two_to_one_quad(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
-                            const poseidon_quad::Lane& ln, const PermCtx& ctx) {
+                            const poseidon_quad::Lane& ln) {
   u64 x[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const u32 w = 3 * ln.q + i;
     x[i] = w < 4 ? lp[w] : (w < 8 ? rp[w - 4] : 0);
   }
-  const u64 sticky = poseidon_quad::permute(x, ln) | ctx.force_fallback;
-  if (__builtin_expect(sticky != 0, 0)) {  // rare: the quad's lane 0 redoes the node with the exact code
-    if (ln.q == 0) {
-      u64 s[12];
-      load_hash(lp, *reinterpret_cast<u64(*)[4]>(&s[0]));
-      load_hash(rp, *reinterpret_cast<u64(*)[4]>(&s[4]));
-      s[8] = s[9] = s[10] = s[11] = 0;
-      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
-      u64 o[4] = {gl::canon(s[0]), gl::canon(s[1]), gl::canon(s[2]), gl::canon(s[3])};
-      store_hash(out, o);
-    }
-    return;
-  }
+  poseidon_quad::permute(x, ln);
   if (ln.q == 0) {
     out[0] = gl::canon(x[0]);
     out[1] = gl::canon(x[1]);
@@ -470,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_mmr_level_quad(u64* __restrict__ ele
   poseidon_quad::Lane ln;
   poseidon_quad::lane_init(ln, ctx.rc);
   const size_t pos = node_pos(((j + 1) << h) - 1, h);
-  two_to_one_quad(elements + 4 * (pos - ((size_t)1 << h)), elements + 4 * (pos - 1), elements + 4 * pos, ln, ctx);
+  two_to_one_quad(elements + 4 * (pos - ((size_t)1 << h)), elements + 4 * (pos - 1), elements + 4 * pos, ln);
 }
 
 __global__ __launch_bounds__(kBlock) void k_merkle_level_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
@@ -479,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level_quad(const u64* __restr
   if (j >= n_out) return;  // quad-uniform
   poseidon_quad::Lane ln;
   poseidon_quad::lane_init(ln, ctx.rc);
-  two_to_one_quad(in + 8 * j, in + 8 * j + 4, out + 4 * j, ln, ctx);
+  two_to_one_quad(in + 8 * j, in + 8 * j + 4, out + 4 * j, ln);
 }
 
 struct PosList {

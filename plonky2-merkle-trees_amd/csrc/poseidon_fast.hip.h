@@ -112,6 +112,41 @@ GL_DEV u64 pow7(u64 x, u64& sticky) {
   return mul(x4, x3, sticky);
 }
 
+// ------------------------------------------------------------------ exact forms (no sticky flag)
+// Same instruction sequences with the rare corrections applied explicitly (+3 instructions per multiply, +2 per MDS
+// row).  Used by the latency-bound layouts (4 and 12 lanes per hash), where a flagged wave redoing its work
+// serially would set the duration of the whole launch; the throughput-bound one-hash-per-lane kernels keep the
+// flag + fallback, which is cheaper on average.
+namespace exact {
+
+GL_DEV u64 reduce128(u64 lo, u64 hi) {
+  const u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 c1, b, b2;
+  const u64 d1 = mad_eps_carry(hl, lo, c1);
+  const u64 d2 = add32(eps_if(c1), d1);
+  const u64 d3 = sub32_borrow(d2, hh, b);                  // wrapped by +2^64 == +EPS in lanes of b ...
+  return sub32_borrow(d3, eps_if(b), b2);                  // ... take it back (d3 >= 2^64 - 2^32 there: no 2nd borrow)
+}
+GL_DEV u64 mul(u64 a, u64 b) {
+  u64 lo, hi;
+  mul_wide(a, b, lo, hi);
+  return reduce128(lo, hi);
+}
+GL_DEV u64 pow7(u64 x) {
+  const u64 x2 = mul(x, x);
+  const u64 x4 = mul(x2, x2);
+  const u64 x3 = mul(x2, x);
+  return mul(x4, x3);
+}
+// top * 2^64 + val  (top < 2^10) folded to 64 bits
+GL_DEV u64 fold96(u32 top, u64 val) {
+  u64 cm;
+  const u64 d = mad_eps_carry(top, val, cm);
+  return add32(eps_if(cm), d);                             // wrapped value < top * EPS < 2^42: + EPS cannot wrap
+}
+
+}  // namespace exact
+
 // out[r] = sum_c MDS[r][c] * s[c] + add[r] for r < ROWS  (add = next round's constants, canonical; ADD = false
 // for the last round).  Rows >= ROWS are left untouched (two_to_one only needs 4 output words of the last layer).
 template <bool ADD, int ROWS = 12>

@@ -6,8 +6,9 @@
 //   * S-boxes: 3 per lane in a full round (4x shorter), word 0's in a partial round;
 //   * MDS: every word is broadcast inside the quad with v_mov_b32_dpp quad_perm:[s,s,s,s] (full-rate moves, no
 //     LDS), then each lane runs the two mad chains of ITS three rows against per-lane row constants in VGPRs;
-//   * the next round's constants are folded into the chains and prefetched one round ahead, carries and rare
-//     events are handled exactly as in poseidon_fast (sticky mask -> exact fallback by the quad's lane 0).
+//   * the next round's constants are folded into the chains and prefetched one round ahead; arithmetic is the exact
+//     form of poseidon_fast (explicit fix-ups, no sticky flag): in a latency-bound launch a flagged wave redoing
+//     its work serially would set the duration of the whole launch.
 // ~5.6 k instructions per wave for 16 hashes: 0.35x the latency of the one-hash-per-lane kernel at 0.73x its
 // throughput, so it is used only where latency, not issue rate, is the bound.
 #pragma once
@@ -41,10 +42,8 @@ GL_DEV void lane_init(Lane& ln, const u64* __restrict__ rc_table) {
   }
 }
 
-// One permutation of the state spread over the quad: x[i] = word 3q+i.  Input: any u64; output: loose u64, valid
-// iff the returned sticky mask is zero for the whole wave.
-GL_DEV u64 permute(u64 (&x)[3], const Lane& ln) {
-  u64 sticky = 0;
+// One permutation of the state spread over the quad: x[i] = word 3q+i.  Input: any u64; output: loose u64 (exact).
+GL_DEV void permute(u64 (&x)[3], const Lane& ln) {
   u64 cn[3];  // constants of round r+1, fetched one round ahead
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -54,9 +53,9 @@ GL_DEV u64 permute(u64 (&x)[3], const Lane& ln) {
   auto round = [&](bool full, bool add, const u64 (&cf)[3]) {
     if (full) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) x[i] = poseidon_fast::pow7(x[i], sticky);
+      for (int i = 0; i < 3; ++i) x[i] = poseidon_fast::exact::pow7(x[i]);
     } else {
-      const u64 y = poseidon_fast::pow7(x[0], sticky);
+      const u64 y = poseidon_fast::exact::pow7(x[0]);
       if (ln.q == 0) x[0] = y;
     }
     u32 lo[12], hi[12];
@@ -78,9 +77,7 @@ GL_DEV u64 permute(u64 (&x)[3], const Lane& ln) {
       }
       ah = poseidon_fast::add32((u32)(al >> 32), ah);
       const u64 val = ((u64)(u32)ah << 32) | (u32)al;
-      u64 cm;
-      x[i] = poseidon_fast::mad_eps_carry((u32)(ah >> 32), val, cm);
-      sticky |= cm;
+      x[i] = poseidon_fast::exact::fold96((u32)(ah >> 32), val);
     }
   };
 #pragma unroll 1
@@ -95,7 +92,6 @@ GL_DEV u64 permute(u64 (&x)[3], const Lane& ln) {
   }
   const u64 zero[3] = {0, 0, 0};
   round(true, false, zero);
-  return sticky;
 }
 
 }  // namespace poseidon_quad

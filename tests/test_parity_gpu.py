@@ -408,3 +408,37 @@ def test_poseidon_gate_witness_rows(pkg, oracle):
     m = sw.astype(bool)
     swapped[m, 0:4], swapped[m, 4:8] = xs[m, 4:8], xs[m, 0:4]
     assert np.array_equal(w[12:24].T, pkg.poseidon_permute_batch(swapped))
+
+
+def test_field_primitives_rare_paths(pkg):
+    """Rule: a rare data-dependent path needs its own test.  The carry/borrow fix-ups of the device field
+    primitives fire with probability 2^-22 .. 2^-64 on random data, so they are driven here with crafted operands
+    (all-ones words, values within 2^32 of 2^64, p-1, ...) and checked against Python big integers."""
+    import ctypes as C
+    lib, N = pkg.lib(), pkg._native
+    M64 = (1 << 64) - 1
+    edge = [0, 1, 2, P - 1, P, P + 1, M64, M64 - 1, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF,
+            0x00000000FFFFFFFE, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF00000002, 0x8000000080000000, 0x3FF, 0xFFFFFC0000000000]
+    rng = np.random.default_rng(99)
+    a = np.array([x for x in edge for _ in edge] + [int(v) for v in rng.integers(0, 1 << 64, 4000, dtype=np.uint64)], dtype=np.uint64)
+    b = np.array([y for _ in edge for y in edge] + [int(v) for v in rng.integers(0, 1 << 64, 4000, dtype=np.uint64)], dtype=np.uint64)
+
+    def run(op):
+        out, flag = np.zeros(a.size, np.uint64), np.zeros(a.size, np.uint8)
+        N.check(lib.p2mt_debug_field_op(op, N.ptr(a), N.ptr(b), a.size, N.ptr(out), N.ptr(flag)))
+        return [int(x) for x in out], flag
+    A, B = [int(x) for x in a], [int(x) for x in b]
+    out, _ = run(0)
+    assert out == [(x + (y << 64)) % P for x, y in zip(A, B)]                      # exact 128 -> 64 reduce
+    out, _ = run(1)
+    assert out == [(x + ((y & 0x3FF) << 64)) % P for x, y in zip(A, B)]            # exact 96 -> 64 fold
+    out, _ = run(3)
+    assert out == [x * y % P for x, y in zip(A, B)]                                # exact multiply
+    out, flag = run(2)                                                             # flag form: right unless flagged
+    exp = [(x + (y << 64)) % P for x, y in zip(A, B)]
+    assert all(o == e for o, e, f in zip(out, exp, flag) if not f)
+    assert flag.sum() > 0, "crafted operands must drive the flagged path"
+    for op, fn in ((4, lambda x, y: (x + y) % P), (5, lambda x, y: (x - y) % P)):  # loose add / sub of the LDE kernel
+        out, flag = run(op)
+        assert all(o == fn(x, y) for o, x, y, f in zip(out, A, B, flag) if not f)
+        assert flag.sum() > 0
