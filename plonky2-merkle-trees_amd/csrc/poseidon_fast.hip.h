@@ -149,7 +149,7 @@ GL_DEV u64 fold96(u32 top, u64 val) {
 
 // out[r] = sum_c MDS[r][c] * s[c] + add[r] for r < ROWS  (add = next round's constants, canonical; ADD = false
 // for the last round).  Rows >= ROWS are left untouched (two_to_one only needs 4 output words of the last layer).
-template <bool ADD, int ROWS = 12>
+template <bool ADD, int ROWS = 12, bool EXACT = false>
 GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
   u32 lo[12], hi[12];
 #pragma unroll
@@ -177,9 +177,13 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
     });
     ah = add32((u32)(al >> 32), ah);                       // X = ah * 2^32 + (u32)al, < 2^74
     const u64 val = ((u64)(u32)ah << 32) | (u32)al;
-    u64 cm;
-    s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);        // top * EPS + val; wraps with probability ~2^-22
-    sticky |= cm;
+    if constexpr (EXACT) {
+      s[r] = exact::fold96((u32)(ah >> 32), val);
+    } else {
+      u64 cm;
+      s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);      // top * EPS + val; wraps with probability ~2^-22
+      sticky |= cm;
+    }
   });
 }
 
@@ -190,41 +194,47 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
 // CAP_ZERO: the caller guarantees s[8..11] == 0 on entry (two_to_one): their first S-box input is the round
 //   constant itself, so (rc[8+i])^7 is read precomputed from rc[360 + i].
 // OUT_ROWS: number of output words the caller needs (4 for a hash => the last MDS layer computes 4 rows).
-template <bool CAP_ZERO = false, int OUT_ROWS = 12>
+// EXACT: use the exact-form primitives (no flag is ever raised; ~8 % more instructions) -- the redo path of a
+//   flagged wave.
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
   u64 sticky = 0;
+  auto sbox = [&](u64 x) -> u64 {
+    if constexpr (EXACT) return exact::pow7(x);
+    else return pow7(x, sticky);
+  };
   constexpr int kVar = CAP_ZERO ? 8 : 12;
 #pragma unroll
   for (int i = 0; i < kVar; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
   {  // round 0
 #pragma unroll
-    for (int i = 0; i < kVar; ++i) s[i] = pow7(s[i], sticky);
+    for (int i = 0; i < kVar; ++i) s[i] = sbox(s[i]);
     if constexpr (CAP_ZERO) {
 #pragma unroll
       for (int i = 8; i < 12; ++i) s[i] = rc[360 + (i - 8)];
     }
-    mds_layer<true>(s, rc + 12, sticky);
+    mds_layer<true, 12, EXACT>(s, rc + 12, sticky);
   }
 #pragma unroll 1
   for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS; ++r) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
-    mds_layer<true>(s, rc + 12 * (r + 1), sticky);
+    for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+    mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
   }
 #pragma unroll 1
   for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {
-    s[0] = pow7(s[0], sticky);
-    mds_layer<true>(s, rc + 12 * (r + 1), sticky);
+    s[0] = sbox(s[0]);
+    mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
   }
 #pragma unroll 1
   for (int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; r < POSEIDON_ROUNDS - 1; ++r) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
-    mds_layer<true>(s, rc + 12 * (r + 1), sticky);
+    for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+    mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
   }
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = pow7(s[i], sticky);
-  mds_layer<false, OUT_ROWS>(s, nullptr, sticky);
+  for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+  mds_layer<false, OUT_ROWS, EXACT>(s, nullptr, sticky);
   return sticky;
 }
 
