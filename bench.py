@@ -32,13 +32,13 @@ import __graft_entry__ as ge  # noqa: E402
 ALGO_BYTES_PER_HASH = 72.0   # 8 B leaf in + 2 x 32 B nodes out per two_to_one, N large
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 # Integer-issue roofline: VALU instructions per two_to_one of the shipped kernel, from
-# SQ_INSTS_VALU / hashes (profiles/r01_v3_*.txt), and the measured gfx950 issue rates
+# SQ_INSTS_VALU / hashes (profiles/r01_final_*.txt), and the measured gfx950 issue rates
 # (profiles/r01_valu_issue_rates_gfx950.txt): ~2.05 wave-instr/CU/ns for v_mad_u64_u32-class ops, ~4.0 for
 # add/sub/xor/mov; the kernel's mix (about 85 % mad-class) caps at ~2.2 wave-instr/CU/ns.
 VALU_INSTR_PER_HASH = 16240.0
 ISSUE_PEAK_WAVE_INSTR_PER_S = 256 * 2.2e9
 # HBM bytes of ONE stage-1 launch (tile_log 10, 2^24 leaves) from the PMC passes in
-# profiles/r01_v3_mmr_build_2p24.txt: FETCH_SIZE 75.0 MB x2 (gfx950 streaming-read correction) + WRITE_SIZE 1346.9 MB.
+# profiles/r01_final_mmr_build_2p24.txt: FETCH_SIZE 75.0 MB x2 (gfx950 streaming-read correction) + WRITE_SIZE 1346.9 MB.
 # Counters cannot be read live from inside the process, so this is the committed measurement; it is reported only
 # for the configuration it was measured on.
 MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {(10, 24): 150.1e6 + 1346.9e6}

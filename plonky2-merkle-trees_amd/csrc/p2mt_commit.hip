@@ -439,19 +439,6 @@ int ntt_dif_dev(u64* d_data, unsigned log_n, size_t n_polys, int inverse) {
 using p2mt::DevBuf;
 using p2mt::rt;
 
-#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                              \
-  do {                                                                                                       \
-    hipStream_t st_ = p2mt::rt().stream;                                                                     \
-    const p2mt::PermCtx ctx_ = p2mt::perm_ctx();                                                             \
-    switch (p2mt::rt().mds * 2 + (p2mt::rt().mds == 2 ? 0 : p2mt::rt().partial)) {                          \
-      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      case 3: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      default: hipLaunchKernelGGL((KERNEL<2, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-    }                                                                                                        \
-    P2MT_LAUNCH_CHECK();                                                                                     \
-  } while (0)
 
 // =================================================================== test hook for the field primitives
 namespace {

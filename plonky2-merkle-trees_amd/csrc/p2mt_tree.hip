@@ -5,9 +5,11 @@
 //   /root/reference/src/mmr/merkle_mountain_ranges.rs:84-252              (MMR, MMR_proof)
 // HBM layout: a HashOut is a 32-byte record (4 x u64, AoS) exactly as the reference's Vec<HashOut>, so
 // `MerkleTree.tree` (level-major) and `MMR.elements` (post-order) can be copied out verbatim.
-// One lane computes one node (poseidon.hip.h); a level of the tree is one launch.  The MMR is built
-// level-synchronously straight into its post-order positions: the node of height h whose last leaf is L
-// lives at 2L - popcount(L) + h, its right child at pos-1, its left child at pos-2^h.
+// The MMR is built level-synchronously straight into its post-order positions: the node of height h whose last
+// leaf is L lives at 2L - popcount(L) + h, its right child at pos-1, its left child at pos-2^h.
+// Kernels by regime: k_mmr_tile fuses the bottom levels of 2^10-leaf tiles (one hash per lane,
+// LDS hand-off, the dominant launch); levels above use one lane, four lanes (DPP quad) or one wavefront per node
+// depending on how many nodes the level has.
 #include "poseidon_quad.hip.h"
 #include "runtime.h"
 
@@ -21,10 +23,6 @@ using gl::u64;
 namespace {
 
 constexpr int kBlock = 256;
-
-struct __attribute__((aligned(16))) Hash4 {
-  u64 v[4];
-};
 
 GL_DEV void load_hash(const u64* p, u64 (&h)[4]) {
   const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
@@ -600,19 +598,6 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 }  // namespace
 
 // Launch KERNEL<mds, partial> for the runtime-selected variant; the PermCtx is appended as the last argument.
-#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                              \
-  do {                                                                                                       \
-    hipStream_t st_ = p2mt::rt().stream;                                                                     \
-    const p2mt::PermCtx ctx_ = p2mt::perm_ctx();                                                             \
-    switch (p2mt::rt().mds * 2 + (p2mt::rt().mds == 2 ? 0 : p2mt::rt().partial)) {                          \
-      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      case 3: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-      default: hipLaunchKernelGGL((KERNEL<2, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
-    }                                                                                                        \
-    P2MT_LAUNCH_CHECK();                                                                                     \
-  } while (0)
 
 namespace p2mt {
 

@@ -93,3 +93,19 @@ struct DevBuf {
     if (rc_ != P2MT_OK) return rc_; \
   } while (0)
 #define P2MT_LAUNCH_CHECK() P2MT_HIP(hipGetLastError())
+
+// Launch KERNEL<mds, partial> for the runtime-selected Poseidon variant on the library stream; the PermCtx is
+// appended as the last kernel argument.  mds 2 = issue-optimised path (default), 0/1 = exact reference variants.
+#define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                              \
+  do {                                                                                                       \
+    hipStream_t st_ = p2mt::rt().stream;                                                                     \
+    const p2mt::PermCtx ctx_ = p2mt::perm_ctx();                                                             \
+    switch (p2mt::rt().mds * 2 + (p2mt::rt().mds == 2 ? 0 : p2mt::rt().partial)) {                          \
+      case 0: hipLaunchKernelGGL((KERNEL<0, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 1: hipLaunchKernelGGL((KERNEL<0, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 2: hipLaunchKernelGGL((KERNEL<1, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      case 3: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+      default: hipLaunchKernelGGL((KERNEL<2, 0>), dim3(GRID), dim3(BLOCK), 0, st_, __VA_ARGS__, ctx_); break; \
+    }                                                                                                        \
+    P2MT_LAUNCH_CHECK();                                                                                     \
+  } while (0)
