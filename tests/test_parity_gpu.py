@@ -442,3 +442,50 @@ def test_field_primitives_rare_paths(pkg):
         out, flag = run(op)
         assert all(o == fn(x, y) for o, x, y, f in zip(out, A, B, flag) if not f)
         assert flag.sum() > 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_mmr_random_extend_sequences(pkg, oracle, seed):
+    """Random sequences of extends (sizes 0, 1, small, around the 2^10-leaf tile and 2^12/2^16 policy boundaries)
+    must reproduce the oracle's `for leaf { add_leaf }` array at every checkpoint."""
+    rng = np.random.default_rng(seed)
+    total = int(rng.integers(30000, 90000))
+    leaves = splitmix_leaves(total, 0x5EED1000 + seed)
+    cuts, pos = [0], 0
+    choices = [0, 1, 2, 3, 63, 64, 65, 1023, 1024, 1025, 2047, 2048, 4095, 4097, 8191, 16385]
+    while pos < total:
+        step = int(rng.choice(choices)) if rng.random() < 0.7 else int(rng.integers(1, 20000))
+        pos = min(total, pos + step)
+        cuts.append(pos)
+    m = pkg.MMR.new()
+    om = oracle.mmr()
+    check_at = set(rng.choice(len(cuts) - 1, size=min(6, len(cuts) - 1), replace=False).tolist()) | {len(cuts) - 2}
+    for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        m.extend(leaves[lo:hi])
+        om.add_leaves(leaves[lo:hi])
+        if i in check_at:
+            assert len(m) == len(om)
+            assert np.array_equal(m.elements, om.elements), (seed, i, lo, hi)
+            if hi > 0:
+                assert np.array_equal(m.bagging_the_peaks(), om.bagging_the_peaks())
+
+
+def test_library_stream_selection(pkg, oracle):
+    """p2mt_set_stream: the library enqueues on the caller's HIP stream (a torch stream here) and results do not
+    depend on which stream is used."""
+    import torch
+    lib, N = pkg.lib(), pkg._native
+    leaves = splitmix_leaves(70000, 0x5EED2000)
+    ref = oracle.mmr(leaves)
+    stream = torch.cuda.Stream()
+    d = torch.from_numpy(leaves.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    try:
+        N.check(lib.p2mt_set_stream(stream.cuda_stream))
+        m = pkg.MMR.new()
+        m.extend_dev(d, leaves.size)
+        root = m.bagging_the_peaks()        # synchronises the library stream
+        el = m.elements
+    finally:
+        N.check(lib.p2mt_set_stream(None))
+    assert np.array_equal(root, ref.bagging_the_peaks()) and np.array_equal(el, ref.elements)
