@@ -101,6 +101,35 @@ void oracle_mmr_add_leaves(oracle_mmr *m, const uint64_t *leaves, size_t n) {
   for (size_t i = 0; i < n; ++i) oracle_mmr_add_leaf(m, leaves[i]);
 }
 
+/* Level-parallel build of the 2^k-leaf MMR (one perfect tree) into its post-order array: node of height h whose
+ * last leaf is L sits at 2L - popcount(L) + h.  Same values as the add_leaf loop (tested). */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int oracle_mmr_build_pow2_parallel(const uint64_t *leaves, size_t n, uint64_t *el, int threads) {
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+  threads = omp_get_max_threads();
+#else
+  threads = 1;
+#endif
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < (long long)n; ++i) {
+    size_t pos = 2 * (size_t)i - (size_t)__builtin_popcountll((unsigned long long)i);
+    oracle_hash_or_noop(&leaves[i], 1, &el[4 * pos]);
+  }
+  for (unsigned h = 1; ((size_t)1 << h) <= n; ++h) {
+    const long long cnt = (long long)(n >> h);
+#pragma omp parallel for schedule(static)
+    for (long long j = 0; j < cnt; ++j) {
+      size_t last = (((size_t)j + 1) << h) - 1;
+      size_t pos = 2 * last - (size_t)__builtin_popcountll((unsigned long long)last) + h;
+      oracle_two_to_one(&el[4 * (pos - ((size_t)1 << h))], &el[4 * (pos - 1)], &el[4 * pos]);
+    }
+  }
+  return threads;
+}
+
 size_t oracle_mmr_len(const oracle_mmr *m) { return m->len; }
 const uint64_t *oracle_mmr_elements(const oracle_mmr *m) { return m->elements; }
 

@@ -76,6 +76,9 @@ oracle_mmr *oracle_mmr_new(void);
 void oracle_mmr_free(oracle_mmr *m);
 void oracle_mmr_add_leaf(oracle_mmr *m, uint64_t leaf);
 void oracle_mmr_add_leaves(oracle_mmr *m, const uint64_t *leaves, size_t n); /* for leaf { add_leaf } */
+/* BASELINE.md B2 ("generous" CPU baseline, NOT the reference's algorithm): the same post-order array for n = 2^k
+ * leaves built level by level with every host core (OpenMP).  Returns the number of threads used. */
+int oracle_mmr_build_pow2_parallel(const uint64_t *leaves, size_t n, uint64_t *elements_out, int threads /* 0 = all */);
 size_t oracle_mmr_len(const oracle_mmr *m);
 const uint64_t *oracle_mmr_elements(const oracle_mmr *m);
 /* returns number of peaks, -1 where the reference panics (empty MMR / len >= 2^32) */

@@ -62,6 +62,7 @@ class Oracle:
         lib.oracle_mmr_free.argtypes = [C.c_void_p]
         lib.oracle_mmr_add_leaf.argtypes = [C.c_void_p, C.c_uint64]
         lib.oracle_mmr_add_leaves.argtypes = [C.c_void_p, _u64p, C.c_size_t]
+        lib.oracle_mmr_build_pow2_parallel.argtypes = [_u64p, C.c_size_t, _u64p, C.c_int]
         lib.oracle_mmr_len.argtypes = [C.c_void_p]
         lib.oracle_mmr_len.restype = C.c_size_t
         lib.oracle_mmr_elements.argtypes = [C.c_void_p]
@@ -162,6 +163,15 @@ class Oracle:
 
     def mmr(self, leaves=None):
         return OracleMMR(self, leaves)
+
+    def mmr_build_pow2_parallel(self, leaves, threads=0, out=None):
+        """level-parallel build on `threads` host threads (0 = all); returns (elements, threads)."""
+        leaves = _arr(leaves)
+        n = leaves.size
+        assert n and n & (n - 1) == 0
+        el = out if out is not None else np.empty((2 * n - 1, 4), np.uint64)
+        threads = self.lib.oracle_mmr_build_pow2_parallel(_ptr(leaves), n, _ptr(el), threads)
+        return el, threads
 
     def mmr_proof_verify(self, siblings, lefts, peaks, leaf, root):
         sib = _arr(siblings).reshape(-1, 4)

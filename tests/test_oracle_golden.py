@@ -275,3 +275,11 @@ def test_poseidon_gate_witness_consistency(oracle):
     w0 = oracle.poseidon_gate_witness(l + r + [0] * 4, 0)
     w1 = oracle.poseidon_gate_witness(l + r + [0] * 4, 1)
     assert np.array_equal(w0[12:16], oracle.two_to_one(l, r)) and np.array_equal(w1[12:16], oracle.two_to_one(r, l))
+
+
+def test_parallel_cpu_baseline_equals_add_leaf_loop(oracle):
+    """BASELINE.md B2 (all-core level-parallel build) produces the same array as the faithful add_leaf loop (B1)."""
+    leaves = [(i * 0x9E3779B97F4A7C15 + 7) % P for i in range(1 << 11)]
+    el, threads = oracle.mmr_build_pow2_parallel(leaves)
+    assert threads >= 1
+    assert np.array_equal(el, oracle.mmr(leaves).elements)
