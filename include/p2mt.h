@@ -126,6 +126,12 @@ int p2mt_mmr_create(p2mt_mmr **out);                    /* MMR::new (:84-86) */
 int p2mt_mmr_destroy(p2mt_mmr *m);
 int p2mt_mmr_reserve(p2mt_mmr *m, size_t n_leaves);     /* pre-size HBM for n_leaves (no reallocation while extending) */
 int p2mt_mmr_reset(p2mt_mmr *m);                        /* back to the empty MMR, keeps the allocation */
+/* MMR::add_leaf (:89-120), one leaf.  Write-combining: the leaf is queued on the host and the queue is flushed as ONE
+ * bulk extend before anything observes the MMR (len/copy/peaks/root/proof/save/extend/elements_dev) or when 2^20
+ * leaves are pending, so `for leaf { add_leaf }` -- how every caller in the reference builds an MMR
+ * (mmr_plonky2_verifier.rs:109-112) -- runs at bulk speed with identical observable state. */
+int p2mt_mmr_add_leaf(p2mt_mmr *m, uint64_t leaf);
+int p2mt_mmr_flush(p2mt_mmr *m);
 /* MMR::add_leaf (:89-120) for k leaves at once: identical `elements` to k successive add_leaf calls. */
 int p2mt_mmr_extend(p2mt_mmr *m, const uint64_t *leaves, size_t k);
 int p2mt_mmr_extend_dev(p2mt_mmr *m, const uint64_t *d_leaves, size_t k);

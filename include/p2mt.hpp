@@ -133,7 +133,7 @@ class MMR {  // struct MMR { elements: Vec<HashOut> }, device-resident (:8-12)
     return m;
   }
 
-  void add_leaf(GoldilocksField leaf) { check(p2mt_mmr_extend(h_, &leaf, 1)); }  // :89-120
+  void add_leaf(GoldilocksField leaf) { check(p2mt_mmr_add_leaf(h_, leaf)); }  // :89-120 (write-combined)
   void extend(const std::vector<GoldilocksField>& leaves) { check(p2mt_mmr_extend(h_, leaves.data(), leaves.size())); }
   void reserve(std::size_t n_leaves) { check(p2mt_mmr_reserve(h_, n_leaves)); }
 

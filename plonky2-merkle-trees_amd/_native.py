@@ -58,6 +58,8 @@ SIGNATURES = {
     "p2mt_mmr_destroy": (C.c_int, [voidp]),
     "p2mt_mmr_reserve": (C.c_int, [voidp, C.c_size_t]),
     "p2mt_mmr_reset": (C.c_int, [voidp]),
+    "p2mt_mmr_add_leaf": (C.c_int, [voidp, C.c_uint64]),
+    "p2mt_mmr_flush": (C.c_int, [voidp]),
     "p2mt_mmr_extend": (C.c_int, [voidp, voidp, C.c_size_t]),
     "p2mt_mmr_extend_dev": (C.c_int, [voidp, voidp, C.c_size_t]),
     "p2mt_mmr_num_leaves": (C.c_size_t, [voidp]),

@@ -860,9 +860,19 @@ extern "C" size_t p2mt_mmr_shard_first_pos(size_t n_local, size_t rank) {
 struct p2mt_mmr {
   u64* elements = nullptr;  // device, post-order HashOut records
   size_t cap_nodes = 0;
-  size_t n_leaves = 0;
-  u64* scratch = nullptr;  // device: 64 peaks + root (65 HashOuts)
+  size_t n_leaves = 0;      // leaves already built into `elements`
+  u64* scratch = nullptr;   // device: 64 peaks + root (65 HashOuts)
+  std::vector<u64> pending; // add_leaf queue (host), flushed as one bulk extend before the MMR is observed
 };
+
+static constexpr size_t kMaxPendingLeaves = (size_t)1 << 20;
+static int mmr_flush(const p2mt_mmr* cm) {
+  p2mt_mmr* m = const_cast<p2mt_mmr*>(cm);  // the queue is an implementation detail of the logical state
+  if (!m || m->pending.empty()) return P2MT_OK;
+  std::vector<u64> batch;
+  batch.swap(m->pending);
+  return p2mt_mmr_extend(m, batch.data(), batch.size());
+}
 
 static size_t mmr_len_for(size_t n_leaves) { return 2 * n_leaves - (size_t)__builtin_popcountll((unsigned long long)n_leaves); }
 
@@ -915,7 +925,19 @@ extern "C" int p2mt_mmr_reserve(p2mt_mmr* m, size_t n_leaves) {
 extern "C" int p2mt_mmr_reset(p2mt_mmr* m) {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   m->n_leaves = 0;
+  m->pending.clear();
   return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_add_leaf(p2mt_mmr* m, uint64_t leaf) {
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  m->pending.push_back(leaf);
+  return m->pending.size() >= kMaxPendingLeaves ? mmr_flush(m) : P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_flush(p2mt_mmr* m) {
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  return mmr_flush(m);
 }
 
 // one level over [j0, j1) of height h: one wavefront per node while the level is small (latency-bound), one
@@ -1021,6 +1043,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
 extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));  // queued add_leaf calls come first
   if (k == 0) return P2MT_OK;
   if (!d_leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
   const size_t n0 = m->n_leaves, n1 = n0 + k;
@@ -1037,6 +1060,7 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
 extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));
   if (k == 0) return P2MT_OK;
   if (!leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
   DevBuf b;
@@ -1047,12 +1071,17 @@ extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
   return P2MT_OK;
 }
 
-extern "C" size_t p2mt_mmr_num_leaves(const p2mt_mmr* m) { return m ? m->n_leaves : 0; }
-extern "C" size_t p2mt_mmr_len(const p2mt_mmr* m) { return m ? mmr_len_for(m->n_leaves) : 0; }
-extern "C" const uint64_t* p2mt_mmr_elements_dev(const p2mt_mmr* m) { return m ? m->elements : nullptr; }
+// (sizes are known without flushing: the queue only adds leaves)
+extern "C" size_t p2mt_mmr_num_leaves(const p2mt_mmr* m) { return m ? m->n_leaves + m->pending.size() : 0; }
+extern "C" size_t p2mt_mmr_len(const p2mt_mmr* m) { return m ? mmr_len_for(m->n_leaves + m->pending.size()) : 0; }
+extern "C" const uint64_t* p2mt_mmr_elements_dev(const p2mt_mmr* m) {
+  if (!m || mmr_flush(m) != P2MT_OK) return nullptr;
+  return m->elements;
+}
 
 extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t count, uint64_t* out) {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));
   const size_t len = mmr_len_for(m->n_leaves);
   if (first > len || count > len - first) return p2mt::fail(P2MT_EINVAL, "copy_elements: range out of bounds");
   if (count == 0) return P2MT_OK;
@@ -1077,6 +1106,7 @@ uint64_t fold_checksum(const uint64_t* p, size_t n_words) {
 
 extern "C" int p2mt_mmr_save(const p2mt_mmr* m, const char* path) {
   if (!m || !path) return p2mt::fail(P2MT_EINVAL, "null argument");
+  P2MT_TRY(mmr_flush(m));
   const size_t len = mmr_len_for(m->n_leaves);
   std::vector<uint64_t> host(4 * len);
   if (len) P2MT_TRY(p2mt_mmr_copy_elements(m, 0, len, host.data()));
@@ -1115,6 +1145,7 @@ extern "C" int p2mt_mmr_load(p2mt_mmr* m, const char* path) {
   for (size_t i = 0; i < host.size(); ++i)
     if (host[i] >= gl::P) return p2mt::fail(P2MT_EINVAL, "mmr_load: non-canonical field element");
   m->n_leaves = 0;
+  m->pending.clear();
   P2MT_TRY(mmr_grow(m, h.n_elements));
   if (h.n_elements) {
     P2MT_HIP(hipMemcpyAsync(m->elements, host.data(), host.size() * 8, hipMemcpyHostToDevice, rt().stream));
@@ -1143,6 +1174,7 @@ static int mmr_peak_positions(const p2mt_mmr* m, PosList* pl) {
 static int mmr_peaks_root(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks, uint64_t* root_out) {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));
   PosList pl;
   P2MT_TRY(mmr_peak_positions(m, &pl));
   u64* d_peaks = m->scratch;
@@ -1169,6 +1201,7 @@ extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indic
                                     uint64_t* siblings_out, uint8_t* lefts_out, int32_t* n_siblings_out) {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));
   if (count == 0) return P2MT_OK;
   if (!mmr_indices || !siblings_out || !lefts_out || !n_siblings_out || max_siblings == 0)
     return p2mt::fail(P2MT_EINVAL, "null pointer");

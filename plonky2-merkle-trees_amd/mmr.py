@@ -66,7 +66,8 @@ class MMR:
         return MMR()
 
     def add_leaf(self, leaf):
-        self.extend([leaf])
+        """MMR::add_leaf (:89-120); queued and flushed in bulk before the MMR is next observed."""
+        N.check(N.lib().p2mt_mmr_add_leaf(self._h, int(leaf)))
 
     def bagging_the_peaks(self):
         out = np.zeros(4, np.uint64)

@@ -489,3 +489,38 @@ def test_library_stream_selection(pkg, oracle):
     finally:
         N.check(lib.p2mt_set_stream(None))
     assert np.array_equal(root, ref.bagging_the_peaks()) and np.array_equal(el, ref.elements)
+
+
+def test_add_leaf_loop_is_write_combined(pkg, oracle):
+    """`for leaf { mmr.add_leaf(leaf) }` (how every reference caller builds an MMR, mmr_plonky2_verifier.rs:109-112):
+    same observable state as the oracle at every observation point, and fast enough to be usable."""
+    import time
+    leaves = splitmix_leaves(50000, 0x5EED3000)
+    m = pkg.MMR.new()
+    om = oracle.mmr()
+    t0 = time.perf_counter()
+    for i, v in enumerate(leaves):
+        m.add_leaf(int(v))
+        if i in (0, 1, 2, 6, 999, 30000):           # observing flushes the queue
+            om.add_leaves(leaves[om_len_leaves(om):i + 1])
+            assert len(m) == len(om) and m.num_leaves == i + 1
+            assert np.array_equal(m.bagging_the_peaks(), om.bagging_the_peaks())
+    dt = time.perf_counter() - t0
+    om.add_leaves(leaves[om_len_leaves(om):])
+    assert np.array_equal(m.elements, om.elements)
+    pr = m.get_proof_normal_index(49999)
+    assert pr.verify(int(leaves[49999]), m.bagging_the_peaks())
+    m.add_leaf(5)
+    m.extend([6, 7])                                   # extend after queued add_leaf keeps the order
+    om.add_leaves(np.array([5, 6, 7], dtype=np.uint64))
+    assert np.array_equal(m.elements, om.elements)
+    assert dt < 20.0, "add_leaf loop took %.1f s" % dt
+
+
+def om_len_leaves(om):
+    """number of leaves in an oracle MMR of len L = 2N - popcount(N)"""
+    L = len(om)
+    n = (L + 1) // 2
+    while 2 * n - bin(n).count("1") < L:
+        n += 1
+    return n
