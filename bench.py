@@ -34,14 +34,17 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 # Integer-issue roofline: VALU instructions per two_to_one of the shipped kernel, from
 # SQ_INSTS_VALU / hashes (profiles/r01_final_*.txt), and the measured gfx950 issue rates
 # (profiles/r01_valu_issue_rates_gfx950.txt): ~2.05 wave-instr/CU/ns for v_mad_u64_u32-class ops, ~4.0 for
-# add/sub/xor/mov; the kernel's mix (about 85 % mad-class) caps at ~2.2 wave-instr/CU/ns.
-VALU_INSTR_PER_HASH = 16240.0
-ISSUE_PEAK_WAVE_INSTR_PER_S = 256 * 2.2e9
+# add/sub/xor/mov.  The 85 % / 15 % mix of the kernel predicts ~2.3; the best rate any of our kernels sustains in situ is
+# 2.33 (verify_batch: 24 chained two_to_one per lane, 2.35 G hashes/s), so 2.4 wave-instr/CU/ns is used as the roof.
+VALU_INSTR_PER_HASH = 16190.0
+ISSUE_PEAK_WAVE_INSTR_PER_S = 256 * 2.4e9
 # HBM bytes of ONE stage-1 launch (tile_log 10, 2^24 leaves) from the PMC passes in
 # profiles/r01_final_mmr_build_2p24.txt: FETCH_SIZE 75.0 MB x2 (gfx950 streaming-read correction) + WRITE_SIZE 1346.9 MB.
 # Counters cannot be read live from inside the process, so this is the committed measurement; it is reported only
 # for the configuration it was measured on.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {(10, 24): 150.1e6 + 1346.9e6}
+# k_mmr_subtree: FETCH_SIZE 444.8 MB raw (889.5 MB with the x2 correction, which is calibrated for coalesced streams only;
+# the leaf reads here are lane-strided) + WRITE_SIZE 1288.4 MB.  k_mmr_tile (P2MT_SUBTREE=0): 150.1 + 1346.9 MB.
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("subtree4", 24): 889.5e6 + 1288.4e6, ("tile10", 24): 150.1e6 + 1346.9e6}
 
 
 def splitmix_leaves(n, seed):
@@ -135,8 +138,13 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
     mds, partial = C.c_int(), C.c_int()
     lib.p2mt_get_variant(C.byref(mds), C.byref(partial))
     tile_log = int(os.environ.get("P2MT_TILE_LOG", "10"))
-    # dominant kernel: the fused stage-1 tile launch (levels 1 .. tile_log-6 of every 2^tile_log-leaf tile)
-    fused_levels = tile_log - 6
+    subtree = int(os.environ.get("P2MT_SUBTREE", "4"))
+    # dominant kernel = stage 1: per-lane subtrees (levels 1..4 of every 16-leaf block, default) or, with
+    # P2MT_SUBTREE=0, the fused LDS tile kernel (levels 1 .. tile_log-6 of every 2^tile_log-leaf tile)
+    fused_levels = subtree if subtree in (4, 5) else tile_log - 6
+    stage1 = ("k_mmr_subtree (stage 1: each lane builds levels 1..%d of its own 2^%d leaves)" % (fused_levels, fused_levels)
+              if subtree in (4, 5) else
+              "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (fused_levels, tile_log))
     # (with the chunked two-stream build there are several stage-1 launches per step; hashes are split evenly)
     launches_per_step = max(kern_n.value, 1) / float(args.steps)
     hashes_in_launch = (n - (n >> fused_levels)) / launches_per_step
@@ -152,13 +160,15 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
         "config": {"workload": "mmr::merkle_mountain_ranges build, 2^%d leaves per GPU, device-resident leaves"
                                % args.log_leaves,
                    "leaves_per_gpu": n, "hashes_per_step": total_hashes,
-                   "poseidon_variant": {"mds": mds.value, "partial": partial.value}, "tile_log": tile_log,
+                   "poseidon_variant": {"mds": mds.value, "partial": partial.value},
+                   "stage1": "subtree%d" % subtree if subtree in (4, 5) else "tile%d" % tile_log,
                    "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS,
-                     "traffic": (MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get((tile_log, args.log_leaves)) or 0)
+                     "traffic": (MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get(("subtree%d" % subtree if subtree in (4, 5)
+                                                                        else "tile%d" % tile_log, args.log_leaves)) or 0)
                      / launches_per_step or None,
-                     "kernel": "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (fused_levels, tile_log),
+                     "kernel": stage1,
                      "launch_ms": launch_ms, "launches_timed": kern_n.value,
                      "algorithmic_bytes_per_launch": algo_bytes, "hashes_per_launch": hashes_in_launch,
                      "note": "Poseidon is integer-issue bound (see issue_roofline): ~16k VALU instructions per "

@@ -150,6 +150,13 @@ int p2mt_mmr_proof(const p2mt_mmr *m, size_t mmr_index, uint64_t *siblings_out /
 /* Many proofs per call: siblings_out is [m][max_siblings][4], n_siblings_out [m]. */
 int p2mt_mmr_proof_batch(const p2mt_mmr *m, const uint64_t *mmr_indices, size_t count, size_t max_siblings,
                          uint64_t *siblings_out, uint8_t *lefts_out, int32_t *n_siblings_out);
+/* Device-resident forms of the batched proof service: every pointer is device memory, nothing is copied or
+ * synchronised.  n_siblings_out[i] = -1 marks an out-of-range index (the host form returns P2MT_EINVAL for it). */
+int p2mt_mmr_proof_batch_dev(const p2mt_mmr *m, const uint64_t *d_mmr_indices, size_t count, size_t max_siblings,
+                             uint64_t *d_siblings_out, uint8_t *d_lefts_out, int32_t *d_n_siblings_out);
+int p2mt_mmr_proof_verify_batch_dev(const uint64_t *d_siblings, const uint8_t *d_lefts, const int32_t *d_n_siblings,
+                                    size_t max_siblings, const uint64_t *d_peaks, int n_peaks, const uint64_t *d_leaves,
+                                    const uint64_t *d_root, size_t m, int8_t *d_status_out);
 /* MMR_proof::verify (:232-252).  *result_out = 1/0; returns P2MT_ENOTPEAK where the reference panics (:245). */
 int p2mt_mmr_proof_verify(const uint64_t *siblings, const uint8_t *lefts, int n_siblings, const uint64_t *peaks,
                           int n_peaks, uint64_t leaf, const uint64_t *root, int *result_out);

@@ -72,6 +72,9 @@ SIGNATURES = {
     "p2mt_mmr_root": (C.c_int, [voidp, voidp]),
     "p2mt_mmr_proof": (C.c_int, [voidp, C.c_size_t, voidp, voidp, intp, voidp, intp, sizep]),
     "p2mt_mmr_proof_batch": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp, voidp]),
+    "p2mt_mmr_proof_batch_dev": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp, voidp]),
+    "p2mt_mmr_proof_verify_batch_dev": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, C.c_int, voidp, voidp,
+                                                  C.c_size_t, voidp]),
     "p2mt_mmr_proof_verify": (C.c_int, [voidp, voidp, C.c_int, voidp, C.c_int, C.c_uint64, voidp, intp]),
     "p2mt_mmr_proof_verify_batch": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, C.c_int, voidp, voidp,
                                               C.c_size_t, voidp]),

@@ -347,6 +347,59 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
   }
 }
 
+// ---------------------------------------------------------------- per-lane subtrees (stage 1, barrier-free)
+// Each LANE builds the perfect subtree over its own 2^LV consecutive leaves depth-first (post-order), so every lane
+// hashes on every step, waves never wait for each other and there is no barrier: the loop is 2^LV - 1 iterations of
+// ONE inlined permutation.  Pending left siblings (at most one per height) live in a per-lane LDS stack; the control
+// flow is the binary-counter carry chain and is identical in all lanes.  A lane's 2^(LV+1)-1 nodes are a contiguous
+// post-order span, written node by node.  HBM traffic is the same algorithmic minimum as k_mmr_tile.
+template <unsigned LV, int BLK>
+__global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ leaves, size_t leaf_base,
+                                                     u64* __restrict__ elements, size_t block0, size_t n_blocks,
+                                                     PermCtx ctx) {
+  __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
+  const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
+  if (blk >= block0 + n_blocks) return;
+  const size_t first_leaf = blk << LV;
+  const u64* lp = leaves + (first_leaf - leaf_base);
+  u64 cur[4] = {0, 0, 0, 0};
+  unsigned pairs_done = 0;  // leaf pairs consumed so far
+  unsigned h = 0;           // height of `cur`
+  unsigned merges = 0;      // merges still owed before the next leaf pair
+#pragma unroll 1
+  for (unsigned step = 0; step < (1u << LV) - 1; ++step) {
+    u64 o[4];
+    if (merges == 0) {  // hash the next leaf pair
+      const u64 a = gl::canon(lp[2 * pairs_done]), b = gl::canon(lp[2 * pairs_done + 1]);
+      const size_t pos = node_pos(first_leaf + 2 * pairs_done + 1, 1);
+      const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
+      store_hash(elements + 4 * (pos - 2), la);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
+      store_hash(elements + 4 * (pos - 1), lb);
+      two_to_one_r<IMPL_FAST, 0>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+        ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
+        rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
+      });
+      merges = (unsigned)__builtin_ctz(~pairs_done);  // trailing ones: carries of the binary counter
+      pairs_done += 1;
+      h = 1;
+      store_hash(elements + 4 * pos, o);
+    } else {  // merge the pending left sibling of height h with cur
+      const u64* sp = &stack[h - 1][threadIdx.x * 4];
+      two_to_one_r<IMPL_FAST, 0>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+        load_hash(sp, ll);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rr[k] = cur[k];
+      });
+      merges -= 1;
+      h += 1;
+      store_hash(elements + 4 * node_pos(first_leaf + 2 * pairs_done - 1, h), o);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = o[k];
+    if (merges == 0 && h < LV) store_hash(&stack[h - 1][threadIdx.x * 4], cur);  // becomes a pending left sibling
+  }
+}
+
 // ---------------------------------------------------------------- one wavefront per node (latency path)
 // Near the top of the tree a level has fewer nodes than the chip has lanes, and a lane-per-hash launch costs one
 // full single-hash latency (~65 us) whatever its size.  Here 12 lanes of a wave share ONE permutation: lane i owns
@@ -981,13 +1034,14 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
     // levels this stage would fuse: stage 1 stops while every level fills whole waves; later stages also stop where
     // the quad/wave-per-node kernels take over
     unsigned n_lev = 0;
+    const unsigned sub_lv = (h0 == 0 && rt().mds == 2) ? rt().subtree_levels : 0;  // per-lane subtree stage 1
     if (h0 == 0) {
-      n_lev = kTileLog - 6;  // last fused level still has 64 nodes per tile
+      n_lev = sub_lv ? sub_lv : kTileLog - 6;  // last fused level still has 64 nodes per tile
     } else {
       while (n_lev < kTileLog - 6 && ((n1 >> (h0 + n_lev + 1)) - (n0 >> (h0 + n_lev + 1))) > kWavePerNodeMax) ++n_lev;
     }
     if (h0 + n_lev > cap) n_lev = cap > h0 ? cap - h0 : 0;
-    const unsigned span_log = h0 + kTileLog;  // log2(leaves per tile)
+    const unsigned span_log = sub_lv ? sub_lv : h0 + kTileLog;  // log2(leaves per tile / per lane subtree)
     size_t a = n1, b = 0;
     if (n_lev && span_log < 48) {
       a = ((n0 + (((size_t)1 << span_log) - 1)) >> span_log) << span_log;
@@ -1011,7 +1065,20 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       for (unsigned h = h0 + 1; h <= cap && (n1 >> h) > (n0 >> h); ++h) P2MT_TRY(launch_level(m, h, n0 >> h, n1 >> h));
       break;
     }
-    {
+    if (sub_lv) {
+      const size_t n_blocks = (b - a) >> span_log;
+      const int prof_slot = p2mt::prof_begin();  // stage 1 is the dominant launch
+      const unsigned sb = rt().subtree_block;
+      const unsigned sgrid = (unsigned)((n_blocks + sb - 1) / sb);
+#define P2MT_SUB(LVV, BB) \
+  hipLaunchKernelGGL((k_mmr_subtree<LVV, BB>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, a >> span_log, \
+                     n_blocks, p2mt::perm_ctx())
+      if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64); else P2MT_SUB(5, 256); }
+      else { if (sb == 64) P2MT_SUB(4, 64); else if (sb == 128) P2MT_SUB(4, 128); else P2MT_SUB(4, 256); }
+#undef P2MT_SUB
+      P2MT_LAUNCH_CHECK();
+      p2mt::prof_end(prof_slot);
+    } else {
       const unsigned grid = (unsigned)((b - a) >> span_log);
       const size_t t0 = a >> span_log;
       const p2mt::PermCtx ctx = p2mt::perm_ctx();
@@ -1197,16 +1264,29 @@ extern "C" int p2mt_mmr_root(const p2mt_mmr* m, uint64_t* root_out) {
   return mmr_peaks_root(m, nullptr, nullptr, root_out);
 }
 
-extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indices, size_t count, size_t max_siblings,
-                                    uint64_t* siblings_out, uint8_t* lefts_out, int32_t* n_siblings_out) {
+extern "C" int p2mt_mmr_proof_batch_dev(const p2mt_mmr* m, const uint64_t* d_mmr_indices, size_t count, size_t max_siblings,
+                                        uint64_t* d_siblings_out, uint8_t* d_lefts_out, int32_t* d_n_siblings_out) {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   P2MT_TRY(mmr_flush(m));
   if (count == 0) return P2MT_OK;
-  if (!mmr_indices || !siblings_out || !lefts_out || !n_siblings_out || max_siblings == 0)
+  if (!d_mmr_indices || !d_siblings_out || !d_lefts_out || !d_n_siblings_out || max_siblings == 0)
     return p2mt::fail(P2MT_EINVAL, "null pointer");
   const size_t len = mmr_len_for(m->n_leaves);
   if (len == 0) return p2mt::fail(P2MT_EINVAL, "get_proof on an empty MMR");
+  hipLaunchKernelGGL(k_mmr_proof_batch, dim3(grid_for(count)), dim3(kBlock), 0, rt().stream, (const u64*)m->elements, len,
+                     d_mmr_indices, count, max_siblings, d_siblings_out, d_lefts_out, d_n_siblings_out);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indices, size_t count, size_t max_siblings,
+                                    uint64_t* siblings_out, uint8_t* lefts_out, int32_t* n_siblings_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  if (count == 0) return P2MT_OK;
+  if (!mmr_indices || !siblings_out || !lefts_out || !n_siblings_out || max_siblings == 0)
+    return p2mt::fail(P2MT_EINVAL, "null pointer");
   DevBuf bi, bs, bl, bn;
   P2MT_TRY(bi.alloc(count * 8));
   P2MT_TRY(bs.alloc(count * max_siblings * 32));
@@ -1216,9 +1296,7 @@ extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indic
   P2MT_HIP(hipMemcpyAsync(bi.p, mmr_indices, count * 8, hipMemcpyHostToDevice, st));
   P2MT_HIP(hipMemsetAsync(bs.p, 0, count * max_siblings * 32, st));
   P2MT_HIP(hipMemsetAsync(bl.p, 0, count * max_siblings, st));
-  hipLaunchKernelGGL(k_mmr_proof_batch, dim3(grid_for(count)), dim3(kBlock), 0, st, (const u64*)m->elements, len,
-                     bi.as<u64>(), count, max_siblings, bs.as<u64>(), bl.as<uint8_t>(), bn.as<int32_t>());
-  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(p2mt_mmr_proof_batch_dev(m, bi.as<u64>(), count, max_siblings, bs.as<u64>(), bl.as<uint8_t>(), bn.as<int32_t>()));
   P2MT_HIP(hipMemcpyAsync(siblings_out, bs.p, count * max_siblings * 32, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipMemcpyAsync(lefts_out, bl.p, count * max_siblings, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipMemcpyAsync(n_siblings_out, bn.p, count * 4, hipMemcpyDeviceToHost, st));
@@ -1242,6 +1320,22 @@ extern "C" int p2mt_mmr_proof(const p2mt_mmr* m, size_t mmr_index, uint64_t* sib
   return P2MT_OK;
 }
 
+extern "C" int p2mt_mmr_proof_verify_batch_dev(const uint64_t* d_siblings, const uint8_t* d_lefts, const int32_t* d_n_siblings,
+                                               size_t max_siblings, const uint64_t* d_peaks, int n_peaks,
+                                               const uint64_t* d_leaves, const uint64_t* d_root, size_t m, int8_t* d_status_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (m == 0) return P2MT_OK;
+  if (!d_n_siblings || !d_peaks || !d_leaves || !d_root || !d_status_out || n_peaks < 1 || n_peaks > 64)
+    return p2mt::fail(P2MT_EINVAL, "bad argument");
+  if (max_siblings && (!d_siblings || !d_lefts)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  u64* d_bagged;
+  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchTmp, 32, (void**)&d_bagged));
+  P2MT_DISPATCH(k_bag_peaks, 1, 64, d_peaks, n_peaks, d_bagged);
+  P2MT_DISPATCH(k_mmr_verify_batch, grid_for(m), kBlock, d_siblings, d_lefts, d_n_siblings, max_siblings ? max_siblings : 1,
+                d_peaks, n_peaks, d_leaves, d_root, (const u64*)d_bagged, m, d_status_out);
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8_t* lefts, const int32_t* n_siblings,
                                            size_t max_siblings, const uint64_t* peaks, int n_peaks, const uint64_t* leaves,
                                            const uint64_t* root, size_t m, int8_t* status_out) {
@@ -1249,18 +1343,21 @@ extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8
   if (m == 0) return P2MT_OK;
   if (!n_siblings || !peaks || !leaves || !root || !status_out || n_peaks < 0 || n_peaks > 64)
     return p2mt::fail(P2MT_EINVAL, "bad argument");
+  if (n_peaks == 0) {  // contains() on an empty peak list is false: the reference's assert fires for every proof
+    for (size_t i = 0; i < m; ++i) status_out[i] = (int8_t)P2MT_ENOTPEAK;
+    return P2MT_OK;
+  }
   if (max_siblings && (!siblings || !lefts)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (size_t i = 0; i < m; ++i)
     if (n_siblings[i] < 0 || (size_t)n_siblings[i] > max_siblings) return p2mt::fail(P2MT_EINVAL, "n_siblings out of range");
-  DevBuf bs, bl, bn, bp, bv, br, bb, bo;
+  DevBuf bs, bl, bn, bp, bv, br, bo;
   const size_t ms = max_siblings ? max_siblings : 1;
   P2MT_TRY(bs.alloc(m * ms * 32));
   P2MT_TRY(bl.alloc(m * ms));
   P2MT_TRY(bn.alloc(m * 4));
-  P2MT_TRY(bp.alloc((size_t)(n_peaks ? n_peaks : 1) * 32));
+  P2MT_TRY(bp.alloc((size_t)n_peaks * 32));
   P2MT_TRY(bv.alloc(m * 8));
   P2MT_TRY(br.alloc(32));
-  P2MT_TRY(bb.alloc(32));
   P2MT_TRY(bo.alloc(m));
   hipStream_t st = rt().stream;
   if (max_siblings) {
@@ -1268,13 +1365,11 @@ extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8
     P2MT_HIP(hipMemcpyAsync(bl.p, lefts, m * ms, hipMemcpyHostToDevice, st));
   }
   P2MT_HIP(hipMemcpyAsync(bn.p, n_siblings, m * 4, hipMemcpyHostToDevice, st));
-  if (n_peaks) P2MT_HIP(hipMemcpyAsync(bp.p, peaks, (size_t)n_peaks * 32, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bp.p, peaks, (size_t)n_peaks * 32, hipMemcpyHostToDevice, st));
   P2MT_HIP(hipMemcpyAsync(bv.p, leaves, m * 8, hipMemcpyHostToDevice, st));
   P2MT_HIP(hipMemcpyAsync(br.p, root, 32, hipMemcpyHostToDevice, st));
-  P2MT_DISPATCH(k_bag_peaks, 1, 64, (const u64*)bp.as<u64>(), n_peaks, bb.as<u64>());
-  P2MT_DISPATCH(k_mmr_verify_batch, grid_for(m), kBlock, (const u64*)bs.as<u64>(), (const uint8_t*)bl.as<uint8_t>(),
-                (const int32_t*)bn.as<int32_t>(), ms, (const u64*)bp.as<u64>(), n_peaks, (const u64*)bv.as<u64>(),
-                (const u64*)br.as<u64>(), (const u64*)bb.as<u64>(), m, bo.as<int8_t>());
+  P2MT_TRY(p2mt_mmr_proof_verify_batch_dev(bs.as<u64>(), bl.as<uint8_t>(), bn.as<int32_t>(), max_siblings, bp.as<u64>(),
+                                           n_peaks, bv.as<u64>(), br.as<u64>(), m, bo.as<int8_t>()));
   P2MT_HIP(hipMemcpyAsync(status_out, bo.p, m, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;

@@ -112,6 +112,14 @@ extern "C" int p2mt_init(int device) {
   }
   if (const char* e = getenv("P2MT_QUAD")) rt().use_quad = atoi(e) != 0;
   if (const char* e = getenv("P2MT_LDE12")) rt().use_lde12 = atoi(e) != 0;
+  if (const char* e = getenv("P2MT_SUBTREE_BLOCK")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256) rt().subtree_block = (unsigned)v;
+  }
+  if (const char* e = getenv("P2MT_SUBTREE")) {
+    const int v = atoi(e);
+    rt().subtree_levels = (v == 4 || v == 5) ? (unsigned)v : 0;
+  }
   rt().initialised = true;
   return P2MT_OK;
 }

@@ -524,3 +524,36 @@ def om_len_leaves(om):
     while 2 * n - bin(n).count("1") < L:
         n += 1
     return n
+
+
+def test_device_resident_proof_service(pkg, oracle):
+    """p2mt_mmr_proof_batch_dev / p2mt_mmr_proof_verify_batch_dev: proofs produced and verified without leaving HBM."""
+    import torch
+    lib, N = pkg.lib(), pkg._native
+    n = 30000
+    leaves = splitmix_leaves(n, 0x5EED4000)
+    m = pkg.MMR.from_leaves(leaves)
+    om = oracle.mmr(leaves)
+    idx = np.array([0, 1, 16383, 16384, 29999, 777], dtype=np.int64)
+    mmr_idx = np.array([pkg.get_mmr_index(int(i)) for i in idx], dtype=np.int64)
+    d_idx = torch.from_numpy(mmr_idx).cuda()
+    cnt, ms = len(idx), 16
+    d_sib = torch.zeros(cnt * ms * 4, dtype=torch.int64, device="cuda")
+    d_lf = torch.zeros(cnt * ms, dtype=torch.uint8, device="cuda")
+    d_ns = torch.zeros(cnt, dtype=torch.int32, device="cuda")
+    N.check(lib.p2mt_mmr_proof_batch_dev(m._h, N.ptr(d_idx), cnt, ms, N.ptr(d_sib), N.ptr(d_lf), N.ptr(d_ns)))
+    peaks, root = m.get_peaks(), m.bagging_the_peaks()
+    d_peaks = torch.from_numpy(peaks.view(np.int64).copy()).cuda()
+    d_root = torch.from_numpy(root.view(np.int64).copy()).cuda()
+    d_leaves = torch.from_numpy(leaves[idx].view(np.int64).copy()).cuda()
+    d_st = torch.zeros(cnt, dtype=torch.int8, device="cuda")
+    N.check(lib.p2mt_mmr_proof_verify_batch_dev(N.ptr(d_sib), N.ptr(d_lf), N.ptr(d_ns), ms, N.ptr(d_peaks), len(peaks),
+                                                N.ptr(d_leaves), N.ptr(d_root), cnt, N.ptr(d_st)))
+    N.check(lib.p2mt_sync())
+    torch.cuda.synchronize()
+    assert d_st.cpu().tolist() == [1] * cnt
+    sib = d_sib.cpu().numpy().view(np.uint64).reshape(cnt, ms, 4)
+    ns = d_ns.cpu().numpy()
+    for t, i in enumerate(idx):
+        ref = om.get_proof_normal_index(int(i))
+        assert ns[t] == len(ref["lefts"]) and np.array_equal(sib[t, :ns[t]], ref["siblings"])
