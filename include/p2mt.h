@@ -77,7 +77,7 @@ int p2mt_timer_stop(float *elapsed_ms); /* records + synchronises the stop event
  * (plonky2 @3b21b87, absent) as called at simple_merkle_tree.rs:23,33,45,93,100,102 and
  * merkle_mountain_ranges.rs:91,96,111,125,233,238,240,249. */
 int p2mt_poseidon_permute_batch(const uint64_t *in /*[n][12]*/, uint64_t *out /*[n][12]*/, size_t n);
-int p2mt_poseidon_permute_batch_dev(const uint64_t *d_in, uint64_t *d_out, size_t n);
+int p2mt_poseidon_permute_batch_dev(const uint64_t *d_in, uint64_t *d_out, size_t n); /* d_in != d_out */
 int p2mt_two_to_one_batch(const uint64_t *in /*[n][8] = left|right*/, uint64_t *out /*[n][4]*/, size_t n);
 int p2mt_two_to_one_batch_dev(const uint64_t *d_in, uint64_t *d_out, size_t n);
 /* hash_or_noop of n rows of `len` elements each (len <= 4: zero-padded copy, no permutation; else sponge) */

@@ -7,9 +7,10 @@
 // `MerkleTree.tree` (level-major) and `MMR.elements` (post-order) can be copied out verbatim.
 // The MMR is built level-synchronously straight into its post-order positions: the node of height h whose last
 // leaf is L lives at 2L - popcount(L) + h, its right child at pos-1, its left child at pos-2^h.
-// Kernels by regime: k_mmr_tile fuses the bottom levels of 2^10-leaf tiles (one hash per lane,
-// LDS hand-off, the dominant launch); levels above use one lane, four lanes (DPP quad) or one wavefront per node
-// depending on how many nodes the level has.
+// Kernels by regime: stage 1 (the dominant launch) is k_mmr_subtree -- every lane builds levels
+// 1..4 of its own 16 leaves depth-first, barrier-free (k_mmr_tile, the LDS-fused predecessor, serves the exact
+// variants); levels above use one lane, four lanes (DPP quad) or one wavefront per node depending on how many nodes
+// the level has.
 #include "poseidon_quad.hip.h"
 #include "runtime.h"
 
@@ -697,11 +698,12 @@ extern "C" int p2mt_poseidon_permute_batch(const uint64_t* in, uint64_t* out, si
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
-  DevBuf b;
-  P2MT_TRY(b.alloc(n * 96));
-  P2MT_HIP(hipMemcpyAsync(b.p, in, n * 96, hipMemcpyHostToDevice, rt().stream));
-  P2MT_TRY(p2mt_poseidon_permute_batch_dev(b.as<u64>(), b.as<u64>(), n));
-  P2MT_HIP(hipMemcpyAsync(out, b.p, n * 96, hipMemcpyDeviceToHost, rt().stream));
+  DevBuf bi, bo;  // distinct buffers: the kernel's pointers are __restrict__
+  P2MT_TRY(bi.alloc(n * 96));
+  P2MT_TRY(bo.alloc(n * 96));
+  P2MT_HIP(hipMemcpyAsync(bi.p, in, n * 96, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_poseidon_permute_batch_dev(bi.as<u64>(), bo.as<u64>(), n));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 96, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
 }
