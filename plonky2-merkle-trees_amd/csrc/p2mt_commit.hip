@@ -29,11 +29,6 @@
 using gl::u32;
 using gl::u64;
 
-namespace p2mt {
-int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, u64* d_out);
-int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out);
-}  // namespace p2mt
-
 namespace {
 
 constexpr int kBlock = 256;

@@ -1,0 +1,411 @@
+// p2mt_hash.hip -- stateless Poseidon batch kernels, PoseidonGate witness rows and the power-of-two Merkle tree.
+//
+// Replaces the hashing loops of
+//   /root/reference/src/simple_merkle_tree/simple_merkle_tree.rs:18-109   (MerkleTree, verify_merkle_proof)
+// and the per-hash plonky2 Hasher calls under them.  HBM layout: a HashOut is a 32-byte record (4 x u64, AoS)
+// exactly as the reference's Vec<HashOut>, so `MerkleTree.tree` (level-major) can be copied out verbatim.
+// A level uses one lane, four lanes (DPP quad) or one wavefront per node depending on how many nodes it has
+// (DESIGN.md 4.3).  The MMR lives in p2mt_mmr.hip; device helpers shared by both are in tree_common.hip.h.
+#include "tree_common.hip.h"
+
+#include <string.h>
+
+#include <vector>
+
+using namespace p2mt_dev;
+
+namespace {
+
+// ---------------------------------------------------------------- stateless batch kernels
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
+                                                          PermCtx ctx) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+  permute_reloadable<M, PR>(s, ctx, [&](u64 (&st)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) st[k] = in[12 * i + k];
+  });
+#pragma unroll
+  for (int k = 0; k < 12; ++k) out[12 * i + k] = gl::canon(s[k]);
+}
+
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
+                                                             PermCtx ctx) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 o[4];
+  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+    load_hash(in + 8 * i, l);
+    load_hash(in + 8 * i + 4, r);
+  });
+  store_hash(out + 4 * i, o);
+}
+
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
+                                                      u64* __restrict__ out, PermCtx ctx) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 o[4];
+  if (noop_short && len <= 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (size_t)k < len ? gl::canon(in[i * len + k]) : 0;
+  } else {
+    const u64* row = in + i * len;
+    sponge<M, PR>(len, ctx, o, [&](size_t k) { return row[k]; });
+  }
+  store_hash(out + 4 * i, o);
+}
+
+// ---------------------------------------------------------------- PoseidonGate witness rows
+// One row per lane, exact spec-form arithmetic (this is a throughput kernel for batches of proofs; a single proof's
+// rows form a dependent chain and belong on the host).  Stores are wire-major, so consecutive lanes write
+// consecutive addresses of each of the 135 wire columns.
+__global__ __launch_bounds__(kBlock) void k_poseidon_gate_witness(const u64* __restrict__ in, const uint8_t* __restrict__ swaps,
+                                                                  size_t n, u64* __restrict__ wires) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    s[k] = gl::canon(in[12 * i + k]);
+    wires[(size_t)k * n + i] = s[k];
+  }
+  const bool swap = swaps[i] != 0;
+  wires[(size_t)24 * n + i] = swap ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u64 delta = swap ? gl::canon(gl::sub_c(s[k + 4], s[k])) : 0;
+    wires[(size_t)(25 + k) * n + i] = delta;
+    const u64 l = gl::canon(gl::add_c(s[k], delta)), r = gl::canon(gl::sub_c(s[k + 4], delta));
+    s[k] = l;
+    s[k + 4] = r;
+  }
+#pragma unroll 1
+  for (int r = 0; r < POSEIDON_ROUNDS; ++r) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = gl::canon(gl::add_c(s[k], POSEIDON_RC[12 * r + k]));
+    if (r < 4 || r >= 26) {
+      if (r >= 1) {
+        const int base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) wires[(size_t)(base + k) * n + i] = s[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) s[k] = gl::pow7(s[k]);
+    } else {
+      wires[(size_t)(65 + (r - 4)) * n + i] = s[0];
+      s[0] = gl::pow7(s[0]);
+    }
+    poseidon::mds_mad64(s);
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) wires[(size_t)(12 + k) * n + i] = gl::canon(s[k]);
+}
+
+// ---------------------------------------------------------------- simple_merkle_tree.rs
+// level0[i] = hash_or_noop([leaf]) = [leaf, 0, 0, 0]  (:33; no permutation, Quirk Q1)
+__global__ __launch_bounds__(kBlock) void k_leaf_digests(const u64* __restrict__ leaves, u64* __restrict__ level0, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const u64 o[4] = {gl::canon(leaves[i]), 0, 0, 0};
+  store_hash(level0 + 4 * i, o);
+}
+
+// next_level_hashes (:21-25): out[j] = two_to_one(in[2j], in[2j+1])
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+                                                         PermCtx ctx) {
+  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n_out) return;
+  u64 o[4];
+  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+    load_hash(in + 8 * j, l);
+    load_hash(in + 8 * j + 4, r);
+  });
+  store_hash(out + 4 * j, o);
+}
+
+// verify_merkle_proof (:91-109), one proof per lane
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_verify_merkle_proof(const u64* __restrict__ leaves, const u64* __restrict__ idx,
+                                                                const u64* __restrict__ roots,
+                                                                const u64* __restrict__ hashes, size_t n_hashes, size_t m,
+                                                                uint8_t* __restrict__ result, PermCtx ctx) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  u64 cur[4] = {gl::canon(leaves[i]), 0, 0, 0};
+  u64 index = idx[i];
+#pragma unroll 1
+  for (size_t k = 0; k < n_hashes; ++k) {
+    const bool even = (index & 1) == 0;
+    u64 nxt[4];
+    two_to_one_r<M, PR>(ctx, nxt, [&](u64 (&l)[4], u64 (&r)[4]) {
+      u64 sib[4];
+      load_hash(hashes + 4 * (i * n_hashes + k), sib);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        l[t] = even ? cur[t] : sib[t];
+        r[t] = even ? sib[t] : cur[t];
+      }
+    });
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+    index >>= 1;
+  }
+  u64 root[4];
+  load_hash(roots + 4 * i, root);
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ok = ok && (cur[t] == gl::canon(root[t]));
+  result[i] = ok ? 1 : 0;
+}
+
+// level-major tree level: out[j] = two_to_one(in[2j], in[2j+1])
+__global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+                                                              PermCtx ctx) {
+  const size_t j = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (j >= n_out) return;  // wave-uniform
+  two_to_one_wave(in + 8 * j, in + 8 * j + 4, out + 4 * j, ctx);
+}
+
+__global__ __launch_bounds__(kBlock) void k_merkle_level_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+                                                              PermCtx ctx) {
+  const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 2;
+  if (j >= n_out) return;  // quad-uniform
+  poseidon_quad::Lane ln;
+  poseidon_quad::lane_init(ln, ctx.rc);
+  two_to_one_quad(in + 8 * j, in + 8 * j + 4, out + 4 * j, ln);
+}
+
+}  // namespace
+
+// Launch KERNEL<mds, partial> for the runtime-selected variant; the PermCtx is appended as the last argument.
+
+namespace p2mt {
+
+// exported to the other translation units
+int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, u64* d_out) {
+  if (n == 0) return P2MT_OK;
+  P2MT_DISPATCH(k_hash_rows, grid_for(n), kBlock, d_in, n, len, noop_short, d_out);
+  return P2MT_OK;
+}
+int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
+  if (n_out == 0) return P2MT_OK;
+  if (n_out <= ((size_t)1 << 12) && rt().mds == 2) {  // small level: one wavefront per node (latency path)
+    const unsigned per_block = kBlock / 64;
+    hipLaunchKernelGGL(k_merkle_level_wave, dim3((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
+                       rt().stream, d_in, d_out, n_out, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  if (n_out <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_merkle_level_quad, dim3(grid_for(4 * n_out)), dim3(kBlock), 0, rt().stream, d_in, d_out, n_out,
+                       p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  P2MT_DISPATCH(k_merkle_level, grid_for(n_out), kBlock, d_in, d_out, n_out);
+  return P2MT_OK;
+}
+
+}  // namespace p2mt
+
+using p2mt::DevBuf;
+using p2mt::rt;
+
+// =================================================================== stateless batch entry points
+extern "C" int p2mt_poseidon_permute_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_DISPATCH(k_permute_batch, grid_for(n), kBlock, d_in, d_out, n);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_poseidon_permute_batch(const uint64_t* in, uint64_t* out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bo;  // distinct buffers: the kernel's pointers are __restrict__
+  P2MT_TRY(bi.alloc(n * 96));
+  P2MT_TRY(bo.alloc(n * 96));
+  P2MT_HIP(hipMemcpyAsync(bi.p, in, n * 96, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_poseidon_permute_batch_dev(bi.as<u64>(), bo.as<u64>(), n));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 96, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_two_to_one_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_DISPATCH(k_two_to_one_batch, grid_for(n), kBlock, d_in, d_out, n);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_two_to_one_batch(const uint64_t* in, uint64_t* out, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bo;
+  P2MT_TRY(bi.alloc(n * 64));
+  P2MT_TRY(bo.alloc(n * 32));
+  P2MT_HIP(hipMemcpyAsync(bi.p, in, n * 64, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_two_to_one_batch_dev(bi.as<u64>(), bo.as<u64>(), n));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+static int hash_rows_host(const uint64_t* in, size_t n, size_t len, int noop_short, uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!out || (!in && len)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bo;
+  P2MT_TRY(bi.alloc(n * len * 8));
+  P2MT_TRY(bo.alloc(n * 32));
+  if (len) P2MT_HIP(hipMemcpyAsync(bi.p, in, n * len * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt::launch_hash_rows_dev(bi.as<u64>(), n, len, noop_short, bo.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_hash_or_noop_batch(const uint64_t* in, size_t n, size_t len, uint64_t* out) {
+  return hash_rows_host(in, n, len, 1, out);
+}
+extern "C" int p2mt_hash_no_pad_batch(const uint64_t* in, size_t n, size_t len, uint64_t* out) {
+  return hash_rows_host(in, n, len, 0, out);
+}
+extern "C" int p2mt_hash_or_noop_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  return p2mt::launch_hash_rows_dev(d_in, n, len, 1, d_out);
+}
+extern "C" int p2mt_hash_no_pad_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  return p2mt::launch_hash_rows_dev(d_in, n, len, 0, d_out);
+}
+
+extern "C" int p2mt_poseidon_gate_witness_batch_dev(const uint64_t* d_inputs, const uint8_t* d_swaps, size_t n,
+                                                    uint64_t* d_wires_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!d_inputs || !d_swaps || !d_wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  hipLaunchKernelGGL(k_poseidon_gate_witness, dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_inputs, d_swaps, n,
+                     d_wires_out);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_poseidon_gate_witness_batch(const uint64_t* inputs, const uint8_t* swaps, size_t n, uint64_t* wires_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  if (!inputs || !swaps || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bs, bo;
+  P2MT_TRY(bi.alloc(n * 96));
+  P2MT_TRY(bs.alloc(n));
+  P2MT_TRY(bo.alloc(n * 135 * 8));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(bi.p, inputs, n * 96, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bs.p, swaps, n, hipMemcpyHostToDevice, st));
+  P2MT_TRY(p2mt_poseidon_gate_witness_batch_dev(bi.as<u64>(), bs.as<uint8_t>(), n, bo.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(wires_out, bo.p, n * 135 * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}
+
+// =================================================================== simple_merkle_tree.rs
+static int log2_strict(size_t n) {
+  if (n == 0 || (n & (n - 1))) return -1;
+  return __builtin_ctzll((unsigned long long)n);
+}
+
+extern "C" int p2mt_merkle_build_pow2_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_levels, uint64_t* d_root) {
+  P2MT_TRY(p2mt::ensure_init());
+  const int k = log2_strict(n);
+  if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
+  if (!d_leaves || !d_levels || !d_root) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  hipLaunchKernelGGL(k_leaf_digests, dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_leaves, d_levels, n);
+  P2MT_LAUNCH_CHECK();
+  u64* cur = d_levels;
+  size_t cur_n = n;
+  for (int i = 0; i < k - 1; ++i) {  // levels 1 .. k-1
+    u64* next = cur + 4 * cur_n;
+    P2MT_TRY(p2mt::launch_merkle_level_dev(cur, next, cur_n / 2));
+    cur = next;
+    cur_n /= 2;
+  }
+  return p2mt::launch_merkle_level_dev(cur, d_root, 1);  // root = two_to_one(last[0], last[1])
+}
+
+extern "C" int p2mt_merkle_build_pow2(const uint64_t* leaves, size_t n, uint64_t* levels_out, uint64_t* root_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  const int k = log2_strict(n);
+  if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
+  if (!leaves || !levels_out || !root_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bl, bt;
+  P2MT_TRY(bl.alloc(n * 8));
+  P2MT_TRY(bt.alloc((2 * n - 2 + 1) * 32));
+  u64* d_root = bt.as<u64>() + 4 * (2 * n - 2);
+  P2MT_HIP(hipMemcpyAsync(bl.p, leaves, n * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_merkle_build_pow2_dev(bl.as<u64>(), n, bt.as<u64>(), d_root));
+  P2MT_HIP(hipMemcpyAsync(levels_out, bt.p, (2 * n - 2) * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+static const uint64_t* level_ptr(const uint64_t* levels, size_t n, int level) {
+  size_t off = 0;
+  for (int i = 0; i < level; ++i) off += n >> i;
+  return levels + 4 * off;
+}
+
+extern "C" int p2mt_merkle_get_proof(const uint64_t* levels, size_t n, size_t leaf_index, uint64_t* proof_out) {
+  const int k = log2_strict(n);
+  if (k < 1 || !levels || !proof_out) return p2mt::fail(P2MT_EINVAL, "get_merkle_proof: bad tree");
+  if (leaf_index >= n) return p2mt::fail(P2MT_EINVAL, "get_merkle_proof: assert!(leaf_index < n)");
+  size_t idx = leaf_index;
+  for (int i = 0; i < k; ++i, idx >>= 1) memcpy(proof_out + 4 * i, level_ptr(levels, n, i) + 4 * (idx ^ 1), 32);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_merkle_get_in_between_hashes(const uint64_t* levels, const uint64_t* root, size_t n,
+                                                 size_t leaf_index, uint64_t* out) {
+  const int k = log2_strict(n);
+  if (k < 1 || !levels || !root || !out) return p2mt::fail(P2MT_EINVAL, "get_in_between_hashes: bad tree");
+  if (leaf_index >= n) return p2mt::fail(P2MT_EINVAL, "get_in_between_hashes: assert!(leaf_index < n)");
+  size_t idx = leaf_index >> 1;
+  for (int i = 1; i < k; ++i, idx >>= 1) memcpy(out + 4 * (i - 1), level_ptr(levels, n, i) + 4 * idx, 32);
+  memcpy(out + 4 * (k - 1), root, 32);
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_verify_merkle_proof_batch(const uint64_t* leaves, const uint64_t* leaf_indices, const uint64_t* roots,
+                                              const uint64_t* hashes, size_t n_hashes, size_t m, uint8_t* result_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (m == 0) return P2MT_OK;
+  if (!leaves || !leaf_indices || !roots || (!hashes && n_hashes) || !result_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bl, bi, br, bh, bo;
+  P2MT_TRY(bl.alloc(m * 8));
+  P2MT_TRY(bi.alloc(m * 8));
+  P2MT_TRY(br.alloc(m * 32));
+  P2MT_TRY(bh.alloc(m * n_hashes * 32));
+  P2MT_TRY(bo.alloc(m));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(bl.p, leaves, m * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(bi.p, leaf_indices, m * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(br.p, roots, m * 32, hipMemcpyHostToDevice, st));
+  if (n_hashes) P2MT_HIP(hipMemcpyAsync(bh.p, hashes, m * n_hashes * 32, hipMemcpyHostToDevice, st));
+  P2MT_DISPATCH(k_verify_merkle_proof, grid_for(m), kBlock, bl.as<u64>(), bi.as<u64>(), br.as<u64>(), bh.as<u64>(),
+                n_hashes, m, bo.as<uint8_t>());
+  P2MT_HIP(hipMemcpyAsync(result_out, bo.p, m, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}
+

@@ -82,6 +82,10 @@ struct DevBuf {
   }
 };
 
+// launchers exported by p2mt_hash.hip to the other translation units (enqueue on rt().stream, device pointers)
+int launch_hash_rows_dev(const uint64_t* d_in, size_t n, size_t len, int noop_short, uint64_t* d_out);
+int launch_merkle_level_dev(const uint64_t* d_in, uint64_t* d_out, size_t n_out);
+
 }  // namespace p2mt
 
 #define P2MT_HIP(x)                                                           \

@@ -1,0 +1,181 @@
+// tree_common.hip.h -- device helpers shared by p2mt_hash.hip and p2mt_mmr.hip: HashOut load/store, post-order
+// position, the re-loadable permutation wrappers of the fast path, the sponge, and the 12-lane / 4-lane two_to_one.
+#pragma once
+#include "poseidon_quad.hip.h"
+#include "runtime.h"
+
+namespace p2mt_dev {
+
+using gl::u32;
+using gl::u64;
+using p2mt::PermCtx;
+
+constexpr int kBlock = 256;
+
+GL_DEV void load_hash(const u64* p, u64 (&h)[4]) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+  const ulonglong2 a = q[0], b = q[1];
+  h[0] = a.x; h[1] = a.y; h[2] = b.x; h[3] = b.y;
+}
+GL_DEV void store_hash(u64* p, const u64 (&h)[4]) {
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
+  q[0] = make_ulonglong2(h[0], h[1]);
+  q[1] = make_ulonglong2(h[2], h[3]);
+}
+
+GL_DEV size_t node_pos(size_t last_leaf, unsigned h) { return 2 * last_leaf - (size_t)__popcll(last_leaf) + h; }
+
+constexpr int IMPL_FAST = 2;  // M == 2: poseidon_fast with exact fallback; M in {0,1}: exact variants of poseidon.hip.h
+
+// One permutation whose input can be re-materialised: `load` fills the state (it is called again if the fast
+// path raised its sticky flag, so that no copy of the input has to stay live in VGPRs).
+template <int M, int PR, typename Load>
+GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load) {
+  load(s);
+  if constexpr (M == IMPL_FAST) {
+    const u64 sticky = poseidon_fast::permute(s, ctx.rc) | ctx.force_fallback;
+    if (__builtin_expect(sticky != 0, 0)) {
+      load(s);
+      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+    }
+  } else {
+    poseidon::permute<M, PR>(s);
+  }
+}
+
+// two_to_one(l, r) with l/r produced by `load_lr`
+template <int M, int PR, typename LoadLR>
+GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr) {
+  u64 s[12];
+  auto load = [&](u64 (&st)[12]) {
+    u64 l[4], r[4];
+    load_lr(l, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      st[k] = l[k];
+      st[4 + k] = r[k];
+      st[8 + k] = 0;
+    }
+  };
+  if constexpr (M == IMPL_FAST) {  // capacity words are zero and only 4 output words are needed
+    load(s);
+    const u64 sticky = poseidon_fast::permute<true, 4>(s, ctx.rc) | ctx.force_fallback;
+    if (__builtin_expect(sticky != 0, 0)) {  // ~0.5 % of waves.  (Redoing with the exact fast-form instead was
+      load(s);                               //  measured 2 % slower overall: bigger kernel, worse allocation.)
+      poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+    }
+  } else {
+    permute_reloadable<M, PR>(s, ctx, load);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = gl::canon(s[k]);
+}
+
+
+// hash_or_noop / hash_no_pad of `len`-element rows: overwrite-mode sponge, rate 8, one row per lane.
+// `get(k)` returns element k of the row.  With the fast variant the whole row is redone exactly if any of its
+// permutations raised the sticky flag.
+template <int M, int PR, typename Get>
+GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
+  u64 s[12];
+  auto run = [&](auto fast) -> u64 {
+    u64 sticky = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = 0;
+#pragma unroll 1
+    for (size_t off = 0; off < len; off += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (off + k < len) s[k] = get(off + k);
+      if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute(s, ctx.rc);
+      else if constexpr (M == IMPL_FAST) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+      else poseidon::permute<M, PR>(s);
+    }
+    return sticky;
+  };
+  if constexpr (M == IMPL_FAST) {
+    const u64 sticky = run(std::true_type{}) | ctx.force_fallback;
+    if (__builtin_expect(sticky != 0, 0)) run(std::false_type{});
+  } else {
+    run(std::false_type{});
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = gl::canon(s[k]);
+}
+
+
+// ---------------------------------------------------------------- one wavefront per node (latency path)
+// Near the top of the tree a level has fewer nodes than the chip has lanes, and a lane-per-hash launch costs one
+// full single-hash latency (~65 us) whatever its size.  Here 12 lanes of a wave share ONE permutation: lane i owns
+// state word i, the twelve S-boxes of a full round run in parallel, and the MDS row of lane r is two mad chains
+// over the words broadcast with v_readlane (SGPR operands) against that lane's row of constants.  All 30 rounds
+// are unrolled with the lane's round constants preloaded, so a node takes ~3.5k instructions instead of ~28k.
+// Used for levels of <= 2^12 nodes; bit-identical to the lane-per-hash kernels.  Exact arithmetic (no sticky flag):
+// a flagged wave redoing its node serially would set the duration of the whole (latency-bound) launch.
+// out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
+GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
+                            const PermCtx& ctx) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned w = lane < 12 ? lane : 0;  // lanes >= 12 shadow lane 0 (results unused)
+
+  u64 x = lane < 4 ? lp[lane] : (lane < 8 ? rp[lane - 4] : 0);
+  u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
+#pragma unroll
+  for (int c = 0; c < 12; ++c) kk[c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - w) % 12] + ((w == 0 && c == 0) ? 8u : 0u);
+
+  const u64* rcw = ctx.rc + w;     // this lane's column of the round-constant table
+  u64 c_next = rcw[12];            // constant of round r+1, fetched one round ahead (hidden under the S-box)
+  x = gl::add_c(x, rcw[0]);
+  // one round: S-box (every lane in a full round, lane 0 in a partial one), then this lane's MDS row with the
+  // next round's constant folded into the two mad chains
+  auto round = [&](bool full, bool add, u64 c_fold) {
+    const u64 y = poseidon_fast::exact::pow7(x);
+    if (full || lane == 0) x = y;
+    const u32 xl = (u32)x, xh = (u32)(x >> 32);
+    u64 al = add ? (u64)(u32)c_fold : 0, ah = add ? (u64)(u32)(c_fold >> 32) : 0;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const u32 sl = (u32)__builtin_amdgcn_readlane((int)xl, c), sh = (u32)__builtin_amdgcn_readlane((int)xh, c);
+      al += (u64)sl * kk[c];
+      ah += (u64)sh * kk[c];
+    }
+    ah = poseidon_fast::add32((u32)(al >> 32), ah);
+    const u64 val = ((u64)(u32)ah << 32) | (u32)al;
+    x = poseidon_fast::exact::fold96((u32)(ah >> 32), val);
+  };
+#pragma unroll 1
+  for (int r = 0; r < POSEIDON_ROUNDS - 1; ++r) {
+    const u64 c_fold = c_next;
+    if (r + 2 < POSEIDON_ROUNDS) c_next = rcw[12 * (r + 2)];
+    const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
+    round(full, true, c_fold);
+  }
+  round(true, false, 0);
+  if (lane < 4) out[lane] = gl::canon(x);
+}
+
+
+// ---------------------------------------------------------------- four lanes per node (poseidon_quad.hip.h)
+// out[0..4) = two_to_one(lp, rp) computed by the calling quad (all four lanes call it with the same pointers)
+GL_DEV void two_to_one_quad(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
+                            const poseidon_quad::Lane& ln) {
+  u64 x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const u32 w = 3 * ln.q + i;
+    x[i] = w < 4 ? lp[w] : (w < 8 ? rp[w - 4] : 0);
+  }
+  poseidon_quad::permute(x, ln);
+  if (ln.q == 0) {
+    out[0] = gl::canon(x[0]);
+    out[1] = gl::canon(x[1]);
+    out[2] = gl::canon(x[2]);
+  } else if (ln.q == 1) {
+    out[3] = gl::canon(x[0]);
+  }
+}
+
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace p2mt_dev
