@@ -211,6 +211,73 @@ int p2mt_polynomial_batch_commit_dev(const uint64_t *d_polys, int is_values, siz
                                      unsigned rate_bits, unsigned cap_height, uint64_t *d_leaves_out,
                                      uint64_t *d_digests_out, uint64_t *d_cap_out);
 
+/* ------------------------------------------------------------------ Plonky2 opening proof (challenger + FRI)
+ * The last stage of CircuitData::prove (mmr_plonky2_verifier.rs:148, mmr_plonky2_verifier_1_recursion.rs:192,218):
+ * plonky2's iop/challenger.rs Challenger, OpeningSet evaluation (plonk/proof.rs eval_all) and
+ * PolynomialBatch::prove_openings -> fri_proof (fri/oracle.rs, fri/prover.rs): alpha-composition of the opened
+ * polynomials, division by (X - z), commit phase (fold by 2^arity_bits, coset FFT, Merkle cap per layer), proof-of-work
+ * grind, query openings.  Extension elements (F[X]/(X^2 - 7)) are 2 consecutive words (a + bX).  Everything runs on the
+ * device; the challenger state lives in device memory so that challenges feed the next kernel without a host round trip.
+ * [parity unpinned: plonky2's source is not part of the reference tree; the tests check against a CPU restatement.] */
+typedef struct p2mt_challenger p2mt_challenger;
+int p2mt_challenger_create(p2mt_challenger **out);  /* Challenger::new(): zero sponge, empty buffers */
+int p2mt_challenger_destroy(p2mt_challenger *c);
+int p2mt_challenger_clone(const p2mt_challenger *src, p2mt_challenger **out);
+/* observe_elements / observe_hash / observe_cap / observe_extension_elements: all are element streams */
+int p2mt_challenger_observe(p2mt_challenger *c, const uint64_t *elements, size_t n);
+int p2mt_challenger_observe_dev(p2mt_challenger *c, const uint64_t *d_elements, size_t n); /* enqueues, returns */
+/* get_n_challenges (an extension challenge = 2 of them, in this order) */
+int p2mt_challenger_get_challenges(p2mt_challenger *c, size_t n, uint64_t *out);
+int p2mt_challenger_get_challenges_dev(p2mt_challenger *c, size_t n, uint64_t *d_out); /* enqueues, returns */
+/* state words for tests/checkpoints: sponge_state[12] | input_buffer[8] | output_buffer[8] | n_in | n_out */
+#define P2MT_CHALLENGER_STATE_WORDS 30
+int p2mt_challenger_get_state(const p2mt_challenger *c, uint64_t *out);
+int p2mt_challenger_set_state(p2mt_challenger *c, const uint64_t *in);
+
+/* PolynomialCoeffs::eval of base-field polynomials at one extension point: out[j] = f_j(point), 2 words each */
+int p2mt_eval_polys_ext(const uint64_t *coeffs /*[n_polys][2^log_n]*/, size_t n_polys, unsigned log_n,
+                        const uint64_t point[2], uint64_t *out /*[n_polys][2]*/);
+int p2mt_eval_polys_ext_dev(const uint64_t *d_coeffs, size_t n_polys, unsigned log_n, const uint64_t point[2],
+                            uint64_t *d_out);
+
+/* FriParams (fri/mod.rs): FriConfig + degree_bits + reduction_arity_bits; hiding = false (zero_knowledge off in
+ * standard_recursion_config, mmr_plonky2_verifier.rs:30) */
+typedef struct p2mt_fri_params {
+  uint32_t degree_bits, rate_bits, cap_height, proof_of_work_bits, num_query_rounds, num_reductions;
+  uint32_t reduction_arity_bits[8]; /* each in 1..4 */
+} p2mt_fri_params;
+/* standard_recursion_config: rate_bits 3, cap_height 4, PoW 16 bits, 28 queries, ConstantArityBits(4, 5) */
+int p2mt_fri_params_standard(unsigned degree_bits, p2mt_fri_params *out);
+/* One committed PolynomialBatch, as p2mt_polynomial_batch_commit* leaves it: coefficients poly-major
+ * [n_polys][2^degree_bits]; leaves [N][n_polys] (N = 2^(degree_bits+rate_bits), bit-reversed point order); digests
+ * level-major.  Host pointers for p2mt_fri_prove_openings, device pointers for the _dev form. */
+typedef struct p2mt_fri_oracle {
+  const uint64_t *coeffs, *leaves, *digests;
+  uint64_t n_polys;
+} p2mt_fri_oracle;
+/* FriBatchInfo: one opening point and the polynomials opened there as (oracle index, polynomial index) pairs */
+typedef struct p2mt_fri_batch {
+  uint64_t point[2];
+  const uint32_t *polys; /* host memory, 2 * n_polys entries */
+  uint64_t n_polys;
+} p2mt_fri_batch;
+/* FriProof as words, plonky2's serialisation order:
+ *   commit_phase_merkle_caps [num_reductions][2^cap_height][4]
+ *   query_round_proofs [num_query_rounds] x { per oracle: leaf row [n_polys] | siblings [log N - cap_height][4];
+ *                                             per layer: evals [2^arity_bits][2] | siblings [..][4] }
+ *   final_poly [2^(degree_bits - sum arity_bits)][2]
+ *   pow_witness [1]  -- the SMALLEST valid witness (plonky2 takes any: parallel find_any, non-deterministic) */
+size_t p2mt_fri_proof_len(const p2mt_fri_params *params, size_t n_oracles, const uint64_t *n_polys);
+/* PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params).  The challenger must have observed
+ * everything up to and including the openings; it is advanced exactly as plonky2's is (alpha, per-layer cap/beta,
+ * final poly, PoW witness/response, query indices).  Synchronises the library stream before returning. */
+int p2mt_fri_prove_openings(const p2mt_fri_oracle *oracles, size_t n_oracles, const p2mt_fri_batch *batches,
+                            size_t n_batches, const p2mt_fri_params *params, p2mt_challenger *challenger,
+                            uint64_t *proof_out);
+int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle *d_oracles, size_t n_oracles, const p2mt_fri_batch *batches,
+                                size_t n_batches, const p2mt_fri_params *params, p2mt_challenger *challenger,
+                                uint64_t *d_proof_out);
+
 #ifdef __cplusplus
 }
 #endif

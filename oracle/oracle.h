@@ -111,6 +111,46 @@ int oracle_polynomial_batch_commit(const uint64_t *polys, int is_values, size_t 
                                    unsigned rate_bits, unsigned cap_height, uint64_t *leaves_out,
                                    uint64_t *digests_out, uint64_t *cap_out);
 
+/* ---- plonky2 iop/challenger.rs, fri/{oracle,prover,verifier}.rs  [parity unpinned] (oracle/fri.c) ---- */
+typedef struct oracle_challenger {
+  uint64_t state[12];
+  uint64_t in[8];
+  uint64_t out[8];
+  uint32_t n_in, n_out;
+} oracle_challenger;
+void oracle_challenger_init(oracle_challenger *c);
+void oracle_challenger_observe(oracle_challenger *c, const uint64_t *e, size_t n);
+uint64_t oracle_challenger_get(oracle_challenger *c);
+
+typedef struct oracle_fri_params {
+  uint32_t degree_bits, rate_bits, cap_height, proof_of_work_bits, num_query_rounds, num_reductions;
+  uint32_t reduction_arity_bits[8];
+} oracle_fri_params;
+/* one committed PolynomialBatch: coeffs poly-major n_polys x 2^degree_bits; leaves/digests as produced by
+ * oracle_polynomial_batch_commit (leaves row-major N x n_polys in bit-reversed point order, digests level-major) */
+typedef struct oracle_fri_oracle {
+  const uint64_t *coeffs, *leaves, *digests;
+  uint64_t n_polys;
+} oracle_fri_oracle;
+/* FriBatchInfo: opening point (extension element) + (oracle_index, polynomial_index) pairs */
+typedef struct oracle_fri_batch {
+  uint64_t point[2];
+  const uint32_t *polys;
+  uint64_t n_polys;
+} oracle_fri_batch;
+void oracle_ext_mul(const uint64_t x[2], const uint64_t y[2], uint64_t out[2]);
+void oracle_ext_inv(const uint64_t x[2], uint64_t out[2]);
+void oracle_fri_params_standard(unsigned degree_bits, oracle_fri_params *p);
+/* proof words: commit-phase caps | per query: per oracle (leaf row | siblings), per layer (evals | siblings) | final poly | pow witness */
+size_t oracle_fri_proof_len(const oracle_fri_params *p, size_t n_oracles, const uint64_t *n_polys);
+void oracle_eval_polys_ext(const uint64_t *coeffs, size_t n_polys, unsigned log_n, const uint64_t point[2], uint64_t *out);
+int oracle_fri_prove(const oracle_fri_oracle *oracles, size_t n_oracles, const oracle_fri_batch *batches, size_t n_batches,
+                     const oracle_fri_params *p, oracle_challenger *ch, uint64_t *proof_out);
+/* caps: n_oracles x 2^cap_height x 4; openings: per batch, n_polys extension values (2 words each), batches concatenated */
+int oracle_fri_verify(const uint64_t *n_polys, size_t n_oracles, const uint64_t *caps, const oracle_fri_batch *batches,
+                      size_t n_batches, const uint64_t *openings, const oracle_fri_params *p, oracle_challenger *ch,
+                      const uint64_t *proof, int *reason);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,21 @@ SIGNATURES = {
                                                voidp, voidp]),
     "p2mt_polynomial_batch_commit_dev": (C.c_int, [voidp, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, voidp,
                                                    voidp, voidp]),
+    "p2mt_challenger_create": (C.c_int, [C.POINTER(voidp)]),
+    "p2mt_challenger_destroy": (C.c_int, [voidp]),
+    "p2mt_challenger_clone": (C.c_int, [voidp, C.POINTER(voidp)]),
+    "p2mt_challenger_observe": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_challenger_observe_dev": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_challenger_get_challenges": (C.c_int, [voidp, C.c_size_t, voidp]),
+    "p2mt_challenger_get_challenges_dev": (C.c_int, [voidp, C.c_size_t, voidp]),
+    "p2mt_challenger_get_state": (C.c_int, [voidp, voidp]),
+    "p2mt_challenger_set_state": (C.c_int, [voidp, voidp]),
+    "p2mt_eval_polys_ext": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
+    "p2mt_eval_polys_ext_dev": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
+    "p2mt_fri_params_standard": (C.c_int, [C.c_uint, voidp]),
+    "p2mt_fri_proof_len": (C.c_size_t, [voidp, C.c_size_t, voidp]),
+    "p2mt_fri_prove_openings": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, voidp, voidp]),
+    "p2mt_fri_prove_openings_dev": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, voidp, voidp]),
 }
 
 

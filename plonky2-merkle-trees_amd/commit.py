@@ -80,8 +80,9 @@ class PolynomialBatch:
     """plonky2 fri/oracle.rs PolynomialBatch (blinding = false): LDE of every polynomial on the coset 7*<w_N>,
     leaf i (bit-reversed order) = all polynomials at one point, Merkle tree with a cap."""
 
-    def __init__(self, tree, n_polys, degree_log, rate_bits):
+    def __init__(self, tree, n_polys, degree_log, rate_bits, polynomials=None):
         self.merkle_tree, self.n_polys, self.degree_log, self.rate_bits = tree, n_polys, degree_log, rate_bits
+        self.polynomials = polynomials  # coefficients [n_polys][n], what prove_openings composes (fri.py)
 
     @staticmethod
     def _commit(polys, is_values, rate_bits, cap_height, want_leaves):
@@ -97,7 +98,8 @@ class PolynomialBatch:
         cap = np.zeros((1 << cap_height, 4), np.uint64)
         N.check(N.lib().p2mt_polynomial_batch_commit(N.ptr(polys), int(is_values), n_polys, log_n, rate_bits,
                                                      cap_height, N.ptr(leaves), N.ptr(digests), N.ptr(cap)))
-        return PolynomialBatch(MerkleCapTree(leaves, digests[:nd], cap, cap_height), n_polys, log_n, rate_bits)
+        return PolynomialBatch(MerkleCapTree(leaves, digests[:nd], cap, cap_height), n_polys, log_n, rate_bits,
+                               ifft(polys) if is_values else polys)
 
     @staticmethod
     def from_values(values, rate_bits=RATE_BITS, cap_height=CAP_HEIGHT, want_leaves=True):

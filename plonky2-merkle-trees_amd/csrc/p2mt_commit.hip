@@ -510,8 +510,8 @@ extern "C" int p2mt_ntt_batch(uint64_t* data, unsigned log_n, size_t n_polys, in
 }
 
 // LDE into leaf order (poly-major): d_out[p][brev(i)] = f_p(shift * w_N^i)
-static int coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned rate_bits, u64 shift, size_t n_polys,
-                                    u64* d_out) {
+int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned rate_bits, u64 shift, size_t n_polys,
+                                   u64* d_out) {
   if (log_n > kLdsLog) return p2mt::fail(P2MT_EINVAL, "coset_lde: log_n > 12 not supported yet");
   if (rate_bits > 8 || log_n + rate_bits > 32) return p2mt::fail(P2MT_EINVAL, "coset_lde: bad rate_bits");
   const u64 *tw, *cp;
@@ -541,7 +541,7 @@ extern "C" int p2mt_coset_lde_batch_dev(const uint64_t* d_coeffs, unsigned log_n
   const size_t total = n_polys << log_big;
   DevBuf tmp;
   P2MT_TRY(tmp.alloc(total * 8));
-  P2MT_TRY(coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, shift, n_polys, tmp.as<u64>()));
+  P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, shift, n_polys, tmp.as<u64>()));
   hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(total)), dim3(kBlock), 0, rt().stream, (const u64*)tmp.as<u64>(), d_out,
                      log_big, n_polys, (u64)1);
   P2MT_LAUNCH_CHECK();
@@ -658,7 +658,7 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
   }
   u64* lde;
   P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
-  P2MT_TRY(coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
+  P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
   if (d_leaves_out) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
                        (const u64*)lde, d_leaves_out, n_polys, big);

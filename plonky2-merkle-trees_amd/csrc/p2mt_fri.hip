@@ -1,0 +1,693 @@
+// p2mt_fri.hip -- Plonky2's opening proof on the device: Challenger, opening evaluation and FRI.
+//
+// Replaces, inside CircuitData::prove (reference call sites /root/reference/src/mmr/mmr_plonky2_verifier.rs:148 and
+// mmr_plonky2_verifier_1_recursion.rs:192,218), plonky2's iop/challenger.rs, plonk/proof.rs eval_all and
+// fri/oracle.rs prove_openings -> fri/prover.rs fri_proof [plonky2 source is not in the reference tree: parity unpinned,
+// the tests compare against a CPU restatement of the same algorithm, whose verifier is the acceptance check].
+//
+// Shape of the computation: a chain of small dependent steps (challenge -> compose -> divide -> LDE -> Merkle cap ->
+// challenge -> fold -> ...), so the design goal is latency, not bandwidth:
+//   * the challenger state lives in device memory and is advanced by a one-wavefront kernel (12 lanes share one
+//     permutation, permute_wave); alpha/beta/query indices are read by the next kernel straight from device memory, so
+//     the whole proof is enqueued without a host round trip except for the proof-of-work result;
+//   * the alpha-composition is a dot product against a table of alpha powers split into real/imaginary parts (two
+//     base-field multiply-adds per coefficient and polynomial instead of an extension multiplication);
+//   * (F(X) - F(z)) / (X - z) is a suffix scan of affine maps in LDS; folding and layer LDEs reuse the commit step's
+//     coset-LDE kernels on the two components of the extension polynomial (base-field twiddles act componentwise);
+//   * the proof-of-work grind is the one throughput kernel: one candidate per lane on the issue-optimised permutation,
+//     atomicMin keeps the smallest witness (deterministic proofs).
+// HBM layout: extension polynomials are two base-field arrays (component-major) while they are transformed, and
+// (a, b) pairs once they become Merkle leaves / proof words.
+#include "tree_common.hip.h"
+
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+using namespace p2mt_dev;
+using p2mt::DevBuf;
+using p2mt::rt;
+
+namespace {
+
+// ---------------------------------------------------------------- F[X]/(X^2 - 7), loose u64 components
+struct Ext {
+  u64 a, b;
+};
+GL_DEV Ext ext_add(Ext x, Ext y) { return Ext{gl::add(x.a, y.a), gl::add(x.b, y.b)}; }
+GL_DEV Ext ext_mul(Ext x, Ext y) {
+  const u64 bb7 = gl::mul(gl::mul(x.b, y.b), 7);
+  return Ext{gl::mul_add(x.a, y.a, bb7), gl::mul_add(x.a, y.b, gl::mul(x.b, y.a))};
+}
+// x * z + c, c in the base field
+GL_DEV Ext ext_mul_add_base(Ext x, Ext z, u64 c) {
+  Ext r = ext_mul(x, z);
+  r.a = gl::add(r.a, c);
+  return r;
+}
+GL_DEV Ext ext_pow(Ext x, u64 e) {
+  Ext r{1, 0};
+  while (e) {
+    if (e & 1) r = ext_mul(r, x);
+    x = ext_mul(x, x);
+    e >>= 1;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------- iop/challenger.rs
+struct ChState {
+  u64 state[12];
+  u64 in[8];
+  u64 out[8];
+  u32 n_in, n_out;
+};
+static_assert(sizeof(ChState) == 8 * (12 + 8 + 8) + 8, "layout shared with p2mt_challenger_get_state");
+
+// Observe obs[0..n_obs), then squeeze n_sq challenges into sq.  One wavefront; lane w < 12 owns sponge word w.
+__global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, const u64* __restrict__ obs, u32 n_obs,
+                                                   u64* __restrict__ sq, u32 n_sq, PermCtx ctx) {
+  __shared__ u64 s_in[8], s_out[8];
+  const unsigned lane = threadIdx.x;
+  u64 x = lane < 12 ? st->state[lane] : 0;
+  u32 n_in = st->n_in, n_out = st->n_out;  // wave-uniform
+  if (lane < 8) {
+    s_in[lane] = st->in[lane];
+    s_out[lane] = st->out[lane];
+  }
+  __syncthreads();
+  // duplexing(): overwrite the first n_in words with the buffered inputs, permute, refill the output buffer
+  auto duplex = [&]() {
+    if (lane < n_in) x = s_in[lane];
+    n_in = 0;
+    x = permute_wave(x, ctx);
+    __syncthreads();
+    if (lane < 8) s_out[lane] = gl::canon(x);
+    __syncthreads();
+    n_out = 8;
+  };
+#pragma unroll 1
+  for (u32 i = 0; i < n_obs; ++i) {
+    n_out = 0;  // observe_element: buffered outputs are stale
+    if (lane == 0) s_in[n_in] = gl::canon(obs[i]);
+    n_in += 1;
+    __syncthreads();
+    if (n_in == 8) duplex();
+  }
+#pragma unroll 1
+  for (u32 k = 0; k < n_sq; ++k) {
+    if (n_in != 0 || n_out == 0) duplex();
+    n_out -= 1;  // Vec::pop: from the back
+    if (lane == 0) sq[k] = s_out[n_out];
+  }
+  __syncthreads();
+  if (lane < 12) st->state[lane] = gl::canon(x);
+  if (lane < 8) {
+    st->in[lane] = s_in[lane];
+    st->out[lane] = s_out[lane];
+  }
+  if (lane == 0) {
+    st->n_in = n_in;
+    st->n_out = n_out;
+  }
+}
+
+// fri_proof_of_work: candidate = base + gid goes where the next observed element would; the response is the first
+// challenge after it (word 7 of the permuted state).  *result = smallest passing candidate (init ~0).
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ st, u32 pow_bits, u64 base, u64 count,
+                                                    unsigned long long* __restrict__ result, PermCtx ctx) {
+  const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+  if (gid >= count) return;
+  const u64 cand = base + gid;
+  const u32 n_in = st->n_in;  // < 8: a full buffer is duplexed at once
+  u64 s[12];
+  permute_reloadable<M, PR>(s, ctx, [&](u64 (&t)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      u64 v = st->state[k];
+      if (k < 8) {
+        if ((u32)k < n_in) v = st->in[k];
+        else if ((u32)k == n_in) v = cand;
+      }
+      t[k] = v;
+    }
+  });
+  const u64 resp = gl::canon(s[7]);
+  if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
+}
+
+// ---------------------------------------------------------------- alpha-composition
+// table[j] = base^j, j < count (canonical pairs)
+__global__ __launch_bounds__(kBlock) void k_ext_powers(const u64* __restrict__ base, u32 count, u64* __restrict__ table) {
+  const u32 j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= count) return;
+  const Ext r = ext_pow(Ext{base[0], base[1]}, j);
+  table[2 * j] = gl::canon(r.a);
+  table[2 * j + 1] = gl::canon(r.b);
+}
+
+constexpr u32 kComposeGroup = 32;  // polynomials per partial sum
+
+// partial[g][c][i] = sum_{j in group g} (alpha^j)_c * f_j[i]   (ReducingFactor::reduce_polys_base as a dot product)
+__global__ __launch_bounds__(kBlock) void k_fri_compose(const u64* const* __restrict__ ptrs, u32 cnt, u32 n,
+                                                        const u64* __restrict__ apow, u64* __restrict__ partial) {
+  const u32 i = blockIdx.x * kBlock + threadIdx.x, g = blockIdx.y;
+  if (i >= n) return;
+  const u32 j0 = g * kComposeGroup, j1 = min(cnt, j0 + kComposeGroup);
+  u64 re = 0, im = 0;
+#pragma unroll 4
+  for (u32 j = j0; j < j1; ++j) {
+    const u64 c = ptrs[j][i];
+    re = gl::mul_add(apow[2 * j], c, re);
+    im = gl::mul_add(apow[2 * j + 1], c, im);
+  }
+  partial[((size_t)g * 2) * n + i] = re;
+  partial[((size_t)g * 2 + 1) * n + i] = im;
+}
+
+// divide_by_linear + ReducingFactor::shift_poly + `final_poly += quotient`, one workgroup:
+//   b_n = 0, b_m = b_{m+1} z + c_m, quotient coefficient m = b_{m+1};  fin[m] = fin[m] * alpha^cnt + b_{m+1}.
+// The recurrence is a suffix scan: each thread reduces its chunk to one value, a log-step scan over the chunk values
+// gives every chunk its carry-in, then the chunk is replayed.
+__global__ __launch_bounds__(kBlock) void k_fri_quotient(const u64* __restrict__ partial, u32 n_groups, u32 n, u64 za, u64 zb,
+                                                         const u64* __restrict__ alpha, u32 cnt, int first,
+                                                         u64* __restrict__ fin) {
+  __shared__ Ext S[kBlock];
+  const u32 len = n >= (u32)kBlock ? n / kBlock : 1, T = n / len, t = threadIdx.x;
+  const Ext z{za, zb};
+  const u32 s = t * len, e = s + len;
+  auto coeff = [&](u32 m) {
+    Ext c{0, 0};
+    for (u32 g = 0; g < n_groups; ++g) {
+      c.a = gl::add(c.a, partial[((size_t)g * 2) * n + m]);
+      c.b = gl::add(c.b, partial[((size_t)g * 2 + 1) * n + m]);
+    }
+    return c;
+  };
+  Ext loc{0, 0};
+  if (t < T)
+    for (u32 m = e; m-- > s;) loc = ext_add(ext_mul(loc, z), coeff(m));
+  S[t] = loc;
+  __syncthreads();
+  Ext zp = ext_pow(z, len);
+  for (u32 d = 1; d < T; d *= 2) {
+    Ext v = S[t];
+    if (t + d < T) v = ext_add(v, ext_mul(zp, S[t + d]));
+    __syncthreads();
+    S[t] = v;
+    __syncthreads();
+    zp = ext_mul(zp, zp);
+  }
+  if (t >= T) return;
+  Ext acc = t + 1 < T ? S[t + 1] : Ext{0, 0};  // b at the end of this chunk
+  const Ext sh = first ? Ext{0, 0} : ext_pow(Ext{alpha[0], alpha[1]}, cnt);
+  for (u32 m = e; m-- > s;) {
+    Ext q = acc;
+    if (!first) q = ext_add(q, ext_mul(Ext{fin[m], fin[n + m]}, sh));
+    fin[m] = gl::canon(q.a);
+    fin[n + m] = gl::canon(q.b);
+    acc = ext_add(ext_mul(acc, z), coeff(m));
+  }
+}
+
+// coeffs.insert(0, ZERO) (plonky2 PR 436): out[c][0] = 0, out[c][m+1] = fin[c][m]; fin[c][n-1] is zero by construction
+__global__ __launch_bounds__(kBlock) void k_fri_mul_x(const u64* __restrict__ fin, u32 n, u64* __restrict__ out) {
+  const u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= 2 * n) return;
+  const u32 m = i & (n - 1);
+  out[i] = m == 0 ? 0 : fin[i - 1];
+}
+
+// (a, b) pairs from component-major arrays: the layer's Merkle leaves (2^arity_bits consecutive pairs per row) and
+// the final polynomial's proof words
+__global__ __launch_bounds__(kBlock) void k_fri_pairs(const u64* __restrict__ comp, u32 n, u64* __restrict__ out) {
+  const u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  reinterpret_cast<ulonglong2*>(out)[i] = make_ulonglong2(comp[i], comp[n + i]);
+}
+
+// P(x) = sum_{i<r} x^i P_i(x^r)  ->  sum_{i<r} beta^i P_i(x): out[k] = sum_i beta^i in[k r + i]
+__global__ __launch_bounds__(kBlock) void k_fri_fold(const u64* __restrict__ in, u32 n_in, u32 arity_bits,
+                                                     const u64* __restrict__ beta, u64* __restrict__ out) {
+  const u32 n_out = n_in >> arity_bits, k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n_out) return;
+  const Ext b{beta[0], beta[1]};
+  const u32 r = 1u << arity_bits;
+  Ext acc{0, 0};
+  for (u32 i = r; i-- > 0;) {
+    acc = ext_mul(acc, b);
+    acc.a = gl::add(acc.a, in[k * r + i]);
+    acc.b = gl::add(acc.b, in[n_in + k * r + i]);
+  }
+  out[k] = gl::canon(acc.a);
+  out[n_out + k] = gl::canon(acc.b);
+}
+
+// ---------------------------------------------------------------- fri_prover_query_rounds
+struct QTree {
+  const u64* leaves;   // row-major rows x width
+  const u64* digests;  // level-major
+  u32 width, log_rows, idx_shift, n_sib;
+};
+constexpr int kMaxQTrees = 16;
+struct QArgs {
+  QTree t[kMaxQTrees];
+  u32 n_trees, log_big;
+  u64 per_query;
+};
+
+// One workgroup per query round: x_index = challenge mod N; per tree the opened row and its Merkle path.
+__global__ __launch_bounds__(kBlock) void k_fri_queries(QArgs a, const u64* __restrict__ qch, u64* __restrict__ out) {
+  const u64 x_index = qch[blockIdx.x] & (((u64)1 << a.log_big) - 1);
+  u64* w = out + (u64)blockIdx.x * a.per_query;
+  for (u32 ti = 0; ti < a.n_trees; ++ti) {
+    const QTree& tr = a.t[ti];
+    const u64 row = x_index >> tr.idx_shift;
+    for (u32 i = threadIdx.x; i < tr.width; i += kBlock) w[i] = tr.leaves[row * tr.width + i];
+    w += tr.width;
+    const u64 rows = (u64)1 << tr.log_rows;
+    for (u32 i = threadIdx.x; i < 4 * tr.n_sib; i += kBlock) {
+      const u32 s = i >> 2;
+      const u64 off = 2 * rows - 2 * (rows >> s);  // rows + rows/2 + ... (s terms)
+      w[i] = tr.digests[4 * (off + ((row >> s) ^ 1)) + (i & 3)];
+    }
+    w += 4 * tr.n_sib;
+  }
+}
+
+// ---------------------------------------------------------------- PolynomialCoeffs::eval at an extension point
+// One workgroup per polynomial: per-thread Horner over a chunk, then a tree reduction with z^(len 2^s).
+__global__ __launch_bounds__(kBlock) void k_eval_ext(const u64* __restrict__ coeffs, u32 log_n, u64 za, u64 zb,
+                                                     u64* __restrict__ out) {
+  __shared__ Ext S[kBlock];
+  const u32 n = 1u << log_n, len = n >= (u32)kBlock ? n / kBlock : 1, T = n / len, t = threadIdx.x;
+  const u64* c = coeffs + ((size_t)blockIdx.x << log_n);
+  const Ext z{za, zb};
+  Ext loc{0, 0};
+  if (t < T)
+    for (u32 m = (t + 1) * len; m-- > t * len;) loc = ext_mul_add_base(loc, z, c[m]);
+  S[t] = loc;
+  __syncthreads();
+  Ext zp = ext_pow(z, len);
+  for (u32 d = 1; d < T; d *= 2) {
+    if ((t & (2 * d - 1)) == 0 && t + d < T) S[t] = ext_add(S[t], ext_mul(zp, S[t + d]));
+    __syncthreads();
+    zp = ext_mul(zp, zp);
+  }
+  if (t == 0) {
+    out[2 * blockIdx.x] = gl::canon(S[0].a);
+    out[2 * blockIdx.x + 1] = gl::canon(S[0].b);
+  }
+}
+
+// ---------------------------------------------------------------- host helpers
+inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
+inline u64 h_pow(u64 a, u64 e) {
+  u64 r = 1;
+  for (; e; e >>= 1, a = h_mul(a, a))
+    if (e & 1) r = h_mul(r, a);
+  return r;
+}
+
+unsigned total_arity_bits(const p2mt_fri_params* p) {
+  unsigned t = 0;
+  for (uint32_t l = 0; l < p->num_reductions; ++l) t += p->reduction_arity_bits[l];
+  return t;
+}
+
+bool params_ok(const p2mt_fri_params* p) {
+  if (!p || p->num_reductions > 8 || p->degree_bits > 12 || p->rate_bits > 8 || p->proof_of_work_bits > 40) return false;
+  if (p->cap_height > p->degree_bits + p->rate_bits) return false;
+  unsigned log_sz = p->degree_bits + p->rate_bits, d = p->degree_bits;
+  for (uint32_t l = 0; l < p->num_reductions; ++l) {
+    const unsigned ab = p->reduction_arity_bits[l];
+    if (ab == 0 || ab > 4 || ab > d || log_sz < ab + p->cap_height) return false;
+    log_sz -= ab;
+    d -= ab;
+  }
+  return true;
+}
+
+size_t digests_count(size_t rows, unsigned cap_height) {
+  size_t c = 0;
+  for (size_t r = rows; r > ((size_t)1 << cap_height); r >>= 1) c += r;
+  return c;
+}
+
+int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, size_t n_sq) {
+  if (n_obs > 0xFFFFFFFFull || n_sq > 0xFFFFFFFFull) return p2mt::fail(P2MT_EINVAL, "challenger: too many elements");
+  hipLaunchKernelGGL(k_challenger, dim3(1), dim3(64), 0, rt().stream, st, d_obs, (u32)n_obs, d_sq, (u32)n_sq, p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+}  // namespace
+
+struct p2mt_challenger {
+  ChState* d = nullptr;
+};
+
+// =================================================================== Challenger
+extern "C" int p2mt_challenger_create(p2mt_challenger** out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  p2mt_challenger* c = new (std::nothrow) p2mt_challenger;
+  if (!c) return p2mt::fail(P2MT_ENOMEM, "out of host memory");
+  if (hipMalloc((void**)&c->d, sizeof(ChState)) != hipSuccess) {
+    delete c;
+    return p2mt::fail(P2MT_ENOMEM, "hipMalloc(challenger) failed");
+  }
+  P2MT_HIP(hipMemsetAsync(c->d, 0, sizeof(ChState), rt().stream));
+  *out = c;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_destroy(p2mt_challenger* c) {
+  if (!c) return P2MT_OK;
+  if (c->d) {
+    (void)hipStreamSynchronize(rt().stream);
+    (void)hipFree(c->d);
+  }
+  delete c;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_clone(const p2mt_challenger* src, p2mt_challenger** out) {
+  if (!src || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_TRY(p2mt_challenger_create(out));
+  P2MT_HIP(hipMemcpyAsync((*out)->d, src->d, sizeof(ChState), hipMemcpyDeviceToDevice, rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_observe_dev(p2mt_challenger* c, const uint64_t* d_elements, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || (n && !d_elements)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (n == 0) return P2MT_OK;
+  return launch_challenger(c->d, d_elements, n, nullptr, 0);
+}
+
+extern "C" int p2mt_challenger_observe(p2mt_challenger* c, const uint64_t* elements, size_t n) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || (n && !elements)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (n == 0) return P2MT_OK;
+  DevBuf b;
+  P2MT_TRY(b.alloc(n * 8));
+  P2MT_HIP(hipMemcpyAsync(b.p, elements, n * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(launch_challenger(c->d, b.as<u64>(), n, nullptr, 0));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_get_challenges_dev(p2mt_challenger* c, size_t n, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || (n && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (n == 0) return P2MT_OK;
+  return launch_challenger(c->d, nullptr, 0, d_out, n);
+}
+
+extern "C" int p2mt_challenger_get_challenges(p2mt_challenger* c, size_t n, uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || (n && !out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (n == 0) return P2MT_OK;
+  DevBuf b;
+  P2MT_TRY(b.alloc(n * 8));
+  P2MT_TRY(launch_challenger(c->d, nullptr, 0, b.as<u64>(), n));
+  P2MT_HIP(hipMemcpyAsync(out, b.p, n * 8, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_get_state(const p2mt_challenger* c, uint64_t* out) {
+  if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  ChState h;
+  P2MT_HIP(hipMemcpyAsync(&h, c->d, sizeof h, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  memcpy(out, h.state, 96);
+  memcpy(out + 12, h.in, 64);
+  memcpy(out + 20, h.out, 64);
+  out[28] = h.n_in;
+  out[29] = h.n_out;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_set_state(p2mt_challenger* c, const uint64_t* in) {
+  if (!c || !in) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (in[28] > 7 || in[29] > 8) return p2mt::fail(P2MT_EINVAL, "challenger state: buffer counts out of range");
+  ChState h;
+  memcpy(h.state, in, 96);
+  memcpy(h.in, in + 12, 64);
+  memcpy(h.out, in + 20, 64);
+  h.n_in = (u32)in[28];
+  h.n_out = (u32)in[29];
+  P2MT_HIP(hipMemcpyAsync(c->d, &h, sizeof h, hipMemcpyHostToDevice, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+// =================================================================== OpeningSet evaluation
+extern "C" int p2mt_eval_polys_ext_dev(const uint64_t* d_coeffs, size_t n_polys, unsigned log_n, const uint64_t point[2],
+                                       uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n_polys == 0) return P2MT_OK;
+  if (!d_coeffs || !point || !d_out || log_n > 24 || n_polys > 0x7FFFFFFF) return p2mt::fail(P2MT_EINVAL, "eval_polys_ext: bad argument");
+  hipLaunchKernelGGL(k_eval_ext, dim3((unsigned)n_polys), dim3(kBlock), 0, rt().stream, d_coeffs, log_n, point[0] % gl::P,
+                     point[1] % gl::P, d_out);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_eval_polys_ext(const uint64_t* coeffs, size_t n_polys, unsigned log_n, const uint64_t point[2],
+                                   uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n_polys == 0) return P2MT_OK;
+  if (!coeffs || !point || !out || log_n > 24) return p2mt::fail(P2MT_EINVAL, "eval_polys_ext: bad argument");
+  DevBuf bi, bo;
+  P2MT_TRY(bi.alloc((n_polys << log_n) * 8));
+  P2MT_TRY(bo.alloc(n_polys * 16));
+  P2MT_HIP(hipMemcpyAsync(bi.p, coeffs, (n_polys << log_n) * 8, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_eval_polys_ext_dev(bi.as<u64>(), n_polys, log_n, point, bo.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n_polys * 16, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+// =================================================================== FRI
+extern "C" int p2mt_fri_params_standard(unsigned degree_bits, p2mt_fri_params* out) {
+  if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  memset(out, 0, sizeof *out);
+  out->degree_bits = degree_bits;
+  out->rate_bits = 3;
+  out->cap_height = 4;
+  out->proof_of_work_bits = 16;
+  out->num_query_rounds = 28;
+  // ConstantArityBits(4, 5) (fri/reduction_strategies.rs)
+  const unsigned arity_bits = 4, final_poly_bits = 5;
+  unsigned d = degree_bits;
+  while (d > final_poly_bits && d + out->rate_bits - arity_bits >= out->cap_height && out->num_reductions < 8) {
+    out->reduction_arity_bits[out->num_reductions++] = arity_bits;
+    d -= arity_bits;
+  }
+  return P2MT_OK;
+}
+
+extern "C" size_t p2mt_fri_proof_len(const p2mt_fri_params* p, size_t n_oracles, const uint64_t* n_polys) {
+  if (!params_ok(p) || (n_oracles && !n_polys)) return 0;
+  const unsigned log_big = p->degree_bits + p->rate_bits;
+  size_t len = (size_t)p->num_reductions * ((size_t)4 << p->cap_height);
+  size_t per_query = 0;
+  for (size_t o = 0; o < n_oracles; ++o) per_query += n_polys[o] + 4 * (size_t)(log_big - p->cap_height);
+  unsigned log_sz = log_big;
+  for (uint32_t l = 0; l < p->num_reductions; ++l) {
+    const unsigned ab = p->reduction_arity_bits[l];
+    per_query += ((size_t)2 << ab) + 4 * (size_t)(log_sz - ab - p->cap_height);
+    log_sz -= ab;
+  }
+  len += per_query * p->num_query_rounds;
+  len += (size_t)2 << (p->degree_bits - total_arity_bits(p));
+  return len + 1;
+}
+
+extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                           size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch,
+                                           uint64_t* d_proof) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!oracles || !batches || !ch || !d_proof || n_oracles == 0 || n_batches == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
+  if (!params_ok(p)) return p2mt::fail(P2MT_EINVAL, "fri: unsupported FriParams (degree_bits <= 12, arity_bits in 1..4, layer trees >= cap)");
+  if (n_oracles + p->num_reductions > (size_t)kMaxQTrees) return p2mt::fail(P2MT_EINVAL, "fri: too many oracles");
+  const unsigned log_n = p->degree_bits, log_big = log_n + p->rate_bits;
+  const u32 n = 1u << log_n;
+  const size_t cap_words = (size_t)4 << p->cap_height;
+  size_t max_cnt = 0, total_cnt = 0;
+  std::vector<uint64_t> n_polys(n_oracles);
+  for (size_t o = 0; o < n_oracles; ++o) {
+    if (!oracles[o].coeffs || !oracles[o].leaves || oracles[o].n_polys == 0) return p2mt::fail(P2MT_EINVAL, "fri: bad oracle");
+    if (!oracles[o].digests && log_big > p->cap_height) return p2mt::fail(P2MT_EINVAL, "fri: oracle without digests");
+    n_polys[o] = oracles[o].n_polys;
+  }
+  for (size_t b = 0; b < n_batches; ++b) {
+    if (!batches[b].polys || batches[b].n_polys == 0) return p2mt::fail(P2MT_EINVAL, "fri: empty batch");
+    for (size_t j = 0; j < batches[b].n_polys; ++j)
+      if (batches[b].polys[2 * j] >= n_oracles || batches[b].polys[2 * j + 1] >= oracles[batches[b].polys[2 * j]].n_polys)
+        return p2mt::fail(P2MT_EINVAL, "fri: batch polynomial index out of range");
+    max_cnt = batches[b].n_polys > max_cnt ? batches[b].n_polys : max_cnt;
+    total_cnt += batches[b].n_polys;
+  }
+  const size_t total = p2mt_fri_proof_len(p, n_oracles, n_polys.data());
+  const size_t final_len = (size_t)1 << (log_n - total_arity_bits(p));
+  const size_t off_final = total - 1 - 2 * final_len;
+  const size_t max_groups = (max_cnt + kComposeGroup - 1) / kComposeGroup;
+
+  // ---- workspace (u64 words), one grow-only slot
+  size_t wsz = 0;
+  auto carve = [&](size_t words) {
+    const size_t at = wsz;
+    wsz += (words + 3) & ~(size_t)3;  // 32-byte granules
+    return at;
+  };
+  const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds);
+  const size_t o_apow = carve(2 * max_cnt), o_ptrs = carve(total_cnt), o_partial = carve(max_groups * 2 * n);
+  const size_t o_fin = carve(2 * (size_t)n), o_c0 = carve(2 * (size_t)n), o_c1 = carve(2 * (size_t)n);
+  size_t o_vals[8], o_leaves[8], o_dig[8];
+  {
+    unsigned log_sz = log_big;
+    for (uint32_t l = 0; l < p->num_reductions; ++l) {
+      const unsigned ab = p->reduction_arity_bits[l];
+      o_vals[l] = carve((size_t)2 << log_sz);
+      o_leaves[l] = carve((size_t)2 << log_sz);
+      o_dig[l] = carve(4 * digests_count((size_t)1 << (log_sz - ab), p->cap_height));
+      log_sz -= ab;
+    }
+  }
+  u64* ws;
+  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchFri, wsz * 8, (void**)&ws));
+  hipStream_t st = rt().stream;
+
+  // ---- alpha, composition, quotients
+  P2MT_TRY(launch_challenger(ch->d, nullptr, 0, ws + o_alpha, 2));
+  hipLaunchKernelGGL(k_ext_powers, dim3(grid_for(max_cnt)), dim3(kBlock), 0, st, (const u64*)(ws + o_alpha), (u32)max_cnt,
+                     ws + o_apow);
+  P2MT_LAUNCH_CHECK();
+  std::vector<const u64*> h_ptrs(total_cnt);
+  {
+    size_t k = 0;
+    for (size_t b = 0; b < n_batches; ++b)
+      for (size_t j = 0; j < batches[b].n_polys; ++j)
+        h_ptrs[k++] = oracles[batches[b].polys[2 * j]].coeffs + (size_t)batches[b].polys[2 * j + 1] * n;
+  }
+  P2MT_HIP(hipMemcpyAsync(ws + o_ptrs, h_ptrs.data(), total_cnt * 8, hipMemcpyHostToDevice, st));
+  {
+    size_t k = 0;
+    for (size_t b = 0; b < n_batches; ++b) {
+      const u32 cnt = (u32)batches[b].n_polys, groups = (cnt + kComposeGroup - 1) / kComposeGroup;
+      hipLaunchKernelGGL(k_fri_compose, dim3(grid_for(n), groups), dim3(kBlock), 0, st,
+                         reinterpret_cast<const u64* const*>(ws + o_ptrs + k), cnt, n, (const u64*)(ws + o_apow), ws + o_partial);
+      P2MT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_fri_quotient, dim3(1), dim3(kBlock), 0, st, (const u64*)(ws + o_partial), groups, n,
+                         batches[b].point[0] % gl::P, batches[b].point[1] % gl::P, (const u64*)(ws + o_alpha), cnt, b == 0 ? 1 : 0,
+                         ws + o_fin);
+      P2MT_LAUNCH_CHECK();
+      k += cnt;
+    }
+  }
+  hipLaunchKernelGGL(k_fri_mul_x, dim3(grid_for(2 * (size_t)n)), dim3(kBlock), 0, st, (const u64*)(ws + o_fin), n, ws + o_c0);
+  P2MT_LAUNCH_CHECK();
+
+  // ---- fri_committed_trees
+  QArgs qa;
+  memset(&qa, 0, sizeof qa);
+  for (size_t o = 0; o < n_oracles; ++o)
+    qa.t[o] = QTree{oracles[o].leaves, oracles[o].digests, (u32)oracles[o].n_polys, log_big, 0, log_big - p->cap_height};
+  qa.n_trees = (u32)n_oracles;
+  qa.log_big = log_big;
+  u64 *cur = ws + o_c0, *nxt = ws + o_c1;
+  u64 shift = 7;
+  unsigned log_sz = log_big, log_deg = log_n, idx_shift = 0;
+  for (uint32_t l = 0; l < p->num_reductions; ++l) {
+    const unsigned ab = p->reduction_arity_bits[l];
+    const size_t sz = (size_t)1 << log_sz, rows = sz >> ab;
+    u64* vals = ws + o_vals[l];
+    u64* leaves = ws + o_leaves[l];
+    const size_t nd = digests_count(rows, p->cap_height);
+    u64* dig = nd ? ws + o_dig[l] : nullptr;
+    // values on the coset shift * <w>, already in the bit-reversed order the leaves are chunked in
+    P2MT_TRY(p2mt::coset_lde_leaf_order_dev(cur, log_deg, p->rate_bits, shift, 2, vals));
+    hipLaunchKernelGGL(k_fri_pairs, dim3(grid_for(sz)), dim3(kBlock), 0, st, (const u64*)vals, (u32)sz, leaves);
+    P2MT_LAUNCH_CHECK();
+    P2MT_TRY(p2mt_merkle_cap_commit_dev(leaves, rows, (size_t)2 << ab, p->cap_height, dig, d_proof + l * cap_words));
+    P2MT_TRY(launch_challenger(ch->d, d_proof + l * cap_words, cap_words, ws + o_betas + 2 * l, 2));
+    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for((size_t)1 << (log_deg - ab))), dim3(kBlock), 0, st, (const u64*)cur, 1u << log_deg,
+                       ab, (const u64*)(ws + o_betas + 2 * l), nxt);
+    P2MT_LAUNCH_CHECK();
+    idx_shift += ab;
+    qa.t[qa.n_trees++] = QTree{leaves, dig, (u32)(2u << ab), log_sz - ab, idx_shift, log_sz - ab - p->cap_height};
+    u64* t = cur; cur = nxt; nxt = t;
+    shift = h_pow(shift, (u64)1 << ab);
+    log_sz -= ab;
+    log_deg -= ab;
+  }
+  // final polynomial -> proof words, observe
+  hipLaunchKernelGGL(k_fri_pairs, dim3(grid_for(final_len)), dim3(kBlock), 0, st, (const u64*)cur, (u32)final_len, d_proof + off_final);
+  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(launch_challenger(ch->d, d_proof + off_final, 2 * final_len, nullptr, 0));
+
+  // ---- fri_proof_of_work: smallest witness, searched in chunks (expected 2^proof_of_work_bits candidates)
+  {
+    unsigned long long* d_wit = reinterpret_cast<unsigned long long*>(d_proof + total - 1);
+    const u64 chunk = (u64)1 << (p->proof_of_work_bits + 2 < 18 ? 18 : p->proof_of_work_bits + 2);
+    unsigned long long found = ~0ull;
+    for (u64 base = 0; found == ~0ull; base += chunk) {
+      if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
+      P2MT_HIP(hipMemsetAsync(d_wit, 0xFF, 8, st));
+      P2MT_DISPATCH(k_fri_pow, grid_for(chunk), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit);
+      P2MT_HIP(hipMemcpyAsync(&found, d_wit, 8, hipMemcpyDeviceToHost, st));
+      P2MT_HIP(hipStreamSynchronize(st));
+    }
+  }
+  // observe the witness; pow_response + one challenge per query round
+  P2MT_TRY(launch_challenger(ch->d, d_proof + total - 1, 1, ws + o_qch, 1 + p->num_query_rounds));
+
+  // ---- fri_prover_query_rounds
+  if (p->num_query_rounds) {
+    qa.per_query = (off_final - p->num_reductions * cap_words) / p->num_query_rounds;
+    hipLaunchKernelGGL(k_fri_queries, dim3(p->num_query_rounds), dim3(kBlock), 0, st, qa, (const u64*)(ws + o_qch + 1),
+                       d_proof + p->num_reductions * cap_words);
+    P2MT_LAUNCH_CHECK();
+  }
+  P2MT_HIP(hipStreamSynchronize(st));  // h_ptrs and the caller's view of d_proof
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_fri_prove_openings(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                       size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch, uint64_t* proof_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!oracles || !proof_out || n_oracles == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
+  if (!params_ok(p)) return p2mt::fail(P2MT_EINVAL, "fri: unsupported FriParams");
+  const unsigned log_big = p->degree_bits + p->rate_bits;
+  const size_t n = (size_t)1 << p->degree_bits, big = (size_t)1 << log_big;
+  const size_t nd = digests_count(big, p->cap_height);
+  std::vector<DevBuf> bufs(3 * n_oracles + 1);
+  std::vector<p2mt_fri_oracle> dev(n_oracles);
+  std::vector<uint64_t> n_polys(n_oracles);
+  hipStream_t st = rt().stream;
+  for (size_t o = 0; o < n_oracles; ++o) {
+    const size_t k = oracles[o].n_polys;
+    if (!oracles[o].coeffs || !oracles[o].leaves || k == 0 || (nd && !oracles[o].digests)) return p2mt::fail(P2MT_EINVAL, "fri: bad oracle");
+    P2MT_TRY(bufs[3 * o].alloc(k * n * 8));
+    P2MT_TRY(bufs[3 * o + 1].alloc(k * big * 8));
+    P2MT_TRY(bufs[3 * o + 2].alloc((nd ? nd : 1) * 32));
+    P2MT_HIP(hipMemcpyAsync(bufs[3 * o].p, oracles[o].coeffs, k * n * 8, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(bufs[3 * o + 1].p, oracles[o].leaves, k * big * 8, hipMemcpyHostToDevice, st));
+    if (nd) P2MT_HIP(hipMemcpyAsync(bufs[3 * o + 2].p, oracles[o].digests, nd * 32, hipMemcpyHostToDevice, st));
+    dev[o] = p2mt_fri_oracle{bufs[3 * o].as<u64>(), bufs[3 * o + 1].as<u64>(), bufs[3 * o + 2].as<u64>(), k};
+    n_polys[o] = k;
+  }
+  const size_t total = p2mt_fri_proof_len(p, n_oracles, n_polys.data());
+  DevBuf& bp = bufs[3 * n_oracles];
+  P2MT_TRY(bp.alloc(total * 8));
+  P2MT_TRY(p2mt_fri_prove_openings_dev(dev.data(), n_oracles, batches, n_batches, p, ch, bp.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(proof_out, bp.p, total * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}

@@ -50,7 +50,7 @@ inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ul
 
 // Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
-enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchCount };
+enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
 
 // RAII: run a scope on another stream, restore the library stream afterwards
@@ -85,6 +85,10 @@ struct DevBuf {
 // launchers exported by p2mt_hash.hip to the other translation units (enqueue on rt().stream, device pointers)
 int launch_hash_rows_dev(const uint64_t* d_in, size_t n, size_t len, int noop_short, uint64_t* d_out);
 int launch_merkle_level_dev(const uint64_t* d_in, uint64_t* d_out, size_t n_out);
+// exported by p2mt_commit.hip: x2^rate_bits coset LDE (log_n <= 12) into leaf order, poly-major:
+// d_out[p][brev(i)] = f_p(shift * w_N^i)
+int coset_lde_leaf_order_dev(const uint64_t* d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift, size_t n_polys,
+                             uint64_t* d_out);
 
 }  // namespace p2mt
 

@@ -112,13 +112,11 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 // are unrolled with the lane's round constants preloaded, so a node takes ~3.5k instructions instead of ~28k.
 // Used for levels of <= 2^12 nodes; bit-identical to the lane-per-hash kernels.  Exact arithmetic (no sticky flag):
 // a flagged wave redoing its node serially would set the duration of the whole (latency-bound) launch.
-// out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
-GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
-                            const PermCtx& ctx) {
+// One permutation by the calling wave (all 64 lanes must call it): lane w < 12 passes state word w (any u64) and
+// receives word w of the permuted state (loose u64, exact); lanes >= 12 shadow lane 0 and their result is unused.
+GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
   const unsigned lane = threadIdx.x & 63;
-  const unsigned w = lane < 12 ? lane : 0;  // lanes >= 12 shadow lane 0 (results unused)
-
-  u64 x = lane < 4 ? lp[lane] : (lane < 8 ? rp[lane - 4] : 0);
+  const unsigned w = lane < 12 ? lane : 0;
   u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
 #pragma unroll
   for (int c = 0; c < 12; ++c) kk[c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - w) % 12] + ((w == 0 && c == 0) ? 8u : 0u);
@@ -151,6 +149,15 @@ GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ 
     round(full, true, c_fold);
   }
   round(true, false, 0);
+  return x;
+}
+
+// out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
+GL_DEV void two_to_one_wave(const u64* __restrict__ lp, const u64* __restrict__ rp, u64* __restrict__ out,
+                            const PermCtx& ctx) {
+  const unsigned lane = threadIdx.x & 63;
+  u64 x = lane < 4 ? lp[lane] : (lane < 8 ? rp[lane - 4] : 0);
+  x = permute_wave(x, ctx);
   if (lane < 4) out[lane] = gl::canon(x);
 }
 

@@ -35,6 +35,39 @@ def _arr(x, shape=None):
     return a
 
 
+# ---- plonky2 FRI structures (oracle/oracle.h)
+class FriParams(C.Structure):
+    _fields_ = [("degree_bits", C.c_uint32), ("rate_bits", C.c_uint32), ("cap_height", C.c_uint32),
+                ("proof_of_work_bits", C.c_uint32), ("num_query_rounds", C.c_uint32), ("num_reductions", C.c_uint32),
+                ("reduction_arity_bits", C.c_uint32 * 8)]
+
+
+class FriOracle(C.Structure):
+    _fields_ = [("coeffs", _u64p), ("leaves", _u64p), ("digests", _u64p), ("n_polys", C.c_uint64)]
+
+
+class FriBatch(C.Structure):
+    _fields_ = [("point", C.c_uint64 * 2), ("polys", C.POINTER(C.c_uint32)), ("n_polys", C.c_uint64)]
+
+
+class ChallengerState(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("inp", C.c_uint64 * 8), ("out", C.c_uint64 * 8), ("n_in", C.c_uint32),
+                ("n_out", C.c_uint32)]
+
+
+def make_fri_batches(batch_cls, batches):
+    """batches: [(point(2,), [(oracle_index, poly_index), ...]), ...] -> (ctypes array, keep-alive list)"""
+    arr = (batch_cls * len(batches))()
+    keep = []
+    for i, (point, polys) in enumerate(batches):
+        pl = np.ascontiguousarray(np.asarray(polys, dtype=np.uint32).reshape(-1, 2))
+        keep.append(pl)
+        arr[i].point[0], arr[i].point[1] = int(point[0]), int(point[1])
+        arr[i].polys = pl.ctypes.data_as(C.POINTER(C.c_uint32))
+        arr[i].n_polys = pl.shape[0]
+    return arr, keep
+
+
 class Oracle:
     def __init__(self):
         self.lib = lib = C.CDLL(build_oracle())
@@ -79,6 +112,20 @@ class Oracle:
         lib.oracle_merkle_cap_commit.argtypes = [_u64p, C.c_size_t, C.c_size_t, C.c_uint, _u64p, _u64p]
         lib.oracle_polynomial_batch_commit.argtypes = [_u64p, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint,
                                                        _u64p, _u64p, _u64p]
+        lib.oracle_challenger_init.argtypes = [C.POINTER(ChallengerState)]
+        lib.oracle_challenger_observe.argtypes = [C.POINTER(ChallengerState), _u64p, C.c_size_t]
+        lib.oracle_challenger_get.argtypes = [C.POINTER(ChallengerState)]
+        lib.oracle_challenger_get.restype = C.c_uint64
+        lib.oracle_ext_mul.argtypes = [_u64p, _u64p, _u64p]
+        lib.oracle_ext_inv.argtypes = [_u64p, _u64p]
+        lib.oracle_fri_params_standard.argtypes = [C.c_uint, C.POINTER(FriParams)]
+        lib.oracle_fri_proof_len.argtypes = [C.POINTER(FriParams), C.c_size_t, _u64p]
+        lib.oracle_fri_proof_len.restype = C.c_size_t
+        lib.oracle_eval_polys_ext.argtypes = [_u64p, C.c_size_t, C.c_uint, _u64p, _u64p]
+        lib.oracle_fri_prove.argtypes = [C.POINTER(FriOracle), C.c_size_t, C.POINTER(FriBatch), C.c_size_t,
+                                         C.POINTER(FriParams), C.POINTER(ChallengerState), _u64p]
+        lib.oracle_fri_verify.argtypes = [_u64p, C.c_size_t, _u64p, C.POINTER(FriBatch), C.c_size_t, _u64p,
+                                          C.POINTER(FriParams), C.POINTER(ChallengerState), _u64p, C.POINTER(C.c_int)]
 
     # ---- field
     def mul(self, a, b): return self.lib.oracle_gl_mul(a, b)
@@ -228,6 +275,93 @@ class Oracle:
         if rc < 0:
             raise ValueError("bad polynomial_batch_commit shape")
         return leaves, digests[:n_dig], cap
+
+    # ---- challenger / FRI (oracle/fri.c)
+    def challenger(self):
+        return OracleChallenger(self)
+
+    def ext_mul(self, x, y):
+        x, y, out = _arr(x), _arr(y), np.zeros(2, np.uint64)
+        self.lib.oracle_ext_mul(_ptr(x), _ptr(y), _ptr(out))
+        return out
+
+    def ext_inv(self, x):
+        x, out = _arr(x), np.zeros(2, np.uint64)
+        self.lib.oracle_ext_inv(_ptr(x), _ptr(out))
+        return out
+
+    def fri_params_standard(self, degree_bits, **override):
+        p = FriParams()
+        self.lib.oracle_fri_params_standard(degree_bits, C.byref(p))
+        for k, v in override.items():
+            if k == "reduction_arity_bits":
+                p.num_reductions = len(v)
+                for i, a in enumerate(v):
+                    p.reduction_arity_bits[i] = a
+            else:
+                setattr(p, k, v)
+        return p
+
+    def fri_proof_len(self, params, n_polys):
+        n_polys = _arr(n_polys)
+        return self.lib.oracle_fri_proof_len(C.byref(params), n_polys.size, _ptr(n_polys))
+
+    def eval_polys_ext(self, coeffs, point):
+        coeffs, point = _arr(coeffs), _arr(point)
+        n_polys, n = coeffs.shape
+        out = np.zeros((n_polys, 2), np.uint64)
+        self.lib.oracle_eval_polys_ext(_ptr(coeffs), n_polys, n.bit_length() - 1, _ptr(point), _ptr(out))
+        return out
+
+    def fri_prove(self, oracles, batches, params, challenger):
+        """oracles: [(coeffs (n_polys, n), leaves (N, n_polys), digests (nd, 4)), ...]"""
+        arr = (FriOracle * len(oracles))()
+        keep = []
+        for i, (coeffs, leaves, digests) in enumerate(oracles):
+            c, l, d = _arr(coeffs), _arr(leaves), _arr(digests)
+            keep += [c, l, d]
+            arr[i].coeffs, arr[i].leaves, arr[i].digests, arr[i].n_polys = _ptr(c), _ptr(l), _ptr(d), c.shape[0]
+        barr, keep2 = make_fri_batches(FriBatch, batches)
+        proof = np.zeros(self.fri_proof_len(params, [o[0].shape[0] for o in oracles]), np.uint64)
+        rc = self.lib.oracle_fri_prove(arr, len(oracles), barr, len(batches), C.byref(params), C.byref(challenger.st),
+                                       _ptr(proof))
+        if rc != 0:
+            raise ValueError("oracle_fri_prove: status %d" % rc)
+        return proof
+
+    def fri_verify(self, n_polys, caps, batches, openings, params, challenger, proof):
+        """-> (accepted: bool, reason: int)"""
+        n_polys, caps, proof = _arr(n_polys), _arr(caps), _arr(proof)
+        openings = _arr(np.concatenate([np.asarray(o, np.uint64).reshape(-1) for o in openings]))
+        barr, keep = make_fri_batches(FriBatch, batches)
+        reason = C.c_int(0)
+        rc = self.lib.oracle_fri_verify(_ptr(n_polys), n_polys.size, _ptr(caps), barr, len(batches), _ptr(openings),
+                                        C.byref(params), C.byref(challenger.st), _ptr(proof), C.byref(reason))
+        if rc < 0:
+            raise ValueError("oracle_fri_verify: malformed arguments")
+        return bool(rc), reason.value
+
+
+class OracleChallenger:
+    def __init__(self, oracle):
+        self.o = oracle
+        self.st = ChallengerState()
+        oracle.lib.oracle_challenger_init(C.byref(self.st))
+
+    def clone(self):
+        c = OracleChallenger(self.o)
+        C.memmove(C.byref(c.st), C.byref(self.st), C.sizeof(ChallengerState))
+        return c
+
+    def observe(self, elements):
+        e = _arr(elements).reshape(-1)
+        self.o.lib.oracle_challenger_observe(C.byref(self.st), _ptr(e), e.size)
+
+    def get_challenge(self):
+        return self.o.lib.oracle_challenger_get(C.byref(self.st))
+
+    def get_n_challenges(self, n):
+        return np.array([self.get_challenge() for _ in range(n)], np.uint64)
 
 
 class OracleMMR:
