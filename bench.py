@@ -254,6 +254,100 @@ def run_commit(args, torch, pkg, lib):
             "details": res}
 
 
+def run_fri(args, torch, pkg, lib):
+    """Secondary metric (ms/proof, opening proof only): PolynomialBatch::prove_openings -> fri_proof over the four
+    committed oracles of one prove (constants_sigmas 84, wires 135, Z/partial products 20, quotient chunks 16) at the
+    outer-circuit shape of config 4 (d = 12) and at config 3's (d = 6), standard_recursion_config FRI parameters
+    (16-bit proof of work, 28 queries).  Oracles are committed beforehand and stay device-resident.  NOT a full plonky2
+    prove (no witness generation / quotient evaluation); the polynomials are synthetic."""
+    from plonky2_merkle_trees_amd import fri as F
+    Nn = pkg._native
+    res = {}
+    for name, log_n in (("config4_outer_d12", 12), ("config3_d6", 6)):
+        n, big = 1 << log_n, 1 << (log_n + 3)
+        widths = [84, 135, 20, 16]
+        rng = np.random.default_rng(11)
+        params = F.FriParams.standard(log_n)
+        hosts, dev = [], []
+        oarr = (F._FriOracle * len(widths))()
+        nd = sum(big >> j for j in range(log_n + 3 - 4))
+        for i, w in enumerate(widths):
+            host = rng.integers(0, pkg.GOLDILOCKS_FIELD_ORDER, size=(w, n), dtype=np.uint64)
+            d_c = torch.from_numpy(host.view(np.int64)).cuda()
+            d_l = torch.zeros(big * w, dtype=torch.int64, device="cuda")
+            d_d = torch.zeros(max(nd, 1) * 4, dtype=torch.int64, device="cuda")
+            d_cap = torch.zeros(64, dtype=torch.int64, device="cuda")
+            Nn.check(lib.p2mt_polynomial_batch_commit_dev(Nn.ptr(d_c), 0, w, log_n, 3, 4, Nn.ptr(d_l), Nn.ptr(d_d),
+                                                          Nn.ptr(d_cap)))
+            hosts.append(host)
+            dev.append((d_c, d_l, d_d, d_cap))
+            oarr[i].coeffs = C.cast(d_c.data_ptr(), Nn.u64p)
+            oarr[i].leaves = C.cast(d_l.data_ptr(), Nn.u64p)
+            oarr[i].digests = C.cast(d_d.data_ptr(), Nn.u64p)
+            oarr[i].n_polys = w
+        torch.cuda.synchronize()
+        zeta = rng.integers(0, pkg.GOLDILOCKS_FIELD_ORDER, size=2, dtype=np.uint64)
+        all_polys = np.array([(oi, pi) for oi, w in enumerate(widths) for pi in range(w)], np.uint32)
+        nxt = np.array([(2, 0), (2, 1)], np.uint32)
+        barr = (F._FriBatch * 2)()
+        for b, (pt, pl) in enumerate(((zeta, all_polys), (zeta[::-1].copy(), nxt))):
+            barr[b].point[0], barr[b].point[1] = int(pt[0]), int(pt[1])
+            barr[b].polys = pl.ctypes.data_as(C.POINTER(C.c_uint32))
+            barr[b].n_polys = pl.shape[0]
+        total = F.fri_proof_len(params, widths)
+        d_proof = torch.zeros(total, dtype=torch.int64, device="cuda")
+        ch = F.Challenger()
+        ch.observe_elements(np.arange(1, 20, dtype=np.uint64))
+        st0 = ch.state()
+        d_open = torch.zeros(2 * (sum(widths) + 2), dtype=torch.int64, device="cuda")
+
+        def openings():  # OpeningSet: every polynomial at zeta, the Zs at g*zeta
+            Nn.check(lib.p2mt_fri_openings_dev(C.addressof(oarr), len(widths), C.addressof(barr), 2, log_n,
+                                               Nn.ptr(d_open)))
+
+        def one():
+            ch.set_state(st0)
+            openings()
+            Nn.check(lib.p2mt_fri_prove_openings_dev(C.addressof(oarr), len(widths), C.addressof(barr), 2,
+                                                     C.addressof(params), ch._h, Nn.ptr(d_proof)))
+
+        for _ in range(args.warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        entry = {"ms_per_opening_proof": ms, "proof_words": int(total), "pow_witness": int(d_proof[-1].item())}
+        if not args.no_cpu_baseline and log_n <= 12:
+            from oracle_lib import Oracle
+            o = Oracle()
+            op = o.fri_params_standard(log_n)
+            ooracles = [(h, d_l.cpu().numpy().view(np.uint64).reshape(big, w), d_d.cpu().numpy().view(np.uint64).reshape(-1, 4))
+                        for h, (_, d_l, d_d, _), w in zip(hosts, dev, widths)]
+            och = o.challenger()
+            och.observe(np.arange(1, 20, dtype=np.uint64))
+            batches = [(zeta, all_polys), (zeta[::-1].copy(), nxt)]
+            t0 = time.perf_counter()
+            want = o.fri_prove(ooracles, batches, op, och)
+            entry["cpu_port_ms_1core"] = (time.perf_counter() - t0) * 1e3
+            got = d_proof.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want), "GPU FRI proof != oracle proof"
+        res[name] = entry
+    main = res["config4_outer_d12"]
+    return {"metric": "ms/proof, opening proof only (openings + FRI over 84/135/20/16 polys, 2^12 -> 2^15, 28 queries, PoW 16)",
+            "value": main["ms_per_opening_proof"], "unit": "ms", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main["ms_per_opening_proof"], "higher_is_better": False,
+            "scaling": "replicas only", "vs_baseline": None, "dtype": "u64 (Goldilocks + quadratic extension)",
+            "data": "synthetic",
+            "config": {"workload": "PolynomialBatch::prove_openings of mmr_plonky2_verifier_1_recursion outer prove "
+                                   "(synthetic polynomials); NOT a full plonky2 prove"},
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                         "note": "a chain of ~40 dependent small launches; see profiles/ for the per-kernel split"},
+            "details": res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,7 +355,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-leaves", type=int, default=24, help="leaves per GPU = 2^this")
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
-    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit"])
+    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --single-device exist only to exercise the N>1 code "
@@ -296,6 +390,8 @@ def main():
     lib = pkg.lib()
     if args.workload == "commit":
         out = run_commit(args, torch, pkg, lib) if rank == 0 else None
+    elif args.workload == "fri":
+        out = run_fri(args, torch, pkg, lib) if rank == 0 else None
     else:
         out = run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist)
     if rank == 0 and out is not None:

@@ -261,6 +261,13 @@ typedef struct p2mt_fri_batch {
   const uint32_t *polys; /* host memory, 2 * n_polys entries */
   uint64_t n_polys;
 } p2mt_fri_batch;
+/* FriOpenings (OpeningSet::to_fri_openings): the value of every batch's polynomials at the batch's point, in batch
+ * order, 2 words each -- what the challenger observes before prove_openings and what the verifier is given.
+ * Only `coeffs` and `n_polys` of the oracles are read.  One launch for the whole set. */
+int p2mt_fri_openings(const p2mt_fri_oracle *oracles, size_t n_oracles, const p2mt_fri_batch *batches,
+                      size_t n_batches, unsigned degree_bits, uint64_t *out /*[sum n_polys][2]*/);
+int p2mt_fri_openings_dev(const p2mt_fri_oracle *d_oracles, size_t n_oracles, const p2mt_fri_batch *batches,
+                          size_t n_batches, unsigned degree_bits, uint64_t *d_out);
 /* FriProof as words, plonky2's serialisation order:
  *   commit_phase_merkle_caps [num_reductions][2^cap_height][4]
  *   query_round_proofs [num_query_rounds] x { per oracle: leaf row [n_polys] | siblings [log N - cap_height][4];

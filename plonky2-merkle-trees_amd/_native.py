@@ -102,6 +102,8 @@ SIGNATURES = {
     "p2mt_challenger_set_state": (C.c_int, [voidp, voidp]),
     "p2mt_eval_polys_ext": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_eval_polys_ext_dev": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
+    "p2mt_fri_openings": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, C.c_uint, voidp]),
+    "p2mt_fri_openings_dev": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, C.c_uint, voidp]),
     "p2mt_fri_params_standard": (C.c_int, [C.c_uint, voidp]),
     "p2mt_fri_proof_len": (C.c_size_t, [voidp, C.c_size_t, voidp]),
     "p2mt_fri_prove_openings": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, voidp, voidp]),

@@ -302,6 +302,33 @@ __global__ __launch_bounds__(kBlock) void k_eval_ext(const u64* __restrict__ coe
   }
 }
 
+// The same for a table of polynomials with a point each (FriOpenings in one launch): entry = {coeff pointer, za, zb, -}
+struct EvalEntry {
+  const u64* coeffs;
+  u64 za, zb, pad;
+};
+__global__ __launch_bounds__(kBlock) void k_eval_ext_table(const EvalEntry* __restrict__ tab, u32 log_n, u64* __restrict__ out) {
+  __shared__ Ext S[kBlock];
+  const u32 n = 1u << log_n, len = n >= (u32)kBlock ? n / kBlock : 1, T = n / len, t = threadIdx.x;
+  const u64* c = tab[blockIdx.x].coeffs;
+  const Ext z{tab[blockIdx.x].za, tab[blockIdx.x].zb};
+  Ext loc{0, 0};
+  if (t < T)
+    for (u32 m = (t + 1) * len; m-- > t * len;) loc = ext_mul_add_base(loc, z, c[m]);
+  S[t] = loc;
+  __syncthreads();
+  Ext zp = ext_pow(z, len);
+  for (u32 d = 1; d < T; d *= 2) {
+    if ((t & (2 * d - 1)) == 0 && t + d < T) S[t] = ext_add(S[t], ext_mul(zp, S[t + d]));
+    __syncthreads();
+    zp = ext_mul(zp, zp);
+  }
+  if (t == 0) {
+    out[2 * blockIdx.x] = gl::canon(S[0].a);
+    out[2 * blockIdx.x + 1] = gl::canon(S[0].b);
+  }
+}
+
 // ---------------------------------------------------------------- host helpers
 inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
 inline u64 h_pow(u64 a, u64 e) {
@@ -473,6 +500,56 @@ extern "C" int p2mt_eval_polys_ext(const uint64_t* coeffs, size_t n_polys, unsig
   return P2MT_OK;
 }
 
+// FriOpenings: every batch's polynomials at the batch's point, batches concatenated, one launch
+extern "C" int p2mt_fri_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                     size_t n_batches, unsigned degree_bits, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!oracles || !batches || !d_out || n_oracles == 0 || degree_bits > 24) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
+  std::vector<EvalEntry> tab;
+  for (size_t b = 0; b < n_batches; ++b) {
+    if (batches[b].n_polys && !batches[b].polys) return p2mt::fail(P2MT_EINVAL, "fri_openings: null batch");
+    for (size_t j = 0; j < batches[b].n_polys; ++j) {
+      const uint32_t o = batches[b].polys[2 * j], pi = batches[b].polys[2 * j + 1];
+      if (o >= n_oracles || !oracles[o].coeffs || pi >= oracles[o].n_polys)
+        return p2mt::fail(P2MT_EINVAL, "fri_openings: batch polynomial index out of range");
+      tab.push_back(EvalEntry{oracles[o].coeffs + ((size_t)pi << degree_bits), batches[b].point[0] % gl::P,
+                              batches[b].point[1] % gl::P, 0});
+    }
+  }
+  if (tab.empty()) return P2MT_OK;
+  EvalEntry* d_tab;
+  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchTmp, tab.size() * sizeof(EvalEntry), (void**)&d_tab));
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(EvalEntry), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_eval_ext_table, dim3((unsigned)tab.size()), dim3(kBlock), 0, st, (const EvalEntry*)d_tab, degree_bits, d_out);
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipStreamSynchronize(st));  // `tab` is pageable host memory
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_fri_openings(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                 size_t n_batches, unsigned degree_bits, uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!oracles || !batches || !out || n_oracles == 0 || degree_bits > 24) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
+  std::vector<DevBuf> bufs(n_oracles + 1);
+  std::vector<p2mt_fri_oracle> dev(n_oracles);
+  size_t total = 0;
+  for (size_t b = 0; b < n_batches; ++b) total += batches[b].n_polys;
+  hipStream_t st = rt().stream;
+  for (size_t o = 0; o < n_oracles; ++o) {
+    if (!oracles[o].coeffs || oracles[o].n_polys == 0) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad oracle");
+    const size_t bytes = (oracles[o].n_polys << degree_bits) * 8;
+    P2MT_TRY(bufs[o].alloc(bytes));
+    P2MT_HIP(hipMemcpyAsync(bufs[o].p, oracles[o].coeffs, bytes, hipMemcpyHostToDevice, st));
+    dev[o] = p2mt_fri_oracle{bufs[o].as<u64>(), nullptr, nullptr, oracles[o].n_polys};
+  }
+  P2MT_TRY(bufs[n_oracles].alloc(total * 16));
+  P2MT_TRY(p2mt_fri_openings_dev(dev.data(), n_oracles, batches, n_batches, degree_bits, bufs[n_oracles].as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(out, bufs[n_oracles].p, total * 16, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+}
+
 // =================================================================== FRI
 extern "C" int p2mt_fri_params_standard(unsigned degree_bits, p2mt_fri_params* out) {
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -635,7 +712,7 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
   // ---- fri_proof_of_work: smallest witness, searched in chunks (expected 2^proof_of_work_bits candidates)
   {
     unsigned long long* d_wit = reinterpret_cast<unsigned long long*>(d_proof + total - 1);
-    const u64 chunk = (u64)1 << (p->proof_of_work_bits + 2 < 18 ? 18 : p->proof_of_work_bits + 2);
+    const u64 chunk = (u64)1 << (p->proof_of_work_bits + 1 < 17 ? 17 : p->proof_of_work_bits + 1);  // P(found) = 1 - e^-2 per launch
     unsigned long long found = ~0ull;
     for (u64 base = 0; found == ~0ull; base += chunk) {
       if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");

@@ -60,6 +60,28 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in
   store_hash(out + 4 * i, o);
 }
 
+// Same rows, one wavefront per row (latency path for small batches, e.g. the 2^7..2^11 leaves of a FRI layer tree):
+// the sponge's permutations are sequential, so a row costs len/8 wave-permutation latencies (~8 us each) instead of
+// len/8 single-lane ones (~60 us each).
+__global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
+                                                           u64* __restrict__ out, PermCtx ctx) {
+  const size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;  // wave-uniform
+  const unsigned lane = threadIdx.x & 63;
+  const u64* r = in + row * len;
+  if (noop_short && len <= 4) {
+    if (lane < 4) out[4 * row + lane] = lane < len ? gl::canon(r[lane]) : 0;
+    return;
+  }
+  u64 x = 0;
+#pragma unroll 1
+  for (size_t off = 0; off < len; off += 8) {
+    if (lane < 8 && off + lane < len) x = r[off + lane];  // overwrite mode: the other words keep the previous state
+    x = permute_wave(x, ctx);
+  }
+  if (lane < 4) out[4 * row + lane] = gl::canon(x);
+}
+
 // ---------------------------------------------------------------- PoseidonGate witness rows
 // One row per lane, exact spec-form arithmetic (this is a throughput kernel for batches of proofs; a single proof's
 // rows form a dependent chain and belong on the host).  Stores are wire-major, so consecutive lanes write
@@ -190,6 +212,13 @@ namespace p2mt {
 // exported to the other translation units
 int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, u64* d_out) {
   if (n == 0) return P2MT_OK;
+  if (n <= ((size_t)1 << 12) && rt().mds == 2) {  // small batch: one wavefront per row (latency path)
+    const unsigned per_block = kBlock / 64;
+    hipLaunchKernelGGL(k_hash_rows_wave, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
+                       d_in, n, len, noop_short, d_out, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
   P2MT_DISPATCH(k_hash_rows, grid_for(n), kBlock, d_in, n, len, noop_short, d_out);
   return P2MT_OK;
 }

@@ -105,6 +105,39 @@ def fri_proof_len(params, n_polys):
     return N.lib().p2mt_fri_proof_len(C.addressof(params), a.size, N.ptr(a))
 
 
+def _batch_array(batches, keep):
+    barr = (_FriBatch * len(batches))()
+    for i, (point, polys) in enumerate(batches):
+        pl = np.ascontiguousarray(np.asarray(polys, dtype=np.uint32).reshape(-1, 2))
+        keep.append(pl)
+        barr[i].point[0], barr[i].point[1] = int(point[0]), int(point[1])
+        barr[i].polys = pl.ctypes.data_as(C.POINTER(C.c_uint32))
+        barr[i].n_polys = pl.shape[0]
+    return barr
+
+
+def openings(batches, oracles):
+    """OpeningSet::to_fri_openings: per batch an (n_polys, 2) array of the polynomials' values at the batch's point."""
+    arr = (_FriOracle * len(oracles))()
+    keep = []
+    degree_bits = None
+    for i, o in enumerate(oracles):
+        c = N.as_u64(o.polynomials)
+        keep.append(c)
+        arr[i].coeffs, arr[i].n_polys = c.ctypes.data_as(N.u64p), o.n_polys
+        degree_bits = o.degree_log
+    barr = _batch_array(batches, keep)
+    total = sum(len(pl) for _, pl in batches)
+    out = np.zeros((total, 2), np.uint64)
+    N.check(N.lib().p2mt_fri_openings(C.addressof(arr), len(oracles), C.addressof(barr), len(batches), degree_bits,
+                                      N.ptr(out)))
+    res, off = [], 0
+    for _, pl in batches:
+        res.append(out[off:off + len(pl)])
+        off += len(pl)
+    return res
+
+
 def prove_openings(batches, oracles, challenger, params):
     """PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params).
 
@@ -122,13 +155,7 @@ def prove_openings(batches, oracles, challenger, params):
         keep += [c, l, d]
         arr[i].coeffs, arr[i].leaves, arr[i].digests = (x.ctypes.data_as(N.u64p) for x in (c, l, d))
         arr[i].n_polys = o.n_polys
-    barr = (_FriBatch * len(batches))()
-    for i, (point, polys) in enumerate(batches):
-        pl = np.ascontiguousarray(np.asarray(polys, dtype=np.uint32).reshape(-1, 2))
-        keep.append(pl)
-        barr[i].point[0], barr[i].point[1] = int(point[0]), int(point[1])
-        barr[i].polys = pl.ctypes.data_as(C.POINTER(C.c_uint32))
-        barr[i].n_polys = pl.shape[0]
+    barr = _batch_array(batches, keep)
     total = fri_proof_len(params, [o.n_polys for o in oracles])
     if total == 0:
         raise N.P2mtPanic(N.P2MT_EINVAL, "unsupported FriParams")

@@ -87,6 +87,8 @@ def run_case(pkg, oracle, degree_bits, n_polys, over, seed, pow_bits=6):
     for go, (c, leaves, dig) in zip(goracles, ooracles):
         assert np.array_equal(go.merkle_tree.leaves, leaves) and np.array_equal(go.merkle_tree.digests, dig)
     openings = openings_of(oracle, coeffs, batches)
+    for g_open, o_open in zip(pkg.fri.openings(batches, goracles), openings):
+        assert np.array_equal(g_open, o_open)
     och, gch = oracle.challenger(), pkg.Challenger()
     for ch_observe in (och.observe, gch.observe_elements):
         ch_observe(caps.reshape(-1))
