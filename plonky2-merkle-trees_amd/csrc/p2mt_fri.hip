@@ -138,6 +138,32 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ 
   if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
 }
 
+// The same grind with four lanes per candidate (poseidon_quad.hip.h): a third of the single-hash latency, which is what
+// bounds a 2^17-candidate launch.
+__global__ __launch_bounds__(kBlock) void k_fri_pow_quad(const ChState* __restrict__ st, u32 pow_bits, u64 base, u64 count,
+                                                         unsigned long long* __restrict__ result, PermCtx ctx) {
+  const u64 gid = ((u64)blockIdx.x * kBlock + threadIdx.x) >> 2;
+  if (gid >= count) return;  // quad-uniform
+  poseidon_quad::Lane ln;
+  poseidon_quad::lane_init(ln, ctx.rc);
+  const u64 cand = base + gid;
+  const u32 n_in = st->n_in;
+  u64 x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const u32 w = 3 * ln.q + i;
+    u64 v = st->state[w];
+    if (w < n_in) v = st->in[w];
+    else if (w == n_in) v = cand;  // n_in < 8
+    x[i] = v;
+  }
+  poseidon_quad::permute(x, ln);
+  if (ln.q == 2) {  // word 7
+    const u64 resp = gl::canon(x[1]);
+    if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
+  }
+}
+
 // ---------------------------------------------------------------- alpha-composition
 // table[j] = base^j, j < count (canonical pairs)
 __global__ __launch_bounds__(kBlock) void k_ext_powers(const u64* __restrict__ base, u32 count, u64* __restrict__ table) {
@@ -171,53 +197,64 @@ __global__ __launch_bounds__(kBlock) void k_fri_compose(const u64* const* __rest
 //   b_n = 0, b_m = b_{m+1} z + c_m, quotient coefficient m = b_{m+1};  fin[m] = fin[m] * alpha^cnt + b_{m+1}.
 // The recurrence is a suffix scan: each thread reduces its chunk to one value, a log-step scan over the chunk values
 // gives every chunk its carry-in, then the chunk is replayed.
-__global__ __launch_bounds__(kBlock) void k_fri_quotient(const u64* __restrict__ partial, u32 n_groups, u32 n, u64 za, u64 zb,
-                                                         const u64* __restrict__ alpha, u32 cnt, int first,
-                                                         u64* __restrict__ fin) {
-  __shared__ Ext S[kBlock];
-  const u32 len = n >= (u32)kBlock ? n / kBlock : 1, T = n / len, t = threadIdx.x;
+constexpr int kQBlock = 1024, kQMaxLen = 4;  // n <= 2^12 coefficients: at most 4 per thread, kept in registers
+struct ZPows {  // z^(len 2^k), k < 10: the scan's multipliers, computed on the host (z is a host value)
+  u64 v[20];
+};
+__global__ __launch_bounds__(kQBlock) void k_fri_quotient(const u64* __restrict__ partial, u32 n_groups, u32 n, u64 za, u64 zb,
+                                                          ZPows zpw, const u64* __restrict__ apow_cnt, int first,
+                                                          u64* __restrict__ fin, u64* __restrict__ shifted) {
+  __shared__ Ext S[kQBlock];
+  const u32 len = n >= (u32)kQBlock ? n / kQBlock : 1, T = n / len, t = threadIdx.x;
   const Ext z{za, zb};
-  const u32 s = t * len, e = s + len;
-  auto coeff = [&](u32 m) {
-    Ext c{0, 0};
-    for (u32 g = 0; g < n_groups; ++g) {
-      c.a = gl::add(c.a, partial[((size_t)g * 2) * n + m]);
-      c.b = gl::add(c.b, partial[((size_t)g * 2 + 1) * n + m]);
-    }
-    return c;
-  };
+  const u32 s = t * len;
+  Ext c[kQMaxLen];  // this thread's composition coefficients (partial sums added up)
+#pragma unroll
+  for (int i = 0; i < kQMaxLen; ++i) {
+    c[i] = Ext{0, 0};
+    if (t < T && (u32)i < len)
+      for (u32 g = 0; g < n_groups; ++g) {
+        c[i].a = gl::add(c[i].a, partial[((size_t)g * 2) * n + s + i]);
+        c[i].b = gl::add(c[i].b, partial[((size_t)g * 2 + 1) * n + s + i]);
+      }
+  }
   Ext loc{0, 0};
-  if (t < T)
-    for (u32 m = e; m-- > s;) loc = ext_add(ext_mul(loc, z), coeff(m));
+#pragma unroll
+  for (int i = kQMaxLen - 1; i >= 0; --i)
+    if ((u32)i < len) loc = ext_add(ext_mul(loc, z), c[i]);
   S[t] = loc;
   __syncthreads();
-  Ext zp = ext_pow(z, len);
-  for (u32 d = 1; d < T; d *= 2) {
+  u32 k = 0;
+  for (u32 d = 1; d < T; d *= 2, ++k) {
     Ext v = S[t];
-    if (t + d < T) v = ext_add(v, ext_mul(zp, S[t + d]));
+    if (t + d < T) v = ext_add(v, ext_mul(Ext{zpw.v[2 * k], zpw.v[2 * k + 1]}, S[t + d]));
     __syncthreads();
     S[t] = v;
     __syncthreads();
-    zp = ext_mul(zp, zp);
   }
   if (t >= T) return;
   Ext acc = t + 1 < T ? S[t + 1] : Ext{0, 0};  // b at the end of this chunk
-  const Ext sh = first ? Ext{0, 0} : ext_pow(Ext{alpha[0], alpha[1]}, cnt);
-  for (u32 m = e; m-- > s;) {
+  const Ext sh = first ? Ext{0, 0} : Ext{apow_cnt[0], apow_cnt[1]};  // alpha^cnt (ReducingFactor::shift_poly)
+#pragma unroll
+  for (int i = kQMaxLen - 1; i >= 0; --i) {
+    if ((u32)i >= len) continue;
+    const u32 m = s + i;
     Ext q = acc;
     if (!first) q = ext_add(q, ext_mul(Ext{fin[m], fin[n + m]}, sh));
-    fin[m] = gl::canon(q.a);
-    fin[n + m] = gl::canon(q.b);
-    acc = ext_add(ext_mul(acc, z), coeff(m));
+    q.a = gl::canon(q.a);
+    q.b = gl::canon(q.b);
+    if (shifted) {  // last batch: coeffs.insert(0, ZERO) (plonky2 PR 436); coefficient n-1 of the sum is zero by construction
+      if (m + 1 < n) {
+        shifted[m + 1] = q.a;
+        shifted[n + m + 1] = q.b;
+      }
+      if (m == 0) shifted[0] = shifted[n] = 0;
+    } else {
+      fin[m] = q.a;
+      fin[n + m] = q.b;
+    }
+    acc = ext_add(ext_mul(acc, z), c[i]);
   }
-}
-
-// coeffs.insert(0, ZERO) (plonky2 PR 436): out[c][0] = 0, out[c][m+1] = fin[c][m]; fin[c][n-1] is zero by construction
-__global__ __launch_bounds__(kBlock) void k_fri_mul_x(const u64* __restrict__ fin, u32 n, u64* __restrict__ out) {
-  const u32 i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= 2 * n) return;
-  const u32 m = i & (n - 1);
-  out[i] = m == 0 ? 0 : fin[i - 1];
 }
 
 // (a, b) pairs from component-major arrays: the layer's Merkle leaves (2^arity_bits consecutive pairs per row) and
@@ -336,6 +373,13 @@ inline u64 h_pow(u64 a, u64 e) {
   for (; e; e >>= 1, a = h_mul(a, a))
     if (e & 1) r = h_mul(r, a);
   return r;
+}
+inline u64 h_add(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % gl::P); }
+inline void h_ext_mul(const u64 x[2], const u64 y[2], u64 out[2]) {
+  const u64 a = h_add(h_mul(x[0], y[0]), h_mul(7, h_mul(x[1], y[1])));
+  const u64 b = h_add(h_mul(x[0], y[1]), h_mul(x[1], y[0]));
+  out[0] = a;
+  out[1] = b;
 }
 
 unsigned total_arity_bits(const p2mt_fri_params* p) {
@@ -623,8 +667,8 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
     wsz += (words + 3) & ~(size_t)3;  // 32-byte granules
     return at;
   };
-  const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds);
-  const size_t o_apow = carve(2 * max_cnt), o_ptrs = carve(total_cnt), o_partial = carve(max_groups * 2 * n);
+  const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds), o_chsave = carve(32);
+  const size_t o_apow = carve(2 * (max_cnt + 1)), o_ptrs = carve(total_cnt), o_partial = carve(max_groups * 2 * n);
   const size_t o_fin = carve(2 * (size_t)n), o_c0 = carve(2 * (size_t)n), o_c1 = carve(2 * (size_t)n);
   size_t o_vals[8], o_leaves[8], o_dig[8];
   {
@@ -643,8 +687,8 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
 
   // ---- alpha, composition, quotients
   P2MT_TRY(launch_challenger(ch->d, nullptr, 0, ws + o_alpha, 2));
-  hipLaunchKernelGGL(k_ext_powers, dim3(grid_for(max_cnt)), dim3(kBlock), 0, st, (const u64*)(ws + o_alpha), (u32)max_cnt,
-                     ws + o_apow);
+  hipLaunchKernelGGL(k_ext_powers, dim3(grid_for(max_cnt + 1)), dim3(kBlock), 0, st, (const u64*)(ws + o_alpha),
+                     (u32)max_cnt + 1, ws + o_apow);
   P2MT_LAUNCH_CHECK();
   std::vector<const u64*> h_ptrs(total_cnt);
   {
@@ -661,15 +705,24 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
       hipLaunchKernelGGL(k_fri_compose, dim3(grid_for(n), groups), dim3(kBlock), 0, st,
                          reinterpret_cast<const u64* const*>(ws + o_ptrs + k), cnt, n, (const u64*)(ws + o_apow), ws + o_partial);
       P2MT_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_fri_quotient, dim3(1), dim3(kBlock), 0, st, (const u64*)(ws + o_partial), groups, n,
-                         batches[b].point[0] % gl::P, batches[b].point[1] % gl::P, (const u64*)(ws + o_alpha), cnt, b == 0 ? 1 : 0,
-                         ws + o_fin);
+      ZPows zpw;
+      {
+        const u32 len = n >= (u32)kQBlock ? n / kQBlock : 1;
+        u64 zp[2] = {1, 0}, zz[2] = {batches[b].point[0] % gl::P, batches[b].point[1] % gl::P};
+        for (u32 i = 0; i < len; ++i) h_ext_mul(zp, zz, zp);
+        for (int kk = 0; kk < 10; ++kk) {
+          zpw.v[2 * kk] = zp[0];
+          zpw.v[2 * kk + 1] = zp[1];
+          h_ext_mul(zp, zp, zp);
+        }
+      }
+      hipLaunchKernelGGL(k_fri_quotient, dim3(1), dim3(kQBlock), 0, st, (const u64*)(ws + o_partial), groups, n,
+                         batches[b].point[0] % gl::P, batches[b].point[1] % gl::P, zpw, (const u64*)(ws + o_apow + 2 * cnt),
+                         b == 0 ? 1 : 0, ws + o_fin, b + 1 == n_batches ? ws + o_c0 : (u64*)nullptr);
       P2MT_LAUNCH_CHECK();
       k += cnt;
     }
   }
-  hipLaunchKernelGGL(k_fri_mul_x, dim3(grid_for(2 * (size_t)n)), dim3(kBlock), 0, st, (const u64*)(ws + o_fin), n, ws + o_c0);
-  P2MT_LAUNCH_CHECK();
 
   // ---- fri_committed_trees
   QArgs qa;
@@ -709,28 +762,38 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
   P2MT_LAUNCH_CHECK();
   P2MT_TRY(launch_challenger(ch->d, d_proof + off_final, 2 * final_len, nullptr, 0));
 
-  // ---- fri_proof_of_work: smallest witness, searched in chunks (expected 2^proof_of_work_bits candidates)
+  // ---- fri_proof_of_work (smallest witness, searched in chunks) + fri_prover_query_rounds.
+  // The rest of the proof is enqueued behind each chunk's grind on the assumption that it finds a witness (it does with
+  // probability 1 - e^-2); if not, the challenger is rolled back and the next chunk is tried.
   {
     unsigned long long* d_wit = reinterpret_cast<unsigned long long*>(d_proof + total - 1);
-    const u64 chunk = (u64)1 << (p->proof_of_work_bits + 1 < 17 ? 17 : p->proof_of_work_bits + 1);  // P(found) = 1 - e^-2 per launch
+    ChState* d_saved = reinterpret_cast<ChState*>(ws + o_chsave);
+    const u64 chunk = (u64)1 << (p->proof_of_work_bits + 1 < 17 ? 17 : p->proof_of_work_bits + 1);
+    qa.per_query = p->num_query_rounds ? (off_final - p->num_reductions * cap_words) / p->num_query_rounds : 0;
     unsigned long long found = ~0ull;
-    for (u64 base = 0; found == ~0ull; base += chunk) {
+    for (u64 base = 0;; base += chunk) {
       if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
       P2MT_HIP(hipMemsetAsync(d_wit, 0xFF, 8, st));
-      P2MT_DISPATCH(k_fri_pow, grid_for(chunk), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit);
+      P2MT_HIP(hipMemcpyAsync(d_saved, ch->d, sizeof(ChState), hipMemcpyDeviceToDevice, st));
+      if (rt().mds == 2 && rt().use_quad && !rt().force_fallback) {
+        hipLaunchKernelGGL(k_fri_pow_quad, dim3(grid_for(4 * chunk)), dim3(kBlock), 0, st, (const ChState*)ch->d,
+                           (u32)p->proof_of_work_bits, base, chunk, d_wit, p2mt::perm_ctx());
+        P2MT_LAUNCH_CHECK();
+      } else {
+        P2MT_DISPATCH(k_fri_pow, grid_for(chunk), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit);
+      }
+      // observe the witness; pow_response + one challenge per query round
+      P2MT_TRY(launch_challenger(ch->d, d_proof + total - 1, 1, ws + o_qch, 1 + p->num_query_rounds));
+      if (p->num_query_rounds) {
+        hipLaunchKernelGGL(k_fri_queries, dim3(p->num_query_rounds), dim3(kBlock), 0, st, qa, (const u64*)(ws + o_qch + 1),
+                           d_proof + p->num_reductions * cap_words);
+        P2MT_LAUNCH_CHECK();
+      }
       P2MT_HIP(hipMemcpyAsync(&found, d_wit, 8, hipMemcpyDeviceToHost, st));
       P2MT_HIP(hipStreamSynchronize(st));
+      if (found != ~0ull) break;
+      P2MT_HIP(hipMemcpyAsync(ch->d, d_saved, sizeof(ChState), hipMemcpyDeviceToDevice, st));
     }
-  }
-  // observe the witness; pow_response + one challenge per query round
-  P2MT_TRY(launch_challenger(ch->d, d_proof + total - 1, 1, ws + o_qch, 1 + p->num_query_rounds));
-
-  // ---- fri_prover_query_rounds
-  if (p->num_query_rounds) {
-    qa.per_query = (off_final - p->num_reductions * cap_words) / p->num_query_rounds;
-    hipLaunchKernelGGL(k_fri_queries, dim3(p->num_query_rounds), dim3(kBlock), 0, st, qa, (const u64*)(ws + o_qch + 1),
-                       d_proof + p->num_reductions * cap_words);
-    P2MT_LAUNCH_CHECK();
   }
   P2MT_HIP(hipStreamSynchronize(st));  // h_ptrs and the caller's view of d_proof
   return P2MT_OK;
