@@ -7,6 +7,8 @@
 //   src/mmr/merkle_mountain_ranges.rs            : MMR::{new_, add_leaf, bagging_the_peaks, get_peaks, get_proof,
 //                                                  get_proof_normal_index, get_subtree_proof_elm}, MMR_proof::verify,
 //                                                  get_mmr_index, get_heights_bitmap_for_mmr_size
+// and, for the prover the reference drives through CircuitData::prove (mmr_plonky2_verifier.rs:148,
+// mmr_plonky2_verifier_1_recursion.rs:192,218), plonky2's PolynomialBatch, Challenger and prove_openings (FRI).
 // Where the reference panics (assert!/unwrap/log2_strict) this throws p2mt::panic carrying the status code.
 // Getters take `this` by const reference instead of consuming `self` (Quirk Q7: callers no longer clone).
 // All hashing happens in libp2mt_hip.so on the GPU; this header only moves buffers.
@@ -177,5 +179,149 @@ class MMR {  // struct MMR { elements: Vec<HashOut> }, device-resident (:8-12)
  private:
   p2mt_mmr* h_ = nullptr;
 };
+
+// ---------------------------------------------------------------- plonky2 prover pieces (fri/oracle.rs, iop/challenger.rs)
+using Extension = std::array<std::uint64_t, 2>;  // a + bX in F[X]/(X^2 - 7)
+
+struct FriParams : p2mt_fri_params {
+  // CircuitConfig::standard_recursion_config().fri_config.fri_params(degree_bits, false)
+  static FriParams standard(unsigned degree_bits) {
+    FriParams p;
+    check(p2mt_fri_params_standard(degree_bits, &p));
+    return p;
+  }
+};
+
+// PolynomialBatch { polynomials, merkle_tree { leaves, digests, cap } } with blinding = false
+struct PolynomialBatch {
+  std::size_t n_polys = 0;
+  unsigned degree_log = 0, rate_bits = 3, cap_height = 4;
+  std::vector<GoldilocksField> polynomials;  // coefficients [n_polys][2^degree_log]
+  std::vector<GoldilocksField> leaves;       // [2^(degree_log+rate_bits)][n_polys], bit-reversed point order
+  std::vector<HashOut> digests, cap;         // digests level-major
+
+  static PolynomialBatch commit(std::vector<GoldilocksField> polys, std::size_t n_polys, bool is_values, unsigned rate_bits,
+                                unsigned cap_height) {
+    PolynomialBatch b;
+    if (n_polys == 0 || polys.size() % n_polys) throw panic(P2MT_EINVAL, "PolynomialBatch: ragged input");
+    const std::size_t n = polys.size() / n_polys;
+    if (n == 0 || (n & (n - 1))) throw panic(P2MT_EINVAL, "log2_strict: not a power of two");
+    b.n_polys = n_polys;
+    b.rate_bits = rate_bits;
+    b.cap_height = cap_height;
+    while ((std::size_t(1) << b.degree_log) < n) ++b.degree_log;
+    const std::size_t big = n << rate_bits;
+    std::size_t nd = 0;
+    for (std::size_t r = big; r > (std::size_t(1) << cap_height); r >>= 1) nd += r;
+    b.leaves.resize(big * n_polys);
+    b.digests.resize(nd ? nd : 1);
+    b.cap.resize(std::size_t(1) << cap_height);
+    check(p2mt_polynomial_batch_commit(polys.data(), is_values ? 1 : 0, n_polys, b.degree_log, rate_bits, cap_height,
+                                       b.leaves.data(), b.digests[0].elements.data(), b.cap[0].elements.data()));
+    b.digests.resize(nd);
+    if (is_values) check(p2mt_ntt_batch(polys.data(), b.degree_log, n_polys, 1));  // keep coefficients, as plonky2 does
+    b.polynomials = std::move(polys);
+    return b;
+  }
+  static PolynomialBatch from_values(std::vector<GoldilocksField> values, std::size_t n_polys, unsigned rate_bits = 3,
+                                     unsigned cap_height = 4) {
+    return commit(std::move(values), n_polys, true, rate_bits, cap_height);
+  }
+  static PolynomialBatch from_coeffs(std::vector<GoldilocksField> coeffs, std::size_t n_polys, unsigned rate_bits = 3,
+                                     unsigned cap_height = 4) {
+    return commit(std::move(coeffs), n_polys, false, rate_bits, cap_height);
+  }
+};
+
+class Challenger {  // Challenger<F, PoseidonHash>, sponge resident on the device
+ public:
+  Challenger() { check(p2mt_challenger_create(&h_)); }
+  ~Challenger() { p2mt_challenger_destroy(h_); }
+  Challenger(const Challenger& o) { check(p2mt_challenger_clone(o.h_, &h_)); }
+  Challenger& operator=(const Challenger&) = delete;
+  void observe_element(GoldilocksField e) { check(p2mt_challenger_observe(h_, &e, 1)); }
+  void observe_elements(const std::vector<GoldilocksField>& e) { check(p2mt_challenger_observe(h_, e.data(), e.size())); }
+  void observe_hash(const HashOut& h) { check(p2mt_challenger_observe(h_, h.elements.data(), 4)); }
+  void observe_cap(const std::vector<HashOut>& cap) {
+    if (!cap.empty()) check(p2mt_challenger_observe(h_, cap[0].elements.data(), 4 * cap.size()));
+  }
+  void observe_extension_elements(const std::vector<Extension>& e) {
+    if (!e.empty()) check(p2mt_challenger_observe(h_, e[0].data(), 2 * e.size()));
+  }
+  GoldilocksField get_challenge() { return get_n_challenges(1)[0]; }
+  std::vector<GoldilocksField> get_n_challenges(std::size_t n) {
+    std::vector<GoldilocksField> out(n);
+    check(p2mt_challenger_get_challenges(h_, n, out.data()));
+    return out;
+  }
+  Extension get_extension_challenge() {
+    auto c = get_n_challenges(2);
+    return Extension{c[0], c[1]};
+  }
+  p2mt_challenger* handle() const { return h_; }
+
+ private:
+  p2mt_challenger* h_ = nullptr;
+};
+
+// FriBatchInfo { point, polynomials: [(oracle index, polynomial index)] }
+struct FriBatchInfo {
+  Extension point{};
+  std::vector<std::pair<std::uint32_t, std::uint32_t>> polynomials;
+};
+
+namespace detail {
+inline void marshal(const std::vector<const PolynomialBatch*>& oracles, const std::vector<FriBatchInfo>& batches,
+                    std::vector<p2mt_fri_oracle>& o, std::vector<p2mt_fri_batch>& b, std::vector<std::vector<std::uint32_t>>& flat) {
+  for (auto* pb : oracles)
+    o.push_back(p2mt_fri_oracle{pb->polynomials.data(), pb->leaves.data(),
+                                pb->digests.empty() ? nullptr : pb->digests[0].elements.data(), pb->n_polys});
+  flat.resize(batches.size());
+  for (std::size_t i = 0; i < batches.size(); ++i) {
+    for (auto& pr : batches[i].polynomials) {
+      flat[i].push_back(pr.first);
+      flat[i].push_back(pr.second);
+    }
+    b.push_back(p2mt_fri_batch{{batches[i].point[0], batches[i].point[1]}, flat[i].data(), batches[i].polynomials.size()});
+  }
+}
+}  // namespace detail
+
+// OpeningSet::to_fri_openings: values[batch][poly] at the batch's point
+inline std::vector<std::vector<Extension>> fri_openings(const std::vector<FriBatchInfo>& batches,
+                                                        const std::vector<const PolynomialBatch*>& oracles) {
+  std::vector<p2mt_fri_oracle> o;
+  std::vector<p2mt_fri_batch> b;
+  std::vector<std::vector<std::uint32_t>> flat;
+  detail::marshal(oracles, batches, o, b, flat);
+  std::size_t total = 0;
+  for (auto& bi : batches) total += bi.polynomials.size();
+  std::vector<Extension> out(total ? total : 1);
+  check(p2mt_fri_openings(o.data(), o.size(), b.data(), b.size(), oracles.at(0)->degree_log, out[0].data()));
+  std::vector<std::vector<Extension>> res;
+  std::size_t off = 0;
+  for (auto& bi : batches) {
+    res.emplace_back(out.begin() + off, out.begin() + off + bi.polynomials.size());
+    off += bi.polynomials.size();
+  }
+  return res;
+}
+
+// PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params) -> FriProof words (layout: p2mt.h)
+inline std::vector<std::uint64_t> prove_openings(const std::vector<FriBatchInfo>& batches,
+                                                 const std::vector<const PolynomialBatch*>& oracles, Challenger& challenger,
+                                                 const FriParams& params) {
+  std::vector<p2mt_fri_oracle> o;
+  std::vector<p2mt_fri_batch> b;
+  std::vector<std::vector<std::uint32_t>> flat;
+  detail::marshal(oracles, batches, o, b, flat);
+  std::vector<std::uint64_t> np;
+  for (auto* pb : oracles) np.push_back(pb->n_polys);
+  const std::size_t total = p2mt_fri_proof_len(&params, np.size(), np.data());
+  if (total == 0) throw panic(P2MT_EINVAL, "unsupported FriParams");
+  std::vector<std::uint64_t> proof(total);
+  check(p2mt_fri_prove_openings(o.data(), o.size(), b.data(), b.size(), &params, challenger.handle(), proof.data()));
+  return proof;
+}
 
 }  // namespace p2mt

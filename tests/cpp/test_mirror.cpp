@@ -107,6 +107,53 @@ static void test_get_proof() {  // :343-374 (the reference prints; here the resu
   }
 }
 
+// Prover pieces (plonky2; no test in the reference beyond prove+verify): known answers derived from the CPU restatement
+// (tools/gen_fri_golden.py), whose permutation is pinned by the reference's own vectors.
+static void test_challenger_and_fri() {
+  Challenger ch;
+  ch.observe_elements({1, 2, 3});
+  auto c = ch.get_n_challenges(3);
+  REQUIRE(c[0] == 12398646804117377360ull && c[1] == 15781308336284228359ull && c[2] == 17027997015668057891ull);
+  ch.observe_elements({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+  REQUIRE(ch.get_challenge() == 5672640524457059960ull);
+
+  // two polynomials of degree < 32: f0 = sum (i+1) x^i, f1 = sum (2i+1) x^i, opened at 3 + 5X
+  std::vector<GoldilocksField> coeffs(64);
+  for (std::uint64_t i = 0; i < 32; ++i) { coeffs[i] = i + 1; coeffs[32 + i] = 2 * i + 1; }
+  PolynomialBatch pb = PolynomialBatch::from_coeffs(coeffs, 2);
+  REQUIRE(pb.leaves.size() == 256 * 2 && pb.cap.size() == 16 && pb.digests.size() == 256 + 128 + 64 + 32);
+  // from_values(fft(coeffs)) is the same commitment
+  std::vector<GoldilocksField> values = coeffs;
+  check(p2mt_ntt_batch(values.data(), 5, 2, 0));
+  PolynomialBatch pv = PolynomialBatch::from_values(values, 2);
+  REQUIRE(pv.cap == pb.cap && pv.polynomials == pb.polynomials);
+
+  std::vector<FriBatchInfo> batches(1);
+  batches[0].point = Extension{3, 5};
+  batches[0].polynomials = {{0, 0}, {0, 1}};
+  FriParams params = FriParams::standard(5);
+  REQUIRE(params.num_reductions == 0 && params.rate_bits == 3 && params.cap_height == 4 && params.num_query_rounds == 28);
+  params.proof_of_work_bits = 4;
+  params.num_query_rounds = 2;
+  Challenger tr;
+  tr.observe_cap(pb.cap);
+  Challenger tr2(tr);
+  auto proof = prove_openings(batches, {&pb}, tr, params);
+  REQUIRE(proof.size() == 101 && proof.back() == 6);
+  REQUIRE(proof[96] == 1587238328117080795ull && proof[99] == 6829301891844123817ull);
+  std::uint64_t x = 0;
+  for (auto w : proof) x ^= w;
+  REQUIRE(x == 6717879834928653870ull);
+  REQUIRE(prove_openings(batches, {&pb}, tr2, params) == proof);  // deterministic (smallest PoW witness)
+  auto op = fri_openings(batches, {&pb});
+  REQUIRE(op.size() == 1 && op[0].size() == 2);
+  // 1 + 2z + ... at z = 3 + 5X must also be what the restatement gives for the first 8 coefficients' polynomial
+  std::vector<GoldilocksField> small = {1, 2, 3, 4, 5, 6, 7, 8};
+  Extension pt{3, 5}, out{};
+  check(p2mt_eval_polys_ext(small.data(), 1, 3, pt.data(), out.data()));
+  REQUIRE(out[0] == 1210260379ull && out[1] == 490064140ull);
+}
+
 int main() {
   if (p2mt_device_count() == 0) { std::fprintf(stderr, "no GPU: the product has no CPU fallback\n"); return 77; }
   check(p2mt_init(0));
@@ -118,6 +165,7 @@ int main() {
   test_get_mmr_index();
   test_mmr_add_leaf();
   test_get_proof();
-  std::puts("cpp mirror: 8 reference tests passed");
+  test_challenger_and_fri();
+  std::puts("cpp mirror: 8 reference tests + prover pieces passed");
   return 0;
 }

@@ -155,3 +155,29 @@ def test_fri_rejects_bad_arguments(pkg, oracle):
         pkg.prove_openings(batches, go, pkg.Challenger(), pkg.FriParams.standard(6, reduction_arity_bits=[5]))
     with pytest.raises(pkg.P2mtPanic):
         pkg.prove_openings(batches, go, pkg.Challenger(), pkg.FriParams.standard(13))
+
+
+def test_gpu_matches_committed_fri_vectors(pkg, oracle, golden):
+    """The committed vectors (tests/golden/fri_vectors.json) through the C ABI; inputs are rebuilt from the seeds."""
+    g = golden["fri_vectors"]
+    ch = pkg.Challenger()
+    ch.observe_elements(g["challenger"]["observe_1"])
+    assert [int(x) for x in ch.get_n_challenges(3)] == g["challenger"]["challenges_1"]
+    ch.observe_elements(g["challenger"]["observe_2"])
+    assert ch.get_challenge() == g["challenger"]["challenge_2"]
+    e = g["eval_ext"]
+    assert [int(x) for x in pkg.eval_polys_ext(np.array(e["coeffs"], np.uint64)[None], e["point"]).reshape(-1)] == e["value"]
+    for case in g["fri"]:
+        params = pkg.FriParams.standard(case["degree_bits"], **case["override"])
+        coeffs, batches = make_instance(oracle, case["degree_bits"], case["n_polys"], case["seed"])
+        goracles = [pkg.PolynomialBatch.from_coeffs(c, params.rate_bits, params.cap_height) for c in coeffs]
+        caps = np.concatenate([o.merkle_tree.cap for o in goracles])
+        assert [int(x) for x in caps.reshape(-1)] == case["caps"]
+        ch = pkg.Challenger()
+        ch.observe_cap(caps)
+        for op, want in zip(pkg.fri.openings(batches, goracles), case["openings"]):
+            assert [int(x) for x in op.reshape(-1)] == want
+            ch.observe_extension_elements(op)
+        proof = pkg.prove_openings(batches, goracles, ch, params)
+        assert [int(x) for x in proof] == case["proof"]
+        assert ch.get_challenge() == case["next_challenge"]

@@ -106,3 +106,28 @@ def test_not_low_degree_is_rejected(oracle):
     proof = oracle.fri_prove(forged, batches, params, ch.clone())
     ok, reason = oracle.fri_verify([3, 2], caps, batches, openings, params, ch.clone(), proof)
     assert not ok and reason == 3
+
+
+def test_oracle_matches_committed_fri_vectors(oracle, golden):
+    """tests/golden/fri_vectors.json (tools/gen_fri_golden.py): regression pin of the restatement."""
+    g = golden["fri_vectors"]
+    ch = oracle.challenger()
+    ch.observe(g["challenger"]["observe_1"])
+    assert [int(x) for x in ch.get_n_challenges(3)] == g["challenger"]["challenges_1"]
+    ch.observe(g["challenger"]["observe_2"])
+    assert ch.get_challenge() == g["challenger"]["challenge_2"]
+    e = g["eval_ext"]
+    assert [int(x) for x in oracle.eval_polys_ext(np.array(e["coeffs"], np.uint64)[None], e["point"]).reshape(-1)] == e["value"]
+    for case in g["fri"]:
+        params = oracle.fri_params_standard(case["degree_bits"], **case["override"])
+        coeffs, batches = make_instance(oracle, case["degree_bits"], case["n_polys"], case["seed"])
+        oracles, caps = oracle_commit(oracle, coeffs, params)
+        assert [int(x) for x in caps.reshape(-1)] == case["caps"]
+        ch = oracle.challenger()
+        ch.observe(caps.reshape(-1))
+        for op, want in zip(openings_of(oracle, coeffs, batches), case["openings"]):
+            assert [int(x) for x in op.reshape(-1)] == want
+            ch.observe(op.reshape(-1))
+        proof = oracle.fri_prove(oracles, batches, params, ch)
+        assert [int(x) for x in proof] == case["proof"]
+        assert ch.get_challenge() == case["next_challenge"]
