@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed golden fixtures.
 Bit-exact everywhere (integer work).  Run with `pytest -m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -557,3 +559,24 @@ def test_device_resident_proof_service(pkg, oracle):
     for t, i in enumerate(idx):
         ref = om.get_proof_normal_index(int(i))
         assert ns[t] == len(ref["lefts"]) and np.array_equal(sib[t, :ns[t]], ref["siblings"])
+
+
+@pytest.mark.parametrize("env", [
+    {"P2MT_SUBTREE": "0"},                              # fused LDS tiles (k_mmr_tile) as stage 1
+    {"P2MT_SUBTREE": "0", "P2MT_TILE_LOG": "9"},
+    {"P2MT_SUBTREE": "0", "P2MT_TILE_LOG": "11"},
+    {"P2MT_SUBTREE": "5"},                              # 32-leaf per-lane subtrees
+    {"P2MT_SUBTREE_BLOCK": "64"},
+    {"P2MT_SUBTREE_BLOCK": "128"},
+    {"P2MT_QUAD": "0", "P2MT_LDE12": "0"},              # no four-lane kernels, radix-2 LDE at 2^12
+])
+def test_env_knobs(env):
+    """Every P2MT_* runtime knob selects kernels that stay bit-exact (each in a fresh process: read once at init)."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "knob_check.py")], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "knobs ok" in r.stdout
