@@ -211,6 +211,23 @@ int p2mt_polynomial_batch_commit_dev(const uint64_t *d_polys, int is_values, siz
                                      unsigned rate_bits, unsigned cap_height, uint64_t *d_leaves_out,
                                      uint64_t *d_digests_out, uint64_t *d_cap_out);
 
+/* ------------------------------------------------------------------ Plonky2 permutation argument
+ * plonky2 plonk/prover.rs all_wires_permutation_partial_products (inside CircuitData::prove, mmr_plonky2_verifier.rs:148):
+ * for every challenge pair (beta, gamma) the Z polynomial and the partial products of
+ *   (w_j + beta k_j x + gamma) / (w_j + beta sigma_j(x) + gamma)   over the routed wires, in chunks of `chunk`
+ * (= quotient_degree_factor, 8 in standard_recursion_config: 80 routed wires -> 1 Z + 9 partial products per challenge).
+ * wires, sigmas: [num_routed][2^degree_bits] columns of values on the subgroup, natural order; k_is: coset shifts of the
+ * identity permutation (7^j).  out: num_challenges Z columns, then num_challenges x num_prods partial-product columns
+ * (num_prods = ceil(num_routed / chunk) - 1) -- the value matrix PolynomialBatch::from_values commits next ("Z is
+ * expected at the front").  P2MT_EINVAL where plonky2 panics: chunk < 2, or a zero denominator.  [parity unpinned] */
+int p2mt_permutation_partial_products(const uint64_t *wires, const uint64_t *sigmas, const uint64_t *k_is,
+                                      const uint64_t *betas, const uint64_t *gammas, size_t num_challenges,
+                                      size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t *out);
+/* d_wires, d_sigmas, d_out: device memory; k_is, betas, gammas: host arrays.  Synchronises (division check). */
+int p2mt_permutation_partial_products_dev(const uint64_t *d_wires, const uint64_t *d_sigmas, const uint64_t *k_is,
+                                          const uint64_t *betas, const uint64_t *gammas, size_t num_challenges,
+                                          size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t *d_out);
+
 /* ------------------------------------------------------------------ Plonky2 opening proof (challenger + FRI)
  * The last stage of CircuitData::prove (mmr_plonky2_verifier.rs:148, mmr_plonky2_verifier_1_recursion.rs:192,218):
  * plonky2's iop/challenger.rs Challenger, OpeningSet evaluation (plonk/proof.rs eval_all) and

@@ -151,6 +151,14 @@ int oracle_fri_verify(const uint64_t *n_polys, size_t n_oracles, const uint64_t 
                       size_t n_batches, const uint64_t *openings, const oracle_fri_params *p, oracle_challenger *ch,
                       const uint64_t *proof, int *reason);
 
+/* ---- plonky2 plonk/prover.rs wires_permutation_partial_products_and_zs  [parity unpinned] (oracle/plonk.c) ----
+ * wires, sigmas: [num_routed][n] columns of values on the subgroup (natural order); k_is: the coset shifts of the identity
+ * permutation; chunk = quotient_degree_factor.  out: num_challenges Z columns, then num_challenges x num_prods
+ * partial-product columns (num_prods = ceil(num_routed / chunk) - 1).  Returns 0, -1 bad shape, -2 zero denominator. */
+int oracle_permutation_partial_products(const uint64_t *wires, const uint64_t *sigmas, const uint64_t *k_is,
+                                        const uint64_t *betas, const uint64_t *gammas, size_t num_challenges,
+                                        size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

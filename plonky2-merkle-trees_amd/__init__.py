@@ -10,10 +10,11 @@ from ._native import P2mtError, P2mtPanic, lib
 from .hashing import (poseidon_gate_witness_batch, hash_no_pad, hash_no_pad_batch, hash_or_noop, hash_or_noop_batch, poseidon_permute_batch,
                       two_to_one, two_to_one_batch)
 from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_batch
-from . import commit, distributed, fri
+from . import commit, distributed, fri, plonk
 from .commit import MerkleCapTree, PolynomialBatch, coset_lde, fft, ifft
 from .distributed import ShardedMMR
 from .fri import Challenger, FriParams, eval_polys_ext, prove_openings
+from .plonk import all_wires_permutation_partial_products
 from .mmr import (MMR, MMR_proof, get_heights_bitmap_for_mmr_size, get_mmr_index, verify_proof_batch)
 
 GOLDILOCKS_FIELD_ORDER = 18446744069414584321  # src/mmr/common.rs:3

@@ -91,6 +91,10 @@ SIGNATURES = {
                                                voidp, voidp]),
     "p2mt_polynomial_batch_commit_dev": (C.c_int, [voidp, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, voidp,
                                                    voidp, voidp]),
+    "p2mt_permutation_partial_products": (C.c_int, [voidp, voidp, voidp, voidp, voidp, C.c_size_t, C.c_size_t, C.c_uint,
+                                                    C.c_uint, voidp]),
+    "p2mt_permutation_partial_products_dev": (C.c_int, [voidp, voidp, voidp, voidp, voidp, C.c_size_t, C.c_size_t,
+                                                        C.c_uint, C.c_uint, voidp]),
     "p2mt_challenger_create": (C.c_int, [C.POINTER(voidp)]),
     "p2mt_challenger_destroy": (C.c_int, [voidp]),
     "p2mt_challenger_clone": (C.c_int, [voidp, C.POINTER(voidp)]),

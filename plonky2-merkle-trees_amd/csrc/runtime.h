@@ -50,7 +50,7 @@ inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ul
 
 // Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
-enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchCount };
+enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
 
 // RAII: run a scope on another stream, restore the library stream afterwards

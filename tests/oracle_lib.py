@@ -112,6 +112,8 @@ class Oracle:
         lib.oracle_merkle_cap_commit.argtypes = [_u64p, C.c_size_t, C.c_size_t, C.c_uint, _u64p, _u64p]
         lib.oracle_polynomial_batch_commit.argtypes = [_u64p, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint,
                                                        _u64p, _u64p, _u64p]
+        lib.oracle_permutation_partial_products.argtypes = [_u64p, _u64p, _u64p, _u64p, _u64p, C.c_size_t, C.c_size_t,
+                                                            C.c_uint, C.c_uint, _u64p]
         lib.oracle_challenger_init.argtypes = [C.POINTER(ChallengerState)]
         lib.oracle_challenger_observe.argtypes = [C.POINTER(ChallengerState), _u64p, C.c_size_t]
         lib.oracle_challenger_get.argtypes = [C.POINTER(ChallengerState)]
@@ -275,6 +277,21 @@ class Oracle:
         if rc < 0:
             raise ValueError("bad polynomial_batch_commit shape")
         return leaves, digests[:n_dig], cap
+
+    # ---- permutation argument (oracle/plonk.c)
+    def permutation_partial_products(self, wires, sigmas, k_is, betas, gammas, chunk=8):
+        """-> (zs (num_challenges, n), partial_products (num_challenges, num_prods, n))"""
+        wires, sigmas, k_is = _arr(wires), _arr(sigmas), _arr(k_is)
+        betas, gammas = _arr(betas).reshape(-1), _arr(gammas).reshape(-1)
+        num_routed, n = wires.shape
+        nc = betas.size
+        num_prods = (num_routed + chunk - 1) // chunk - 1
+        out = np.zeros((nc * (1 + num_prods), n), np.uint64)
+        rc = self.lib.oracle_permutation_partial_products(_ptr(wires), _ptr(sigmas), _ptr(k_is), _ptr(betas), _ptr(gammas),
+                                                          nc, num_routed, n.bit_length() - 1, chunk, _ptr(out))
+        if rc != 0:
+            raise ValueError("oracle_permutation_partial_products: status %d" % rc)
+        return out[:nc], out[nc:].reshape(nc, num_prods, n)
 
     # ---- challenger / FRI (oracle/fri.c)
     def challenger(self):
