@@ -159,6 +159,31 @@ int oracle_permutation_partial_products(const uint64_t *wires, const uint64_t *s
                                         const uint64_t *betas, const uint64_t *gammas, size_t num_challenges,
                                         size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t *out);
 
+/* ---- plonky2 gates + plonk/vanishing_poly.rs + prover.rs compute_quotient_polys + verifier.rs  [parity unpinned] (oracle/plonk.c) ----
+ * Circuit shape the verifier circuits of /root/reference/src/mmr/mmr_plonky2_verifier.rs:13-91 build to under
+ * CircuitConfig::standard_recursion_config(): the gate types in plonky2's sorted order (degree, id), each with its selector
+ * polynomial and selector group (gates/selectors.rs). */
+enum { ORACLE_GATE_NOOP = 0, ORACLE_GATE_CONSTANT = 1, ORACLE_GATE_PUBLIC_INPUT = 2, ORACLE_GATE_ARITHMETIC = 3, ORACLE_GATE_POSEIDON = 4 };
+#define ORACLE_PLONK_NUM_GATE_CONSTRAINTS 123 /* PoseidonGate: 1 + 4 + 36 + 22 + 48 + 12 */
+typedef struct oracle_plonk_desc {
+  uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, num_gates;
+  uint32_t gate_kind[8], gate_selector[8], group_start[8], group_end[8];
+} oracle_plonk_desc;
+/* compute_quotient_polys: cs/wires/zs leaves are the LDE matrices of the three committed batches as
+ * oracle_polynomial_batch_commit leaves them ([8n][n_polys], leaf index bit-reversed; cs = selectors | constants | sigmas,
+ * zs = Z per challenge | partial products).  out: num_challenges x quotient_degree_factor coefficient chunks of n. Returns 0. */
+int oracle_plonk_quotient_polys(const oracle_plonk_desc *d, const uint64_t *k_is, const uint64_t *cs_leaves,
+                                const uint64_t *wires_leaves, const uint64_t *zs_leaves, const uint64_t pi_hash[4],
+                                const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas, uint64_t *out);
+/* The verifier's check of the opened values (verifier.rs verify_with_challenges, before verify_fri_proof):
+ * vanishing(zeta) == Z_H(zeta) * sum_k t_k(zeta) zeta^(n k) per challenge.  Every opening is an extension element (2 words):
+ * constants [num_selectors + num_constants], sigmas [num_routed], wires [num_wires], zs / next_zs [num_challenges],
+ * pps [num_challenges * num_prods], quotient [num_challenges * quotient_degree_factor].  Returns 1 accept, 0 reject. */
+int oracle_plonk_check_openings(const oracle_plonk_desc *d, const uint64_t *k_is, const uint64_t zeta[2], const uint64_t *constants,
+                                const uint64_t *sigmas, const uint64_t *wires, const uint64_t *zs, const uint64_t *next_zs,
+                                const uint64_t *pps, const uint64_t *quotient, const uint64_t pi_hash[4], const uint64_t *betas,
+                                const uint64_t *gammas, const uint64_t *alphas);
+
 #ifdef __cplusplus
 }
 #endif

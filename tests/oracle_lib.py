@@ -50,6 +50,12 @@ class FriBatch(C.Structure):
     _fields_ = [("point", C.c_uint64 * 2), ("polys", C.POINTER(C.c_uint32)), ("n_polys", C.c_uint64)]
 
 
+class PlonkDesc(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("degree_bits", "num_wires", "num_routed", "num_constants", "num_selectors",
+                                          "num_challenges", "quotient_degree_factor", "num_gates")] + \
+               [(k, C.c_uint32 * 8) for k in ("gate_kind", "gate_selector", "group_start", "group_end")]
+
+
 class ChallengerState(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("inp", C.c_uint64 * 8), ("out", C.c_uint64 * 8), ("n_in", C.c_uint32),
                 ("n_out", C.c_uint32)]
@@ -114,6 +120,8 @@ class Oracle:
                                                        _u64p, _u64p, _u64p]
         lib.oracle_permutation_partial_products.argtypes = [_u64p, _u64p, _u64p, _u64p, _u64p, C.c_size_t, C.c_size_t,
                                                             C.c_uint, C.c_uint, _u64p]
+        lib.oracle_plonk_quotient_polys.argtypes = [C.POINTER(PlonkDesc)] + [_u64p] * 9
+        lib.oracle_plonk_check_openings.argtypes = [C.POINTER(PlonkDesc)] + [_u64p] * 13
         lib.oracle_challenger_init.argtypes = [C.POINTER(ChallengerState)]
         lib.oracle_challenger_observe.argtypes = [C.POINTER(ChallengerState), _u64p, C.c_size_t]
         lib.oracle_challenger_get.argtypes = [C.POINTER(ChallengerState)]
@@ -292,6 +300,33 @@ class Oracle:
         if rc != 0:
             raise ValueError("oracle_permutation_partial_products: status %d" % rc)
         return out[:nc], out[nc:].reshape(nc, num_prods, n)
+
+    # ---- gate constraints / quotient / opening check (oracle/plonk.c)
+    def ifft_rows(self, a):
+        return np.stack([self.ifft(r) for r in _arr(a)])
+
+    def plonk_desc(self, degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges,
+                   quotient_degree_factor, gate_kinds, gate_selectors, gate_groups):
+        d = PlonkDesc(degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges,
+                      quotient_degree_factor, len(gate_kinds))
+        for i, (k, s, (gs, ge)) in enumerate(zip(gate_kinds, gate_selectors, gate_groups)):
+            d.gate_kind[i], d.gate_selector[i], d.group_start[i], d.group_end[i] = k, s, gs, ge
+        return d
+
+    def plonk_quotient_polys(self, desc, k_is, cs_leaves, wires_leaves, zs_leaves, pi_hash, betas, gammas, alphas):
+        """compute_quotient_polys -> (num_challenges, quotient_degree_factor << degree_bits) coefficients"""
+        args = [_arr(x) for x in (k_is, cs_leaves, wires_leaves, zs_leaves, pi_hash, betas, gammas, alphas)]
+        out = np.zeros((desc.num_challenges, desc.quotient_degree_factor << desc.degree_bits), np.uint64)
+        rc = self.lib.oracle_plonk_quotient_polys(C.byref(desc), *[_ptr(a) for a in args], _ptr(out))
+        if rc != 0:
+            raise ValueError("oracle_plonk_quotient_polys: status %d" % rc)
+        return out
+
+    def plonk_check_openings(self, desc, k_is, zeta, constants, sigmas, wires, zs, next_zs, pps, quotient, pi_hash, betas,
+                             gammas, alphas):
+        args = [_arr(x) for x in (k_is, zeta, constants, sigmas, wires, zs, next_zs, pps, quotient, pi_hash, betas, gammas,
+                                  alphas)]
+        return bool(self.lib.oracle_plonk_check_openings(C.byref(desc), *[_ptr(a) for a in args]))
 
     # ---- challenger / FRI (oracle/fri.c)
     def challenger(self):
