@@ -246,6 +246,9 @@ int p2mt_challenger_observe_dev(p2mt_challenger *c, const uint64_t *d_elements, 
 /* get_n_challenges (an extension challenge = 2 of them, in this order) */
 int p2mt_challenger_get_challenges(p2mt_challenger *c, size_t n, uint64_t *out);
 int p2mt_challenger_get_challenges_dev(p2mt_challenger *c, size_t n, uint64_t *d_out); /* enqueues, returns */
+/* observe + squeeze in one launch (the duplex the prover performs after every commitment), and a reset to Challenger::new() */
+int p2mt_challenger_reset(p2mt_challenger *c);
+int p2mt_challenger_duplex_dev(p2mt_challenger *c, const uint64_t *d_elements, size_t n_obs, uint64_t *d_out, size_t n_out);
 /* state words for tests/checkpoints: sponge_state[12] | input_buffer[8] | output_buffer[8] | n_in | n_out */
 #define P2MT_CHALLENGER_STATE_WORDS 30
 int p2mt_challenger_get_state(const p2mt_challenger *c, uint64_t *out);
@@ -301,6 +304,80 @@ int p2mt_fri_prove_openings(const p2mt_fri_oracle *oracles, size_t n_oracles, co
 int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle *d_oracles, size_t n_oracles, const p2mt_fri_batch *batches,
                                 size_t n_batches, const p2mt_fri_params *params, p2mt_challenger *challenger,
                                 uint64_t *d_proof_out);
+
+/* ------------------------------------------------------------------ Plonky2 CircuitBuilder / CircuitData::prove
+ * What the reference does through plonky2 at mmr_plonky2_verifier.rs:13-91 (verify_mmr_proof_circuit: CircuitBuilder calls,
+ * with the gadgets of src/mmr/common.rs:5-58 on top), :122-146 (PartialWitness) and :148 (circuit_data.prove(pw)), under
+ * CircuitConfig::standard_recursion_config() (:30): 135 wires, 80 routed, 2 constants, 2 challenges, quotient degree factor 8,
+ * FRI rate 1/8, cap height 4, 16-bit proof of work, 28 queries, zero-knowledge off.  Supported gate set: NoopGate,
+ * ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate -- everything those circuits instantiate.  The builder and the
+ * generator schedule are host code; witness fill, the three commitments, the permutation argument, the quotient
+ * polynomials, the openings and the FRI proof run on the device, chained on the library stream.
+ * [parity unpinned: plonky2's source is not part of the reference tree; checked bit for bit against the tests' CPU
+ *  restatement, whose verifier must accept the proof.]
+ * A Target is an opaque 64-bit handle (plonky2 Target::{Wire, VirtualTarget}); BoolTarget / HashOutTarget are 1 / 4 of them. */
+typedef uint64_t p2mt_target;
+typedef struct p2mt_circuit_builder p2mt_circuit_builder; /* CircuitBuilder<GoldilocksField, 2> */
+typedef struct p2mt_circuit_data p2mt_circuit_data;       /* CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2> */
+typedef struct p2mt_partial_witness p2mt_partial_witness; /* PartialWitness<GoldilocksField> */
+int p2mt_cb_create(p2mt_circuit_builder **out);           /* CircuitBuilder::new(standard_recursion_config()) (:31) */
+int p2mt_cb_destroy(p2mt_circuit_builder *b);
+int p2mt_cb_add_virtual_target(p2mt_circuit_builder *b, p2mt_target *out);            /* :33; add_virtual_hash = 4 of them (:41,:66) */
+int p2mt_cb_add_virtual_bool_target_safe(p2mt_circuit_builder *b, p2mt_target *out);  /* :42 (virtual target + assert_bool) */
+int p2mt_cb_constant(p2mt_circuit_builder *b, uint64_t c, p2mt_target *out);          /* zero() / one() (:76) */
+int p2mt_cb_connect(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y);           /* :77; P2MT_EINVAL for an unroutable wire */
+/* const_0 * multiplicand_0 * multiplicand_1 + const_1 * addend (gadgets/arithmetic.rs), with plonky2's constant folding,
+ * operation cache and ArithmeticGate slot packing (20 operations per row, one row per constant pair) */
+int p2mt_cb_arithmetic(p2mt_circuit_builder *b, uint64_t const_0, uint64_t const_1, p2mt_target multiplicand_0,
+                       p2mt_target multiplicand_1, p2mt_target addend, p2mt_target *out);
+int p2mt_cb_add(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y, p2mt_target *out);
+int p2mt_cb_sub(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y, p2mt_target *out);
+int p2mt_cb_mul(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y, p2mt_target *out);                     /* common.rs:48-51 */
+int p2mt_cb_mul_add(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y, p2mt_target z, p2mt_target *out);  /* common.rs:52-55 */
+int p2mt_cb_mul_sub(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y, p2mt_target z, p2mt_target *out);
+int p2mt_cb_not(p2mt_circuit_builder *b, p2mt_target x, p2mt_target *out);                                    /* common.rs:46 */
+int p2mt_cb_or(p2mt_circuit_builder *b, p2mt_target b1, p2mt_target b2, p2mt_target *out);                    /* common.rs:13-15,25 */
+int p2mt_cb_assert_bool(p2mt_circuit_builder *b, p2mt_target x);
+int p2mt_cb_is_equal(p2mt_circuit_builder *b, p2mt_target x, p2mt_target y, p2mt_target *out);                /* common.rs:9-12 */
+/* hash_n_to_hash_no_pad::<PoseidonHash> (:81): one PoseidonGate row per 8 inputs; hash_or_noop (:34,:46-54): <= 4 inputs
+ * are padded with zero() and no gate is added.  out: 4 targets. */
+int p2mt_cb_hash_n_to_hash_no_pad(p2mt_circuit_builder *b, const p2mt_target *inputs, size_t n, p2mt_target *out);
+int p2mt_cb_hash_or_noop(p2mt_circuit_builder *b, const p2mt_target *inputs, size_t n, p2mt_target *out);
+int p2mt_cb_register_public_inputs(p2mt_circuit_builder *b, const p2mt_target *targets, size_t n);           /* :83,:86 */
+size_t p2mt_cb_num_gates(const p2mt_circuit_builder *b);
+/* builder.build::<PoseidonGoldilocksConfig>() (:89): public-input hash + PublicInputGate, ConstantGates, padding to a power
+ * of two with NoopGates, selector / constant / sigma polynomials and their commitment on the device, circuit digest.
+ * The builder must not be used afterwards (plonky2's build consumes it); destroy it.  P2MT_EINVAL for more than 2^12 rows. */
+int p2mt_cb_build(p2mt_circuit_builder *b, p2mt_circuit_data **out);
+int p2mt_circuit_destroy(p2mt_circuit_data *c);
+typedef struct p2mt_circuit_info {
+  uint32_t degree_bits, num_gate_types, num_selectors, num_constants_sigmas, num_public_inputs, num_partial_products;
+  uint32_t gate_counts[5];  /* rows per gate type: Noop, Constant, PublicInput, Arithmetic, Poseidon */
+  uint32_t gate_kinds[5], gate_selector[5], group_start[5], group_end[5]; /* sorted gate types and their selector groups */
+  uint64_t proof_len, fri_proof_len; /* words */
+} p2mt_circuit_info;
+int p2mt_circuit_get_info(const p2mt_circuit_data *c, p2mt_circuit_info *info);
+int p2mt_circuit_public_inputs(const p2mt_circuit_data *c, p2mt_target *out); /* circuit_data.prover_only.public_inputs (:137) */
+/* constants_sigmas values [num_constants_sigmas][2^degree_bits] (selectors | constants | sigmas), the commitment's cap [16][4]
+ * and circuit_digest [4]; any pointer may be NULL */
+int p2mt_circuit_constants_sigmas(const p2mt_circuit_data *c, uint64_t *values_out, uint64_t *cap_out, uint64_t *digest_out);
+int p2mt_pw_create(p2mt_partial_witness **out);  /* PartialWitness::new() (:123) */
+int p2mt_pw_destroy(p2mt_partial_witness *pw);
+int p2mt_pw_clear(p2mt_partial_witness *pw);
+int p2mt_pw_set_target(p2mt_partial_witness *pw, p2mt_target t, uint64_t value); /* set_target / set_bool_target; set_hash_target = 4 calls (:126-146) */
+/* generate_partial_witness + full_witness only: wires_out [135][2^degree_bits].  P2MT_EINVAL where plonky2 panics: a target
+ * set twice with different values (a witness that contradicts the circuit), generators that cannot run. */
+int p2mt_circuit_generate_witness(p2mt_circuit_data *c, const p2mt_partial_witness *pw, uint64_t *wires_out);
+/* circuit_data.prove(pw) (:148).  proof_out (p2mt_circuit_info.proof_len words), plonky2's serialisation order:
+ *   wires_cap [16][4] | plonk_zs_partial_products_cap [16][4] | quotient_polys_cap [16][4]
+ *   OpeningSet, 2 words each: constants [num_selectors + 2] | plonk_sigmas [80] | wires [135] | plonk_zs [2] | plonk_zs_next [2]
+ *                             | partial_products [18] | quotient_polys [16]
+ *   FriProof (layout at p2mt_fri_proof_len) | public_inputs [num_public_inputs]
+ * Deterministic (the PublicInputGate's unused wires stay zero where plonky2 randomises them; smallest proof-of-work witness). */
+int p2mt_circuit_prove(p2mt_circuit_data *c, const p2mt_partial_witness *pw, uint64_t *proof_out, size_t proof_cap);
+/* intermediates of the last prove (parity tests): 0 wires [135][n], 1 Z | partial products [20][n] (values), 2 quotient chunks
+ * [16][n] (coefficients), 3 challenges {betas[2], gammas[2], alphas[2], zeta[2]}, 4 public_inputs_hash [4] */
+int p2mt_circuit_prove_trace(const p2mt_circuit_data *c, int what, uint64_t *out);
 
 #ifdef __cplusplus
 }

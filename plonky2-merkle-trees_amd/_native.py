@@ -104,6 +104,8 @@ SIGNATURES = {
     "p2mt_challenger_get_challenges_dev": (C.c_int, [voidp, C.c_size_t, voidp]),
     "p2mt_challenger_get_state": (C.c_int, [voidp, voidp]),
     "p2mt_challenger_set_state": (C.c_int, [voidp, voidp]),
+    "p2mt_challenger_reset": (C.c_int, [voidp]),
+    "p2mt_challenger_duplex_dev": (C.c_int, [voidp, voidp, C.c_size_t, voidp, C.c_size_t]),
     "p2mt_eval_polys_ext": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_eval_polys_ext_dev": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_fri_openings": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, C.c_uint, voidp]),
@@ -112,6 +114,38 @@ SIGNATURES = {
     "p2mt_fri_proof_len": (C.c_size_t, [voidp, C.c_size_t, voidp]),
     "p2mt_fri_prove_openings": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, voidp, voidp]),
     "p2mt_fri_prove_openings_dev": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, voidp, voidp]),
+    "p2mt_cb_create": (C.c_int, [C.POINTER(voidp)]),
+    "p2mt_cb_destroy": (C.c_int, [voidp]),
+    "p2mt_cb_add_virtual_target": (C.c_int, [voidp, u64p]),
+    "p2mt_cb_add_virtual_bool_target_safe": (C.c_int, [voidp, u64p]),
+    "p2mt_cb_constant": (C.c_int, [voidp, C.c_uint64, u64p]),
+    "p2mt_cb_connect": (C.c_int, [voidp, C.c_uint64, C.c_uint64]),
+    "p2mt_cb_arithmetic": (C.c_int, [voidp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_add": (C.c_int, [voidp, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_sub": (C.c_int, [voidp, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_mul": (C.c_int, [voidp, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_mul_add": (C.c_int, [voidp, C.c_uint64, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_mul_sub": (C.c_int, [voidp, C.c_uint64, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_not": (C.c_int, [voidp, C.c_uint64, u64p]),
+    "p2mt_cb_or": (C.c_int, [voidp, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_assert_bool": (C.c_int, [voidp, C.c_uint64]),
+    "p2mt_cb_is_equal": (C.c_int, [voidp, C.c_uint64, C.c_uint64, u64p]),
+    "p2mt_cb_hash_n_to_hash_no_pad": (C.c_int, [voidp, voidp, C.c_size_t, voidp]),
+    "p2mt_cb_hash_or_noop": (C.c_int, [voidp, voidp, C.c_size_t, voidp]),
+    "p2mt_cb_register_public_inputs": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_cb_num_gates": (C.c_size_t, [voidp]),
+    "p2mt_cb_build": (C.c_int, [voidp, C.POINTER(voidp)]),
+    "p2mt_circuit_destroy": (C.c_int, [voidp]),
+    "p2mt_circuit_get_info": (C.c_int, [voidp, voidp]),
+    "p2mt_circuit_public_inputs": (C.c_int, [voidp, voidp]),
+    "p2mt_circuit_constants_sigmas": (C.c_int, [voidp, voidp, voidp, voidp]),
+    "p2mt_pw_create": (C.c_int, [C.POINTER(voidp)]),
+    "p2mt_pw_destroy": (C.c_int, [voidp]),
+    "p2mt_pw_clear": (C.c_int, [voidp]),
+    "p2mt_pw_set_target": (C.c_int, [voidp, C.c_uint64, C.c_uint64]),
+    "p2mt_circuit_generate_witness": (C.c_int, [voidp, voidp, voidp]),
+    "p2mt_circuit_prove": (C.c_int, [voidp, voidp, voidp, C.c_size_t]),
+    "p2mt_circuit_prove_trace": (C.c_int, [voidp, C.c_int, voidp]),
 }
 
 

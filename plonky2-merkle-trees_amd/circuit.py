@@ -1,0 +1,185 @@
+"""Host-side mirror of the plonky2 surface the reference's verifier circuits use (mmr_plonky2_verifier.rs:13-151):
+CircuitBuilder, CircuitData {prove}, PartialWitness -- over the C ABI (include/p2mt.h).  A Target is an opaque integer
+handle; a HashOutTarget is a list of 4, a BoolTarget a Target."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class CircuitInfo(C.Structure):
+    _fields_ = [("degree_bits", C.c_uint32), ("num_gate_types", C.c_uint32), ("num_selectors", C.c_uint32),
+                ("num_constants_sigmas", C.c_uint32), ("num_public_inputs", C.c_uint32),
+                ("num_partial_products", C.c_uint32), ("gate_counts", C.c_uint32 * 5), ("gate_kinds", C.c_uint32 * 5),
+                ("gate_selector", C.c_uint32 * 5), ("group_start", C.c_uint32 * 5), ("group_end", C.c_uint32 * 5),
+                ("proof_len", C.c_uint64), ("fri_proof_len", C.c_uint64)]
+
+
+def _targets(ts):
+    return np.ascontiguousarray(np.asarray([int(t) for t in ts], dtype=np.uint64))
+
+
+class CircuitBuilder:
+    """CircuitBuilder::<GoldilocksField, 2>::new(CircuitConfig::standard_recursion_config())."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        N.check(N.lib().p2mt_cb_create(C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().p2mt_cb_destroy(h)
+
+    def _out(self, fn, *args):
+        t = C.c_uint64()
+        N.check(fn(self._h, *args, C.byref(t)))
+        return t.value
+
+    def add_virtual_target(self):
+        return self._out(N.lib().p2mt_cb_add_virtual_target)
+
+    def add_virtual_hash(self):
+        return [self.add_virtual_target() for _ in range(4)]
+
+    def add_virtual_bool_target_safe(self):
+        return self._out(N.lib().p2mt_cb_add_virtual_bool_target_safe)
+
+    def constant(self, c):
+        return self._out(N.lib().p2mt_cb_constant, int(c))
+
+    def zero(self):
+        return self.constant(0)
+
+    def one(self):
+        return self.constant(1)
+
+    def connect(self, x, y):
+        N.check(N.lib().p2mt_cb_connect(self._h, x, y))
+
+    def arithmetic(self, const_0, const_1, multiplicand_0, multiplicand_1, addend):
+        return self._out(N.lib().p2mt_cb_arithmetic, int(const_0), int(const_1), multiplicand_0, multiplicand_1, addend)
+
+    def add(self, x, y):
+        return self._out(N.lib().p2mt_cb_add, x, y)
+
+    def sub(self, x, y):
+        return self._out(N.lib().p2mt_cb_sub, x, y)
+
+    def mul(self, x, y):
+        return self._out(N.lib().p2mt_cb_mul, x, y)
+
+    def mul_add(self, x, y, z):
+        return self._out(N.lib().p2mt_cb_mul_add, x, y, z)
+
+    def mul_sub(self, x, y, z):
+        return self._out(N.lib().p2mt_cb_mul_sub, x, y, z)
+
+    def not_(self, b):
+        return self._out(N.lib().p2mt_cb_not, b)
+
+    def or_(self, b1, b2):
+        return self._out(N.lib().p2mt_cb_or, b1, b2)
+
+    def assert_bool(self, b):
+        N.check(N.lib().p2mt_cb_assert_bool(self._h, b))
+
+    def is_equal(self, x, y):
+        return self._out(N.lib().p2mt_cb_is_equal, x, y)
+
+    def _hash(self, fn, inputs):
+        ins, out = _targets(inputs), np.zeros(4, np.uint64)
+        N.check(fn(self._h, N.ptr(ins), ins.size, N.ptr(out)))
+        return [int(t) for t in out]
+
+    def hash_n_to_hash_no_pad(self, inputs):
+        return self._hash(N.lib().p2mt_cb_hash_n_to_hash_no_pad, inputs)
+
+    def hash_or_noop(self, inputs):
+        return self._hash(N.lib().p2mt_cb_hash_or_noop, inputs)
+
+    def register_public_inputs(self, targets):
+        ts = _targets(targets)
+        N.check(N.lib().p2mt_cb_register_public_inputs(self._h, N.ptr(ts), ts.size))
+
+    def num_gates(self):
+        return N.lib().p2mt_cb_num_gates(self._h)
+
+    def build(self):
+        """builder.build::<PoseidonGoldilocksConfig>()"""
+        h = C.c_void_p()
+        N.check(N.lib().p2mt_cb_build(self._h, C.byref(h)))
+        return CircuitData(h)
+
+
+class PartialWitness:
+    def __init__(self):
+        self._h = C.c_void_p()
+        N.check(N.lib().p2mt_pw_create(C.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().p2mt_pw_destroy(h)
+
+    def set_target(self, target, value):
+        N.check(N.lib().p2mt_pw_set_target(self._h, target, int(value)))
+
+    def set_bool_target(self, target, value):
+        self.set_target(target, 1 if value else 0)
+
+    def set_hash_target(self, targets, value):
+        for t, v in zip(targets, value):
+            self.set_target(t, v)
+
+
+class _ProverOnly:
+    def __init__(self, public_inputs):
+        self.public_inputs = public_inputs
+
+
+class CircuitData:
+    """CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2>; the prover data lives in device memory."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.info = CircuitInfo()
+        N.check(N.lib().p2mt_circuit_get_info(self._h, C.addressof(self.info)))
+        pis = np.zeros(max(self.info.num_public_inputs, 1), np.uint64)
+        N.check(N.lib().p2mt_circuit_public_inputs(self._h, N.ptr(pis)))
+        self.prover_only = _ProverOnly([int(t) for t in pis[:self.info.num_public_inputs]])
+        self.degree_bits = self.info.degree_bits
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().p2mt_circuit_destroy(h)
+
+    def constants_sigmas(self):
+        """-> (values (num_constants_sigmas, n), cap (16, 4), circuit_digest (4,))"""
+        vals = np.zeros((self.info.num_constants_sigmas, 1 << self.degree_bits), np.uint64)
+        cap, digest = np.zeros((16, 4), np.uint64), np.zeros(4, np.uint64)
+        N.check(N.lib().p2mt_circuit_constants_sigmas(self._h, N.ptr(vals), N.ptr(cap), N.ptr(digest)))
+        return vals, cap, digest
+
+    def generate_witness(self, pw):
+        wires = np.zeros((135, 1 << self.degree_bits), np.uint64)
+        N.check(N.lib().p2mt_circuit_generate_witness(self._h, pw._h, N.ptr(wires)))
+        return wires
+
+    def prove(self, pw):
+        """circuit_data.prove(pw) -> ProofWithPublicInputs as words (layout: include/p2mt.h)."""
+        proof = np.zeros(self.info.proof_len, np.uint64)
+        N.check(N.lib().p2mt_circuit_prove(self._h, pw._h, N.ptr(proof), proof.size))
+        return proof
+
+    def prove_trace(self):
+        n = 1 << self.degree_bits
+        out = {}
+        for key, what, shape in (("wires", 0, (135, n)), ("zs_pp", 1, (20, n)), ("quotient_chunks", 2, (16, n)),
+                                 ("challenges", 3, (8,)), ("pi_hash", 4, (4,))):
+            a = np.zeros(shape, np.uint64)
+            N.check(N.lib().p2mt_circuit_prove_trace(self._h, what, N.ptr(a)))
+            out[key] = a
+        return out

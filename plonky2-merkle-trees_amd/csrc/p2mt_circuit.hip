@@ -1,0 +1,1197 @@
+// p2mt_circuit.hip -- CircuitBuilder / CircuitData::prove for the reference's MMR-verifier circuits, device-resident.
+//
+// Replaces what /root/reference/src/mmr/mmr_plonky2_verifier.rs:13-91 (circuit construction through plonky2's
+// CircuitBuilder; gadgets of src/mmr/common.rs:5-58) and :148 (`circuit_data.prove(pw)`) run inside plonky2 (git rev 3b21b87d,
+// NOT in the reference tree -- parity unpinned, checked bit for bit against the tests' CPU restatement):
+//   host   CircuitBuilder under CircuitConfig::standard_recursion_config() restricted to the gate set those circuits use
+//          (NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate); build(): selector / constant / sigma
+//          polynomials and their commitment; the generator schedule (levels of independent generators).
+//   device witness fill (k_witness_run: one workgroup interprets the levelled generator list, one wavefront per PoseidonGate
+//          row with the 12-lanes-per-permutation layout recording every S-box input wire), wires commitment, challenger,
+//          Z / partial products, the quotient polynomials (k_quotient: one lane per point of the 8n-point LDE coset evaluates
+//          every gate's constraints, the permutation checks and L_0 (Z - 1), combined with powers of alpha and divided by
+//          Z_H), coset IFFT, quotient commitment, openings and the FRI proof (p2mt_fri.hip).
+// Nothing here is GEMM-shaped: 64-bit modular arithmetic on the integer VALU, latency-bound at these sizes (64..4096 rows).
+#include "tree_common.hip.h"
+
+#include <algorithm>
+#include <map>
+#include <new>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+using namespace p2mt_dev;
+using p2mt::rt;
+
+namespace {
+
+// CircuitConfig::standard_recursion_config() (mmr_plonky2_verifier.rs:30)
+constexpr u32 kNumWires = 135, kNumRouted = 80, kNumConsts = 2, kNumCh = 2, kQF = 8, kRateBits = 3, kCapHeight = 4;
+constexpr u32 kNumChunks = (kNumRouted + kQF - 1) / kQF, kNumProds = kNumChunks - 1, kNumOps = kNumRouted / 4;
+constexpr u32 kNumZs = kNumCh * (1 + kNumProds), kNumQuot = kNumCh * kQF;
+enum { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_POSEIDON, G_KINDS };
+// plonky2 sorts the gate types by (degree, id): Noop(0) < Constant(1) < PublicInput(1) < Arithmetic(3) < Poseidon(7), which
+// is the enum order
+constexpr u32 kGateDegree[G_KINDS] = {0, 1, 1, 3, 7};
+constexpr u64 kWireFlag = 1ull << 63, kUnusedSelector = 0xFFFFFFFFull;
+
+inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
+inline u64 h_add(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % gl::P); }
+inline u64 h_pow(u64 a, u64 e) {
+  u64 r = 1;
+  for (; e; e >>= 1, a = h_mul(a, a))
+    if (e & 1) r = h_mul(r, a);
+  return r;
+}
+inline u64 h_root_of_unity(unsigned log_n) {
+  u64 g = h_pow(7, (gl::P - 1) >> 32);
+  for (unsigned i = log_n; i < 32; ++i) g = h_mul(g, g);
+  return g;
+}
+
+inline u64 wire_t(u32 row, u32 col) { return kWireFlag | ((u64)row << 8) | col; }
+inline bool is_wire(u64 t) { return (t & kWireFlag) != 0; }
+inline u32 wire_row(u64 t) { return (u32)((t & ~kWireFlag) >> 8); }
+inline u32 wire_col(u64 t) { return (u32)(t & 0xFF); }
+
+struct GateInst {
+  int kind;
+  u64 c[2];
+};
+enum { GEN_POSEIDON = 0, GEN_ARITH = 1, GEN_EQUALITY = 2, GEN_CONST = 3 };
+struct Gen {
+  int kind;
+  u32 row, i;
+  u64 c0, c1;
+  u64 x, y, eq, inv;  // EqualityGenerator targets
+};
+
+// one generator as the device interpreter sees it (slots index the value table)
+struct WOp {
+  u32 kind, a, b, c, out, out2;
+  u64 c0, c1;
+};
+
+}  // namespace
+
+struct p2mt_circuit_builder {
+  u64 n_virtual = 0;
+  std::vector<GateInst> gates;
+  std::vector<std::pair<u64, u64>> copies;
+  std::vector<Gen> gens;
+  std::map<u64, u64> const_to_target;  // iterated in increasing canonical order at build()
+  std::unordered_map<u64, u64> target_to_const;
+  std::map<std::tuple<u64, u64, u64, u64, u64>, u64> arith_results;
+  std::map<std::pair<u64, u64>, std::pair<u32, u32>> slots;  // (c0, c1) -> (row, next free operation)
+  std::vector<u64> public_inputs;
+};
+
+struct p2mt_partial_witness {
+  std::vector<std::pair<u64, u64>> sets;  // (target, canonical value), in call order
+};
+
+struct p2mt_circuit_data {
+  u32 degree_bits = 0, n = 0, num_selectors = 0, n_kinds = 0, n_cs = 0, n_slots = 0, n_pi = 0;
+  u32 kind[G_KINDS] = {}, sel[G_KINDS] = {}, gs[G_KINDS] = {}, ge[G_KINDS] = {}, counts[G_KINDS] = {};
+  u64 n_virtual = 0;
+  std::vector<Gen> gens;
+  std::vector<u64> public_inputs;
+  std::vector<u32> slot_of;  // target index -> value slot (one per copy-constraint class)
+  std::vector<std::pair<u32, u64>> const_inits;
+  std::vector<u64> h_cs;     // constants_sigmas values [n_cs][n]
+  u64 cs_cap[64] = {}, digest[4] = {};
+  p2mt_fri_params fri = {};
+  size_t fri_len = 0, proof_len = 0, n_digests = 0;
+  // generator schedule, valid for the input-slot set it was computed for
+  std::vector<u32> sched_inputs;
+  bool sched_valid = false;
+  u32 n_levels = 0;
+  // device memory: one allocation, carved
+  u64* d_base = nullptr;
+  u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_leaves = nullptr, *d_cs_dig = nullptr;
+  u64 *d_w_vals = nullptr, *d_w_coeffs = nullptr, *d_w_lde = nullptr, *d_w_leaves = nullptr, *d_w_dig = nullptr;
+  u64 *d_z_vals = nullptr, *d_z_coeffs = nullptr, *d_z_lde = nullptr, *d_z_leaves = nullptr, *d_z_dig = nullptr, *d_pp_q = nullptr;
+  u64 *d_q_vals = nullptr, *d_q_coeffs = nullptr, *d_q_lde = nullptr, *d_q_leaves = nullptr, *d_q_dig = nullptr;
+  u64 *d_head = nullptr, *d_open = nullptr, *d_chal = nullptr, *d_kis = nullptr, *d_vals = nullptr, *d_init = nullptr;
+  u32 *d_set = nullptr, *d_wire_slot = nullptr, *d_pi_slot = nullptr, *d_lvl = nullptr;
+  WOp* d_ops = nullptr;
+  int* d_err = nullptr;  // [0] witness conflict (op index + 1, or -1 unset public input), [1] zero denominator
+  size_t init_cap = 0, ops_cap = 0;
+  p2mt_challenger* ch = nullptr;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ builder (host)
+int cb_check(const p2mt_circuit_builder* b, u64 t, bool routable) {
+  if (is_wire(t)) {
+    if (wire_row(t) >= b->gates.size() || wire_col(t) >= kNumWires || (t & ~kWireFlag) >> 40) return p2mt::fail(P2MT_EINVAL, "circuit: bad wire target");
+    if (routable && wire_col(t) >= kNumRouted) return p2mt::fail(P2MT_EINVAL, "circuit: tried to route a wire that isn't routable");
+    return P2MT_OK;
+  }
+  if (t >= b->n_virtual) return p2mt::fail(P2MT_EINVAL, "circuit: unknown virtual target");
+  return P2MT_OK;
+}
+u64 cb_virtual(p2mt_circuit_builder* b) { return b->n_virtual++; }
+u64 cb_constant(p2mt_circuit_builder* b, u64 c) {
+  c %= gl::P;
+  auto it = b->const_to_target.find(c);
+  if (it != b->const_to_target.end()) return it->second;
+  const u64 t = cb_virtual(b);
+  b->const_to_target[c] = t;
+  b->target_to_const[t] = c;
+  return t;
+}
+int cb_connect(p2mt_circuit_builder* b, u64 x, u64 y) {
+  P2MT_TRY(cb_check(b, x, true));
+  P2MT_TRY(cb_check(b, y, true));
+  b->copies.emplace_back(x, y);
+  return P2MT_OK;
+}
+u32 cb_add_gate(p2mt_circuit_builder* b, int kind, u64 c0 = 0, u64 c1 = 0) {
+  b->gates.push_back(GateInst{kind, {c0, c1}});
+  return (u32)b->gates.size() - 1;
+}
+// gadgets/arithmetic.rs arithmetic(): const_0 * m0 * m1 + const_1 * addend
+int cb_arithmetic(p2mt_circuit_builder* b, u64 c0, u64 c1, u64 m0, u64 m1, u64 ad, u64* out) {
+  P2MT_TRY(cb_check(b, m0, true));
+  P2MT_TRY(cb_check(b, m1, true));
+  P2MT_TRY(cb_check(b, ad, true));
+  c0 %= gl::P;
+  c1 %= gl::P;
+  {  // arithmetic_special_cases
+    const u64 zero = cb_constant(b, 0);
+    auto cst = [&](u64 t, u64* v) {
+      auto it = b->target_to_const.find(t);
+      if (it == b->target_to_const.end()) return false;
+      *v = it->second;
+      return true;
+    };
+    u64 m0c = 0, m1c = 0, adc = 0;
+    const bool h0 = cst(m0, &m0c), h1 = cst(m1, &m1c), ha = cst(ad, &adc);
+    const bool first_zero = c0 == 0 || m0 == zero || m1 == zero, second_zero = c1 == 0 || ad == zero;
+    const bool first_known = first_zero || (h0 && h1), second_known = second_zero || ha;
+    if (first_known && second_known) {
+      const u64 f = first_zero ? 0 : h_mul(h_mul(m0c, m1c), c0), s = second_zero ? 0 : h_mul(adc, c1);
+      *out = cb_constant(b, h_add(f, s));
+      return P2MT_OK;
+    }
+    if (first_zero && c1 == 1) {
+      *out = ad;
+      return P2MT_OK;
+    }
+    if (second_zero) {
+      if (h0 && h_mul(m0c, c0) == 1) {
+        *out = m1;
+        return P2MT_OK;
+      }
+      if (h1 && h_mul(m1c, c0) == 1) {
+        *out = m0;
+        return P2MT_OK;
+      }
+    }
+  }
+  const auto op = std::make_tuple(c0, c1, m0, m1, ad);
+  auto hit = b->arith_results.find(op);
+  if (hit != b->arith_results.end()) {
+    *out = hit->second;
+    return P2MT_OK;
+  }
+  const auto key = std::make_pair(c0, c1);
+  u32 row, i;
+  auto sl = b->slots.find(key);
+  if (sl != b->slots.end()) {
+    row = sl->second.first;
+    i = sl->second.second;
+  } else {
+    row = cb_add_gate(b, G_ARITHMETIC, c0, c1);
+    i = 0;
+  }
+  if (i == kNumOps - 1) b->slots.erase(key);
+  else b->slots[key] = std::make_pair(row, i + 1);
+  b->copies.emplace_back(m0, wire_t(row, 4 * i));
+  b->copies.emplace_back(m1, wire_t(row, 4 * i + 1));
+  b->copies.emplace_back(ad, wire_t(row, 4 * i + 2));
+  Gen g{};
+  g.kind = GEN_ARITH;
+  g.row = row;
+  g.i = i;
+  g.c0 = c0;
+  g.c1 = c1;
+  b->gens.push_back(g);
+  *out = wire_t(row, 4 * i + 3);
+  b->arith_results[op] = *out;
+  return P2MT_OK;
+}
+// hash/poseidon.rs permute_swapped with swap = _false(): one PoseidonGate row
+int cb_permute(p2mt_circuit_builder* b, u64 (&state)[12]) {
+  const u32 row = cb_add_gate(b, G_POSEIDON);
+  b->copies.emplace_back(cb_constant(b, 0), wire_t(row, 24));
+  for (u32 i = 0; i < 12; ++i) b->copies.emplace_back(state[i], wire_t(row, i));
+  Gen g{};
+  g.kind = GEN_POSEIDON;
+  g.row = row;
+  b->gens.push_back(g);
+  for (u32 i = 0; i < 12; ++i) state[i] = wire_t(row, 12 + i);
+  return P2MT_OK;
+}
+int cb_hash_no_pad(p2mt_circuit_builder* b, const u64* in, size_t n, u64* out) {
+  for (size_t k = 0; k < n; ++k) P2MT_TRY(cb_check(b, in[k], true));
+  const u64 zero = cb_constant(b, 0);
+  u64 state[12];
+  for (auto& s : state) s = zero;
+  for (size_t off = 0; off < n; off += 8) {
+    for (size_t k = 0; k < 8 && off + k < n; ++k) state[k] = in[off + k];
+    P2MT_TRY(cb_permute(b, state));
+  }
+  for (int k = 0; k < 4; ++k) out[k] = state[k];
+  return P2MT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ witness fill (device)
+GL_DEV u64 ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+GL_DEV void st64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+GL_DEV u32 ld32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+GL_DEV void st32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+GL_DEV u64 fsub(u64 a, u64 b) { return gl::sub_c(a, gl::canon(b)); }
+
+// x^(p-2); inverse of 0 is 0
+GL_DEV u64 gl_inv(u64 x) {
+  auto sqn = [](u64 v, int k) {
+    for (int i = 0; i < k; ++i) v = gl::sqr(v);
+    return v;
+  };
+  const u64 t2 = gl::mul(gl::sqr(x), x);
+  const u64 t4 = gl::mul(sqn(t2, 2), t2);
+  const u64 t8 = gl::mul(sqn(t4, 4), t4);
+  const u64 t16 = gl::mul(sqn(t8, 8), t8);
+  const u64 t24 = gl::mul(sqn(t16, 8), t8);
+  const u64 t28 = gl::mul(sqn(t24, 4), t4);
+  const u64 t30 = gl::mul(sqn(t28, 2), t2);
+  const u64 t31 = gl::mul(gl::sqr(t30), x);
+  const u64 t32 = gl::mul(gl::sqr(t31), x);
+  return gl::mul(sqn(t31, 33), t32);
+}
+
+// PartitionWitness::set_target: a slot already holding a value must agree (plonky2 panics otherwise)
+GL_DEV void put(u64* vals, u32* set, u32 slot, u64 v, int* err, u32 op_index) {
+  v = gl::canon(v);
+  if (ld32(set + slot)) {
+    if (ld64(vals + slot) != v) atomicCAS(err, 0, (int)op_index + 1);
+  } else {
+    st64(vals + slot, v);
+    st32(set + slot, 1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__ pairs, u32 n_pairs, u64* vals, u32* set) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_pairs) return;
+  const u32 slot = (u32)pairs[2 * t];
+  vals[slot] = pairs[2 * t + 1];
+  set[slot] = 1;
+}
+
+// One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
+// and puts the PoseidonGate rows first).  PoseidonGenerator: one wavefront per row, lane w < 12 owns state word w.
+__global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                                                        u64* vals, u32* set, const u32* __restrict__ wire_slot, int* err,
+                                                        PermCtx ctx) {
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kBlock / 64;
+  for (u32 l = 0; l < n_levels; ++l) {
+    const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
+    for (u32 o = s + wave; o < s + np; o += n_waves) {  // wave-uniform
+      const u32* ws = wire_slot + (size_t)ops[o].a * kNumWires;
+      u64 x = lane < 12 ? ld64(vals + ws[lane]) : 0;
+      const u64 swap = ld64(vals + ws[24]);
+      const u64 partner = __shfl_xor((unsigned long long)x, 4);
+      if (lane < 4) {  // delta_i = swap * (in[i+4] - in[i]); the permutation runs on the swapped state
+        const u64 d = gl::canon(gl::mul(swap, fsub(partner, x)));
+        st64(vals + ws[25 + lane], d);
+        st32(set + ws[25 + lane], 1);
+        x = gl::add(x, d);
+      } else if (lane < 8) {
+        x = fsub(x, gl::mul(swap, fsub(x, partner)));
+      }
+      x = permute_wave_hook(x, ctx, [&](int r, u64 xv) {
+        if (lane >= 12 || r == 0) return;
+        u32 col;
+        if (r < 4) col = 29 + 12 * (r - 1) + lane;
+        else if (r < 26) {
+          if (lane != 0) return;
+          col = 65 + (r - 4);
+        } else col = 87 + 12 * (r - 26) + lane;
+        st64(vals + ws[col], gl::canon(xv));
+        st32(set + ws[col], 1);
+      });
+      if (lane < 12) put(vals, set, ws[12 + lane], x, err, o);
+    }
+    for (u32 o = s + np + tid; o < e; o += kBlock) {
+      const WOp op = ops[o];
+      if (op.kind == GEN_ARITH) {
+        const u64 m0 = ld64(vals + op.a), m1 = ld64(vals + op.b), ad = ld64(vals + op.c);
+        put(vals, set, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
+      } else {  // EqualityGenerator
+        const u64 x = ld64(vals + op.a), y = ld64(vals + op.b);
+        put(vals, set, op.out, x == y ? 1 : 0, err, o);
+        put(vals, set, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
+      }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+// PartitionWitness::full_witness: wires[col][row] = value of the wire's class (0 if nothing set it) + the public inputs
+__global__ __launch_bounds__(kBlock) void k_witness_scatter(const u64* __restrict__ vals, const u32* __restrict__ set,
+                                                            const u32* __restrict__ wire_slot, u32 log_n, u64* __restrict__ wires,
+                                                            const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
+                                                            int* err) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x, n = 1u << log_n;
+  if (t < n_pi) {
+    const u32 s = pi_slot[t];
+    if (!set[s]) atomicCAS(err, 0, -1);
+    pi_out[t] = vals[s];
+  }
+  if (t >= kNumWires * n) return;
+  const u32 col = t >> log_n, row = t & (n - 1);
+  const u32 s = wire_slot[(size_t)row * kNumWires + col];
+  wires[t] = set[s] ? vals[s] : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ quotient (device)
+struct QDesc {
+  u32 log_n, n_kinds, num_selectors, n_cs;
+  u32 kind[G_KINDS], sel[G_KINDS], gs[G_KINDS], ge[G_KINDS];
+  u64 zh[kQF], zh_inv[kQF];  // Z_H(x_i) = 7^n w_8^(i mod 8) - 1 and its inverse
+  u64 n_inv, w_big;
+};
+
+// compute_quotient_polys + eval_vanishing_poly_base: one lane per point x_i = 7 w^i of the LDE coset.  The committed batches
+// are read poly-major in leaf order ([poly][brev(i)]: coalesced over lanes); the quotient values go out in natural order for
+// the coset IFFT.  terms: L_0(x)(Z_c - 1) | partial-product checks | gate constraints (filtered), reduced with powers of
+// alpha_c (running power, so nothing is stored per term).
+__global__ __launch_bounds__(64) void k_quotient(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
+                                                 const u64* __restrict__ zl, const u64* __restrict__ pi_hash,
+                                                 const u64* __restrict__ chal, const u64* __restrict__ k_is,
+                                                 const u64* __restrict__ rc, u64* __restrict__ qvals) {
+  const u32 log_big = d.log_n + 3, big = 1u << log_big;
+  const u32 r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= big) return;
+  const u32 i = __brev(r) >> (32 - log_big);
+  const u32 r_next = __brev((i + kQF) & (big - 1)) >> (32 - log_big);
+  const u64 x = gl::mul(7, gl::pow(d.w_big, i));
+  auto CS = [&](u32 j) { return cs[(size_t)j * big + r]; };
+  auto W = [&](u32 j) { return wl[(size_t)j * big + r]; };
+  auto Z = [&](u32 j) { return zl[(size_t)j * big + r]; };
+  auto ZN = [&](u32 j) { return zl[(size_t)j * big + r_next]; };
+  u64 alpha[kNumCh], acc[kNumCh], ap[kNumCh];
+#pragma unroll
+  for (u32 c = 0; c < kNumCh; ++c) {
+    alpha[c] = chal[2 * kNumCh + c];
+    acc[c] = 0;
+    ap[c] = 1;
+  }
+  auto term = [&](u64 t) {
+#pragma unroll
+    for (u32 c = 0; c < kNumCh; ++c) {
+      acc[c] = gl::mul_add(ap[c], t, acc[c]);
+      ap[c] = gl::mul(ap[c], alpha[c]);
+    }
+  };
+  {  // L_0(x) (Z_c(x) - 1), L_0(x) = (x^n - 1) / (n (x - 1))
+    const u64 l0 = gl::mul(gl::mul(d.zh[i & (kQF - 1)], d.n_inv), gl_inv(gl::canon(gl::sub_c(x, 1))));
+    for (u32 c = 0; c < kNumCh; ++c) term(gl::mul(l0, gl::sub_c(Z(c), 1)));
+  }
+  const u32 sig0 = d.num_selectors + kNumConsts;
+  for (u32 c = 0; c < kNumCh; ++c) {  // check_partial_products
+    const u64 beta = chal[c], gamma = chal[kNumCh + c], bx = gl::mul(beta, x);
+#pragma unroll 1
+    for (u32 q = 0; q < kNumChunks; ++q) {
+      u64 num = 1, den = 1;
+#pragma unroll 1
+      for (u32 j = q * kQF; j < (q + 1) * kQF && j < kNumRouted; ++j) {
+        const u64 wg = gl::add(W(j), gamma);
+        num = gl::mul(num, gl::mul_add(bx, k_is[j], wg));
+        den = gl::mul(den, gl::mul_add(beta, CS(sig0 + j), wg));
+      }
+      const u64 prev = q == 0 ? Z(c) : Z(kNumCh + c * kNumProds + q - 1);
+      const u64 next = q == kNumProds ? ZN(c) : Z(kNumCh + c * kNumProds + q);
+      term(fsub(gl::mul(prev, num), gl::mul(next, den)));
+    }
+  }
+  // gate constraints: sum_g filter_g(selector) * sum_j alpha^j c_{g,j}, shifted by the alpha power reached so far
+  u64 head[kNumCh], ap0[kNumCh], tot[kNumCh];
+#pragma unroll
+  for (u32 c = 0; c < kNumCh; ++c) {
+    head[c] = acc[c];
+    ap0[c] = ap[c];
+    tot[c] = 0;
+  }
+  for (u32 g = 0; g < d.n_kinds; ++g) {
+#pragma unroll
+    for (u32 c = 0; c < kNumCh; ++c) {
+      acc[c] = 0;
+      ap[c] = 1;
+    }
+    const u32 kind = d.kind[g];
+    if (kind == G_NOOP) continue;
+    if (kind == G_CONSTANT) {
+      for (u32 j = 0; j < kNumConsts; ++j) term(gl::sub_c(CS(d.num_selectors + j), W(j)));
+    } else if (kind == G_PUBLIC_INPUT) {
+      for (u32 j = 0; j < 4; ++j) term(gl::sub_c(W(j), pi_hash[j]));
+    } else if (kind == G_ARITHMETIC) {
+      const u64 c0 = CS(d.num_selectors), c1 = CS(d.num_selectors + 1);
+#pragma unroll 1
+      for (u32 o = 0; o < kNumOps; ++o) {
+        const u64 prod = gl::mul(gl::mul(W(4 * o), W(4 * o + 1)), c0);
+        term(fsub(W(4 * o + 3), gl::mul_add(W(4 * o + 2), c1, prod)));
+      }
+    } else {  // PoseidonGate
+      const u64 swap = W(24);
+      term(gl::mul(swap, gl::sub_c(swap, 1)));
+      u64 s[12];
+#pragma unroll
+      for (u32 k = 0; k < 4; ++k) {
+        const u64 lhs = W(k), rhs = W(k + 4), delta = W(25 + k);
+        term(fsub(gl::mul(swap, gl::sub_c(rhs, lhs)), delta));
+        s[k] = gl::add(lhs, delta);
+        s[k + 4] = gl::sub_c(rhs, delta);
+      }
+#pragma unroll
+      for (u32 k = 8; k < 12; ++k) s[k] = W(k);
+#pragma unroll 1
+      for (u32 rd = 0; rd < POSEIDON_ROUNDS; ++rd) {
+#pragma unroll
+        for (u32 k = 0; k < 12; ++k) s[k] = gl::add_c(s[k], rc[12 * rd + k]);
+        if (rd >= 4 && rd < 26) {
+          const u64 in = W(65 + rd - 4);
+          term(fsub(s[0], in));
+          s[0] = gl::pow7(in);
+        } else {
+          if (rd != 0) {
+            const u32 base = rd < 4 ? 29 + 12 * (rd - 1) : 87 + 12 * (rd - 26);
+#pragma unroll
+            for (u32 k = 0; k < 12; ++k) {
+              const u64 in = W(base + k);
+              term(fsub(s[k], in));
+              s[k] = in;
+            }
+          }
+#pragma unroll
+          for (u32 k = 0; k < 12; ++k) s[k] = gl::pow7(s[k]);
+        }
+        poseidon::mds_layer<poseidon::MDS_MAD64>(s);
+      }
+#pragma unroll
+      for (u32 k = 0; k < 12; ++k) term(fsub(s[k], W(12 + k)));
+    }
+    // compute_filter
+    const u64 sv = CS(d.sel[g]);
+    u64 f = 1;
+    for (u32 k = d.gs[g]; k < d.ge[g]; ++k)
+      if (k != g) f = gl::mul(f, fsub((u64)k, sv));
+    if (d.num_selectors > 1) f = gl::mul(f, fsub(kUnusedSelector, sv));
+#pragma unroll
+    for (u32 c = 0; c < kNumCh; ++c) tot[c] = gl::mul_add(f, acc[c], tot[c]);
+  }
+  const u64 zh_inv = d.zh_inv[i & (kQF - 1)];
+#pragma unroll
+  for (u32 c = 0; c < kNumCh; ++c) qvals[(size_t)c * big + i] = gl::canon(gl::mul(gl::mul_add(tot[c], ap0[c], head[c]), zh_inv));
+}
+
+// OpeningSet order (constants | sigmas | wires | zs | zs_next | partial products | quotient) from the FriOpenings order the
+// challenger observed (... | zs | partial products | quotient || zs_next)
+__global__ __launch_bounds__(kBlock) void k_opening_set(const u64* __restrict__ fri_order, u64* __restrict__ out, u32 n_cs) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  const u32 a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot), total = a + 2 * kNumCh + tail;
+  if (t >= total) return;
+  u32 src;
+  if (t < a) src = t;
+  else if (t < a + 2 * kNumCh) src = a + tail + (t - a);
+  else src = t - 2 * kNumCh;
+  out[t] = fri_order[src];
+}
+
+size_t digests_count(size_t n, unsigned cap_height) {
+  size_t c = 0;
+  for (unsigned j = 0; ((size_t)n >> j) > ((size_t)1 << cap_height); ++j) c += n >> j;
+  return c;
+}
+
+inline u32 target_index(const p2mt_circuit_data* c, u64 t) {
+  return is_wire(t) ? wire_row(t) * kNumWires + wire_col(t) : (u32)(c->n * kNumWires + t);
+}
+
+int valid_target(const p2mt_circuit_data* c, u64 t) {
+  if (is_wire(t)) return wire_row(t) < c->n && wire_col(t) < kNumWires && !((t & ~kWireFlag) >> 40);
+  return t < c->n_virtual;
+}
+
+// Order the generators into levels for the given set of externally set slots (generate_partial_witness's watch lists,
+// resolved ahead of time: readiness does not depend on values).  Returns P2MT_EINVAL if some generator can never run.
+int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
+  if (c->sched_valid && c->sched_inputs == input_slots) return P2MT_OK;
+  c->sched_valid = false;
+  std::vector<int> set_level(c->n_slots, -1);
+  for (const auto& ci : c->const_inits) set_level[ci.first] = 0;
+  for (u32 s : input_slots) set_level[s] = 0;
+  auto slot_w = [&](u32 row, u32 col) { return c->slot_of[row * kNumWires + col]; };
+  struct Item {
+    int level;
+    WOp op;
+  };
+  std::vector<Item> items;
+  std::vector<char> done(c->gens.size(), 0);
+  size_t remaining = c->gens.size();
+  while (remaining) {
+    size_t progressed = 0;
+    for (size_t gi = 0; gi < c->gens.size(); ++gi) {
+      if (done[gi]) continue;
+      const Gen& g = c->gens[gi];
+      u32 ins[13], outs[123];
+      u32 n_in = 0, n_out = 0;
+      WOp op{};
+      op.kind = (u32)g.kind;
+      if (g.kind == GEN_ARITH) {
+        for (u32 k = 0; k < 3; ++k) ins[n_in++] = slot_w(g.row, 4 * g.i + k);
+        outs[n_out++] = slot_w(g.row, 4 * g.i + 3);
+        op.a = ins[0];
+        op.b = ins[1];
+        op.c = ins[2];
+        op.out = outs[0];
+        op.c0 = g.c0;
+        op.c1 = g.c1;
+      } else if (g.kind == GEN_EQUALITY) {
+        ins[n_in++] = c->slot_of[target_index(c, g.x)];
+        ins[n_in++] = c->slot_of[target_index(c, g.y)];
+        outs[n_out++] = c->slot_of[target_index(c, g.eq)];
+        outs[n_out++] = c->slot_of[target_index(c, g.inv)];
+        op.a = ins[0];
+        op.b = ins[1];
+        op.out = outs[0];
+        op.out2 = outs[1];
+      } else {  // PoseidonGenerator
+        for (u32 k = 0; k < 12; ++k) ins[n_in++] = slot_w(g.row, k);
+        ins[n_in++] = slot_w(g.row, 24);
+        for (u32 k = 12; k < kNumWires; ++k)
+          if (k != 24) outs[n_out++] = slot_w(g.row, k);
+        op.a = g.row;
+      }
+      int level = 0;
+      bool ready = true;
+      for (u32 k = 0; k < n_in; ++k) {
+        if (set_level[ins[k]] < 0) ready = false;
+        else level = std::max(level, set_level[ins[k]]);
+      }
+      if (!ready) continue;
+      for (u32 k = 0; k < n_out; ++k) level = std::max(level, set_level[outs[k]]);  // a check waits for the value it checks
+      ++level;
+      for (u32 k = 0; k < n_out; ++k)
+        if (set_level[outs[k]] < 0) set_level[outs[k]] = level;
+      items.push_back(Item{level, op});
+      done[gi] = 1;
+      ++progressed;
+    }
+    if (!progressed) return p2mt::fail(P2MT_EINVAL, "prove: some generators weren't run (a target they depend on was never set)");
+    remaining -= progressed;
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+    return a.level != b.level ? a.level < b.level : (a.op.kind == GEN_POSEIDON) > (b.op.kind == GEN_POSEIDON);
+  });
+  std::vector<WOp> ops(items.size());
+  std::vector<u32> lvl;
+  int cur = -1;
+  for (size_t k = 0; k < items.size(); ++k) {
+    ops[k] = items[k].op;
+    if (items[k].level != cur) {
+      cur = items[k].level;
+      lvl.push_back((u32)k);
+      lvl.push_back(0);
+    }
+    if (items[k].op.kind == GEN_POSEIDON) ++lvl.back();
+  }
+  lvl.push_back((u32)items.size());
+  c->n_levels = (u32)(lvl.size() / 2);
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipStreamSynchronize(st));  // the previous schedule may still be in use
+  if (!ops.empty()) P2MT_HIP(hipMemcpy(c->d_ops, ops.data(), ops.size() * sizeof(WOp), hipMemcpyHostToDevice));
+  P2MT_HIP(hipMemcpy(c->d_lvl, lvl.data(), lvl.size() * 4, hipMemcpyHostToDevice));
+  c->sched_inputs = input_slots;
+  c->sched_valid = true;
+  return P2MT_OK;
+}
+
+// witness fill for one PartialWitness: enqueue init / run / scatter (no synchronisation); wires -> d_w_vals, public inputs
+// -> the tail of the proof buffer
+int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
+  std::vector<u64> pairs;
+  std::unordered_map<u32, u64> seen;
+  pairs.reserve(2 * (c->const_inits.size() + pw->sets.size()));
+  for (const auto& ci : c->const_inits) {
+    seen[ci.first] = ci.second;
+    pairs.push_back(ci.first);
+    pairs.push_back(ci.second);
+  }
+  std::vector<u32> input_slots;
+  for (const auto& sv : pw->sets) {
+    if (!valid_target(c, sv.first)) return p2mt::fail(P2MT_EINVAL, "prove: witness sets a target that is not part of this circuit");
+    const u32 slot = c->slot_of[target_index(c, sv.first)];
+    auto it = seen.find(slot);
+    if (it != seen.end()) {
+      if (it->second != sv.second) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values");
+      continue;
+    }
+    seen[slot] = sv.second;
+    pairs.push_back(slot);
+    pairs.push_back(sv.second);
+    input_slots.push_back(slot);
+  }
+  std::sort(input_slots.begin(), input_slots.end());
+  P2MT_TRY(schedule(c, input_slots));
+  const size_t n_pairs = pairs.size() / 2;
+  if (n_pairs > c->init_cap) return p2mt::fail(P2MT_EINVAL, "prove: too many witness assignments");
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemsetAsync(c->d_set, 0, (size_t)c->n_slots * 4, st));
+  P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
+  P2MT_HIP(hipMemcpyAsync(c->d_init, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, st));  // pageable: staged before return
+  hipLaunchKernelGGL(k_witness_init, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
+                     c->d_set);
+  P2MT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
+                     c->d_set, (const u32*)c->d_wire_slot, c->d_err, p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
+  hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for((size_t)kNumWires * c->n)), dim3(kBlock), 0, st, (const u64*)c->d_vals,
+                     (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->degree_bits, c->d_w_vals, (const u32*)c->d_pi_slot,
+                     c->n_pi, d_pi_out, c->d_err);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+int witness_status(p2mt_circuit_data* c, const int* err) {
+  (void)c;
+  if (err[0] == -1) return p2mt::fail(P2MT_EINVAL, "prove: a public input target was never set");
+  if (err[0] != 0) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
+  if (err[1] != 0) return p2mt::fail(P2MT_EINVAL, "prove: zero denominator in the permutation argument (plonky2 panics on this division)");
+  return P2MT_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================== C ABI: builder
+extern "C" int p2mt_cb_create(p2mt_circuit_builder** out) {
+  if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  *out = new (std::nothrow) p2mt_circuit_builder;
+  return *out ? P2MT_OK : p2mt::fail(P2MT_ENOMEM, "out of host memory");
+}
+extern "C" int p2mt_cb_destroy(p2mt_circuit_builder* b) {
+  delete b;
+  return P2MT_OK;
+}
+#define CB_ARGS(b, out) \
+  if (!(b) || !(out)) return p2mt::fail(P2MT_EINVAL, "null pointer")
+extern "C" int p2mt_cb_add_virtual_target(p2mt_circuit_builder* b, p2mt_target* out) {
+  CB_ARGS(b, out);
+  *out = cb_virtual(b);
+  return P2MT_OK;
+}
+extern "C" int p2mt_cb_constant(p2mt_circuit_builder* b, uint64_t c, p2mt_target* out) {
+  CB_ARGS(b, out);
+  *out = cb_constant(b, c);
+  return P2MT_OK;
+}
+extern "C" int p2mt_cb_connect(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y) {
+  if (!b) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  return cb_connect(b, x, y);
+}
+extern "C" int p2mt_cb_arithmetic(p2mt_circuit_builder* b, uint64_t const_0, uint64_t const_1, p2mt_target multiplicand_0,
+                                  p2mt_target multiplicand_1, p2mt_target addend, p2mt_target* out) {
+  CB_ARGS(b, out);
+  return cb_arithmetic(b, const_0, const_1, multiplicand_0, multiplicand_1, addend, out);
+}
+extern "C" int p2mt_cb_add(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  CB_ARGS(b, out);
+  return cb_arithmetic(b, 1, 1, x, cb_constant(b, 1), y, out);
+}
+extern "C" int p2mt_cb_sub(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  CB_ARGS(b, out);
+  return cb_arithmetic(b, 1, gl::P - 1, x, cb_constant(b, 1), y, out);
+}
+extern "C" int p2mt_cb_mul(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  CB_ARGS(b, out);
+  return cb_arithmetic(b, 1, 0, x, y, x, out);
+}
+extern "C" int p2mt_cb_mul_add(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target z, p2mt_target* out) {
+  CB_ARGS(b, out);
+  return cb_arithmetic(b, 1, 1, x, y, z, out);
+}
+extern "C" int p2mt_cb_mul_sub(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target z, p2mt_target* out) {
+  CB_ARGS(b, out);
+  return cb_arithmetic(b, 1, gl::P - 1, x, y, z, out);
+}
+extern "C" int p2mt_cb_not(p2mt_circuit_builder* b, p2mt_target x, p2mt_target* out) {
+  CB_ARGS(b, out);
+  const u64 one = cb_constant(b, 1);
+  return cb_arithmetic(b, 1, gl::P - 1, one, one, x, out);
+}
+extern "C" int p2mt_cb_or(p2mt_circuit_builder* b, p2mt_target b1, p2mt_target b2, p2mt_target* out) {
+  CB_ARGS(b, out);
+  u64 res_minus_b2;
+  P2MT_TRY(cb_arithmetic(b, gl::P - 1, 1, b1, b2, b1, &res_minus_b2));
+  return cb_arithmetic(b, 1, 1, res_minus_b2, cb_constant(b, 1), b2, out);
+}
+extern "C" int p2mt_cb_assert_bool(p2mt_circuit_builder* b, p2mt_target x) {
+  if (!b) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  u64 z;
+  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, x, x, x, &z));
+  return cb_connect(b, z, cb_constant(b, 0));
+}
+extern "C" int p2mt_cb_add_virtual_bool_target_safe(p2mt_circuit_builder* b, p2mt_target* out) {
+  CB_ARGS(b, out);
+  *out = cb_virtual(b);
+  return p2mt_cb_assert_bool(b, *out);
+}
+extern "C" int p2mt_cb_is_equal(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  CB_ARGS(b, out);
+  P2MT_TRY(cb_check(b, x, true));
+  P2MT_TRY(cb_check(b, y, true));
+  const u64 zero = cb_constant(b, 0), one = cb_constant(b, 1);
+  const u64 equal = cb_virtual(b);
+  u64 not_equal, diff, not_equal_check, diff_normalized;
+  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, one, one, equal, &not_equal));
+  const u64 inv = cb_virtual(b);
+  Gen g{};
+  g.kind = GEN_EQUALITY;
+  g.x = x;
+  g.y = y;
+  g.eq = equal;
+  g.inv = inv;
+  b->gens.push_back(g);
+  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, x, one, y, &diff));
+  P2MT_TRY(cb_arithmetic(b, 1, 0, diff, inv, diff, &not_equal_check));
+  P2MT_TRY(cb_arithmetic(b, 1, 0, diff, equal, diff, &diff_normalized));
+  P2MT_TRY(cb_connect(b, diff_normalized, zero));
+  P2MT_TRY(cb_connect(b, not_equal, not_equal_check));
+  *out = equal;
+  return P2MT_OK;
+}
+extern "C" int p2mt_cb_hash_n_to_hash_no_pad(p2mt_circuit_builder* b, const p2mt_target* inputs, size_t n, p2mt_target* out) {
+  CB_ARGS(b, out);
+  if (n && !inputs) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  return cb_hash_no_pad(b, inputs, n, out);
+}
+extern "C" int p2mt_cb_hash_or_noop(p2mt_circuit_builder* b, const p2mt_target* inputs, size_t n, p2mt_target* out) {
+  CB_ARGS(b, out);
+  if (n && !inputs) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (n <= 4) {
+    const u64 zero = cb_constant(b, 0);
+    for (size_t k = 0; k < n; ++k) P2MT_TRY(cb_check(b, inputs[k], false));
+    for (size_t k = 0; k < 4; ++k) out[k] = k < n ? inputs[k] : zero;
+    return P2MT_OK;
+  }
+  return cb_hash_no_pad(b, inputs, n, out);
+}
+extern "C" int p2mt_cb_register_public_inputs(p2mt_circuit_builder* b, const p2mt_target* targets, size_t n) {
+  if (!b || (n && !targets)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  for (size_t k = 0; k < n; ++k) P2MT_TRY(cb_check(b, targets[k], true));
+  b->public_inputs.insert(b->public_inputs.end(), targets, targets + n);
+  return P2MT_OK;
+}
+extern "C" size_t p2mt_cb_num_gates(const p2mt_circuit_builder* b) { return b ? b->gates.size() : 0; }
+
+// ==================================================================================================== build()
+extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
+  if (!c) return P2MT_OK;
+  if (c->ch) p2mt_challenger_destroy(c->ch);
+  if (c->d_base) {
+    (void)hipStreamSynchronize(rt().stream);
+    (void)hipFree(c->d_base);
+  }
+  delete c;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
+  CB_ARGS(b, out);
+  P2MT_TRY(p2mt::ensure_init());
+  // public-input hash routed into a PublicInputGate
+  u64 pi_hash_t[4];
+  P2MT_TRY(cb_hash_no_pad(b, b->public_inputs.data(), b->public_inputs.size(), pi_hash_t));
+  const u32 pi_gate = cb_add_gate(b, G_PUBLIC_INPUT);
+  for (u32 k = 0; k < 4; ++k) b->copies.emplace_back(pi_hash_t[k], wire_t(pi_gate, k));
+  // one ConstantGate slot per distinct constant, in increasing canonical order
+  {
+    std::vector<std::pair<u32, u32>> free_slots;
+    for (const auto& ct : b->const_to_target) {
+      if (free_slots.empty()) {
+        const u32 row = cb_add_gate(b, G_CONSTANT);
+        for (u32 k = kNumConsts; k-- > 0;) free_slots.emplace_back(row, k);
+      }
+      const auto sl = free_slots.back();
+      free_slots.pop_back();
+      b->gates[sl.first].c[sl.second] = ct.first;
+      b->copies.emplace_back(wire_t(sl.first, sl.second), ct.second);
+      Gen g{};
+      g.kind = GEN_CONST;
+      g.row = sl.first;
+      g.i = sl.second;
+      g.c0 = ct.first;
+      b->gens.push_back(g);
+    }
+  }
+  while (b->gates.size() < 2 || (b->gates.size() & (b->gates.size() - 1))) cb_add_gate(b, G_NOOP);
+  const size_t n = b->gates.size();
+  if (n > ((size_t)1 << 12)) return p2mt::fail(P2MT_EINVAL, "build: more than 2^12 rows (LDE kernels cover degree_bits <= 12)");
+
+  p2mt_circuit_data* c = new (std::nothrow) p2mt_circuit_data;
+  if (!c) return p2mt::fail(P2MT_ENOMEM, "out of host memory");
+  struct Guard {
+    p2mt_circuit_data* c;
+    ~Guard() {
+      if (c) p2mt_circuit_destroy(c);
+    }
+  } guard{c};
+  c->n = (u32)n;
+  c->degree_bits = (u32)__builtin_ctzll((unsigned long long)n);
+  c->n_virtual = b->n_virtual;
+  c->public_inputs = b->public_inputs;
+  c->n_pi = (u32)b->public_inputs.size();
+  for (const auto& g : b->gates) ++c->counts[g.kind];
+  // gate types present, sorted by (degree, id); selector groups (gates/selectors.rs selector_polynomials)
+  u32 index_of[G_KINDS] = {};
+  for (u32 k = 0; k < G_KINDS; ++k)
+    if (c->counts[k]) {
+      index_of[k] = c->n_kinds;
+      c->kind[c->n_kinds++] = k;
+    }
+  const u32 max_degree = kQF + 1;
+  u32 group_of[G_KINDS] = {};
+  if (kGateDegree[c->kind[c->n_kinds - 1]] + c->n_kinds - 1 <= max_degree) {
+    c->num_selectors = 1;
+    for (u32 g = 0; g < c->n_kinds; ++g) {
+      c->gs[g] = 0;
+      c->ge[g] = c->n_kinds;
+      group_of[g] = 0;
+    }
+  } else {
+    u32 start = 0;
+    while (start < c->n_kinds) {
+      u32 size = 0;
+      while (start + size < c->n_kinds && size + kGateDegree[c->kind[start + size]] < max_degree) ++size;
+      for (u32 g = start; g < start + size; ++g) {
+        c->gs[g] = start;
+        c->ge[g] = start + size;
+        group_of[g] = c->num_selectors;
+      }
+      ++c->num_selectors;
+      start += size;
+    }
+  }
+  for (u32 g = 0; g < c->n_kinds; ++g) c->sel[g] = group_of[g];
+  const u32 n_cs = c->n_cs = c->num_selectors + kNumConsts + kNumRouted;
+  c->h_cs.assign((size_t)n_cs * n, 0);
+  for (size_t row = 0; row < n; ++row) {
+    const u32 gi = index_of[b->gates[row].kind];
+    for (u32 s = 0; s < c->num_selectors; ++s) c->h_cs[(size_t)s * n + row] = s == group_of[gi] ? gi : kUnusedSelector;
+    for (u32 k = 0; k < kNumConsts; ++k) c->h_cs[(size_t)(c->num_selectors + k) * n + row] = b->gates[row].c[k];
+  }
+  // copy constraints -> classes (Forest) -> value slots and sigma (plonk/permutation_argument.rs)
+  const size_t n_targets = n * kNumWires + b->n_virtual;
+  std::vector<u32> parent(n_targets);
+  for (size_t k = 0; k < n_targets; ++k) parent[k] = (u32)k;
+  auto find = [&](u32 x) {
+    while (parent[x] != x) {
+      parent[x] = parent[parent[x]];
+      x = parent[x];
+    }
+    return x;
+  };
+  for (const auto& cp : b->copies) {
+    const u32 a = find(target_index(c, cp.first)), d = find(target_index(c, cp.second));
+    if (a != d) parent[d] = a;
+  }
+  c->slot_of.assign(n_targets, 0);
+  {
+    std::vector<u32> slot_of_rep(n_targets, 0xFFFFFFFFu);
+    for (size_t k = 0; k < n_targets; ++k) {
+      const u32 r = find((u32)k);
+      if (slot_of_rep[r] == 0xFFFFFFFFu) slot_of_rep[r] = c->n_slots++;
+      c->slot_of[k] = slot_of_rep[r];
+    }
+  }
+  u64 k_is[kNumRouted];
+  k_is[0] = 1;
+  for (u32 j = 1; j < kNumRouted; ++j) k_is[j] = h_mul(k_is[j - 1], 7);
+  {
+    // members of every class in row-major order; sigma sends a wire to the next member of its class (cyclically)
+    std::vector<u32> first(c->n_slots, 0xFFFFFFFFu), last(c->n_slots, 0xFFFFFFFFu), next(n * kNumRouted, 0);
+    for (size_t row = 0; row < n; ++row)
+      for (u32 col = 0; col < kNumRouted; ++col) {
+        const u32 s = c->slot_of[row * kNumWires + col], id = (u32)(row * kNumRouted + col);
+        if (first[s] == 0xFFFFFFFFu) first[s] = id;
+        else next[last[s]] = id;
+        last[s] = id;
+        next[id] = first[s];
+      }
+    std::vector<u64> subgroup(n);
+    const u64 g = h_root_of_unity(c->degree_bits);
+    subgroup[0] = 1;
+    for (size_t k = 1; k < n; ++k) subgroup[k] = h_mul(subgroup[k - 1], g);
+    const u32 s0 = c->num_selectors + kNumConsts;
+    for (u32 col = 0; col < kNumRouted; ++col)
+      for (size_t row = 0; row < n; ++row) {
+        const u32 nb = next[row * kNumRouted + col];
+        c->h_cs[(size_t)(s0 + col) * n + row] = h_mul(k_is[nb % kNumRouted], subgroup[nb / kNumRouted]);
+      }
+  }
+  for (const auto& g : b->gens) {
+    if (g.kind == GEN_CONST) c->const_inits.emplace_back(c->slot_of[g.row * kNumWires + g.i], g.c0);
+    else c->gens.push_back(g);
+  }
+  P2MT_TRY(p2mt_fri_params_standard(c->degree_bits, &c->fri));
+  {
+    const uint64_t np[4] = {n_cs, kNumWires, kNumZs, kNumQuot};
+    c->fri_len = p2mt_fri_proof_len(&c->fri, 4, np);
+    if (c->fri_len == 0) return p2mt::fail(P2MT_EINVAL, "build: unsupported FRI shape for this degree");
+  }
+  const size_t n_open = n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
+  c->proof_len = 3 * 64 + 2 * n_open + c->fri_len + c->n_pi;
+
+  // ---- device memory
+  const size_t big = n << kRateBits;
+  const size_t nd = c->n_digests = digests_count(big, kCapHeight);
+  size_t words = 0;
+  auto carve = [&](size_t w) {
+    const size_t at = words;
+    words += (w + 3) & ~(size_t)3;
+    return at;
+  };
+  struct Batch {
+    size_t vals, coeffs, lde, leaves, dig;
+  };
+  auto carve_batch = [&](size_t polys) { return Batch{carve(polys * n), carve(polys * n), carve(polys * big), carve(polys * big), carve(4 * (nd ? nd : 1))}; };
+  const Batch bc = carve_batch(n_cs), bw = carve_batch(kNumWires), bz = carve_batch(kNumZs), bq = carve_batch(kNumQuot);
+  const size_t o_qvals = carve(kNumCh * big), o_ppq = carve((size_t)kNumCh * kNumChunks * n);
+  const size_t o_head = carve(8 + c->proof_len), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
+  const size_t o_vals = carve(c->n_slots), o_set = carve((c->n_slots + 1) / 2);
+  c->init_cap = c->const_inits.size() + n_targets;
+  const size_t o_init = carve(2 * c->init_cap);
+  const size_t o_wslot = carve((n * kNumWires + 1) / 2), o_pislot = carve((c->n_pi + 2) / 2);
+  c->ops_cap = c->gens.size();
+  const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2), o_err = carve(1);
+  if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");
+  u64* base = c->d_base;
+  c->d_cs_vals = base + bc.vals, c->d_cs_coeffs = base + bc.coeffs, c->d_cs_lde = base + bc.lde, c->d_cs_leaves = base + bc.leaves, c->d_cs_dig = base + bc.dig;
+  c->d_w_vals = base + bw.vals, c->d_w_coeffs = base + bw.coeffs, c->d_w_lde = base + bw.lde, c->d_w_leaves = base + bw.leaves, c->d_w_dig = base + bw.dig;
+  c->d_z_vals = base + bz.vals, c->d_z_coeffs = base + bz.coeffs, c->d_z_lde = base + bz.lde, c->d_z_leaves = base + bz.leaves, c->d_z_dig = base + bz.dig;
+  c->d_q_coeffs = base + bq.coeffs, c->d_q_lde = base + bq.lde, c->d_q_leaves = base + bq.leaves, c->d_q_dig = base + bq.dig;
+  c->d_q_vals = base + o_qvals, c->d_pp_q = base + o_ppq;
+  c->d_head = base + o_head, c->d_open = base + o_open, c->d_chal = base + o_chal, c->d_kis = base + o_kis;
+  c->d_vals = base + o_vals, c->d_set = (u32*)(base + o_set), c->d_init = base + o_init;
+  c->d_wire_slot = (u32*)(base + o_wslot), c->d_pi_slot = (u32*)(base + o_pislot);
+  c->d_ops = (WOp*)(base + o_ops), c->d_lvl = (u32*)(base + o_lvl), c->d_err = (int*)(base + o_err);
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemsetAsync(c->d_base, 0, words * 8, st));
+  std::vector<u32> pi_slot(c->n_pi);
+  for (u32 k = 0; k < c->n_pi; ++k) pi_slot[k] = c->slot_of[target_index(c, c->public_inputs[k])];
+  P2MT_HIP(hipMemcpyAsync(c->d_cs_vals, c->h_cs.data(), c->h_cs.size() * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(c->d_kis, k_is, sizeof k_is, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(c->d_wire_slot, c->slot_of.data(), n * kNumWires * 4, hipMemcpyHostToDevice, st));
+  if (c->n_pi) P2MT_HIP(hipMemcpyAsync(c->d_pi_slot, pi_slot.data(), c->n_pi * 4, hipMemcpyHostToDevice, st));
+  // constants_sigmas commitment and the circuit digest = hash_no_pad(cap || hash_no_pad([]) || degree_bits)
+  u64* d_cap = c->d_head + 8;  // borrowed: the proof buffer is not in use yet
+  P2MT_TRY(p2mt::commit_batch_dev(c->d_cs_vals, 1, n_cs, c->degree_bits, kRateBits, kCapHeight, c->d_cs_coeffs, c->d_cs_lde,
+                                  c->d_cs_leaves, nd ? c->d_cs_dig : nullptr, d_cap));
+  const u64 tail[5] = {0, 0, 0, 0, c->degree_bits};
+  P2MT_HIP(hipMemcpyAsync(d_cap + 64, tail, sizeof tail, hipMemcpyHostToDevice, st));
+  P2MT_TRY(p2mt::launch_hash_rows_dev(d_cap, 1, 69, 0, c->d_head));
+  P2MT_HIP(hipMemcpyAsync(c->cs_cap, d_cap, sizeof c->cs_cap, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(c->digest, c->d_head, sizeof c->digest, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  P2MT_TRY(p2mt_challenger_create(&c->ch));
+  guard.c = nullptr;
+  *out = c;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_circuit_get_info(const p2mt_circuit_data* c, p2mt_circuit_info* info) {
+  if (!c || !info) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  info->degree_bits = c->degree_bits;
+  info->num_gate_types = c->n_kinds;
+  info->num_selectors = c->num_selectors;
+  info->num_constants_sigmas = c->n_cs;
+  info->num_public_inputs = c->n_pi;
+  info->num_partial_products = kNumProds;
+  info->proof_len = c->proof_len;
+  info->fri_proof_len = c->fri_len;
+  for (u32 k = 0; k < G_KINDS; ++k) info->gate_counts[k] = c->counts[k];
+  for (u32 g = 0; g < G_KINDS; ++g) {
+    info->gate_kinds[g] = g < c->n_kinds ? c->kind[g] : 0;
+    info->gate_selector[g] = g < c->n_kinds ? c->sel[g] : 0;
+    info->group_start[g] = g < c->n_kinds ? c->gs[g] : 0;
+    info->group_end[g] = g < c->n_kinds ? c->ge[g] : 0;
+  }
+  return P2MT_OK;
+}
+extern "C" int p2mt_circuit_public_inputs(const p2mt_circuit_data* c, p2mt_target* out) {
+  if (!c || (c->n_pi && !out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  for (u32 k = 0; k < c->n_pi; ++k) out[k] = c->public_inputs[k];
+  return P2MT_OK;
+}
+extern "C" int p2mt_circuit_constants_sigmas(const p2mt_circuit_data* c, uint64_t* values_out, uint64_t* cap_out, uint64_t* digest_out) {
+  if (!c) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (values_out) std::copy(c->h_cs.begin(), c->h_cs.end(), values_out);
+  if (cap_out) std::copy(c->cs_cap, c->cs_cap + 64, cap_out);
+  if (digest_out) std::copy(c->digest, c->digest + 4, digest_out);
+  return P2MT_OK;
+}
+
+// ==================================================================================================== PartialWitness
+extern "C" int p2mt_pw_create(p2mt_partial_witness** out) {
+  if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  *out = new (std::nothrow) p2mt_partial_witness;
+  return *out ? P2MT_OK : p2mt::fail(P2MT_ENOMEM, "out of host memory");
+}
+extern "C" int p2mt_pw_destroy(p2mt_partial_witness* pw) {
+  delete pw;
+  return P2MT_OK;
+}
+extern "C" int p2mt_pw_set_target(p2mt_partial_witness* pw, p2mt_target t, uint64_t value) {
+  if (!pw) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  pw->sets.emplace_back(t, value % gl::P);
+  return P2MT_OK;
+}
+extern "C" int p2mt_pw_clear(p2mt_partial_witness* pw) {
+  if (!pw) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  pw->sets.clear();
+  return P2MT_OK;
+}
+
+// ==================================================================================================== prove
+extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* wires_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || !pw || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_TRY(fill_witness(c, pw));
+  hipStream_t st = rt().stream;
+  int err[2] = {0, 0};
+  P2MT_HIP(hipMemcpyAsync(wires_out, c->d_w_vals, (size_t)kNumWires * c->n * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return witness_status(c, err);
+}
+
+extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, size_t proof_cap) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || !pw || !proof_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (proof_cap < c->proof_len) return p2mt::fail(P2MT_EINVAL, "prove: proof buffer too small (p2mt_circuit_get_info)");
+  hipStream_t st = rt().stream;
+  const u32 n = c->n, log_n = c->degree_bits, log_big = log_n + kRateBits, big = n << kRateBits, n_cs = c->n_cs;
+  u64 *d_digest = c->d_head, *d_pi_hash = c->d_head + 4, *d_proof = c->d_head + 8;
+  u64 *d_w_cap = d_proof, *d_z_cap = d_proof + 64, *d_q_cap = d_proof + 128, *d_open_set = d_proof + 192;
+  const size_t n_open = n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
+  u64* d_fri = d_open_set + 2 * n_open;
+  u64* d_pi = d_proof + (c->proof_len - c->n_pi);
+
+  // witness, public-input hash, wires commitment
+  P2MT_TRY(fill_witness(c, pw));
+  P2MT_HIP(hipMemcpyAsync(d_digest, c->digest, 32, hipMemcpyHostToDevice, st));
+  if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(d_pi, 1, c->n_pi, 0, d_pi_hash));
+  else P2MT_HIP(hipMemsetAsync(d_pi_hash, 0, 32, st));
+  P2MT_TRY(p2mt::commit_batch_dev(c->d_w_vals, 1, kNumWires, log_n, kRateBits, kCapHeight, c->d_w_coeffs, c->d_w_lde, c->d_w_leaves,
+                                  c->n_digests ? c->d_w_dig : nullptr, d_w_cap));
+  // challenger: circuit digest, public-input hash, wires cap -> betas, gammas
+  P2MT_TRY(p2mt_challenger_reset(c->ch));
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_digest, 8 + 64, c->d_chal, 2 * kNumCh));
+  // Z and partial products, committed with Z at the front
+  P2MT_TRY(p2mt::partial_products_async_dev(c->d_w_vals, c->d_cs_vals + (size_t)(c->num_selectors + kNumConsts) * n, c->d_kis,
+                                            c->d_chal, c->d_chal + kNumCh, kNumCh, kNumRouted, log_n, kQF, c->d_pp_q, c->d_z_vals,
+                                            c->d_err + 1));
+  P2MT_TRY(p2mt::commit_batch_dev(c->d_z_vals, 1, kNumZs, log_n, kRateBits, kCapHeight, c->d_z_coeffs, c->d_z_lde, c->d_z_leaves,
+                                  c->n_digests ? c->d_z_dig : nullptr, d_z_cap));
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_z_cap, 64, c->d_chal + 2 * kNumCh, kNumCh));  // alphas
+  // quotient polynomials
+  QDesc qd{};
+  qd.log_n = log_n;
+  qd.n_kinds = c->n_kinds;
+  qd.num_selectors = c->num_selectors;
+  qd.n_cs = n_cs;
+  for (u32 g = 0; g < G_KINDS; ++g) qd.kind[g] = c->kind[g], qd.sel[g] = c->sel[g], qd.gs[g] = c->gs[g], qd.ge[g] = c->ge[g];
+  {
+    const u64 shift_n = h_pow(7, n), w_q = h_root_of_unity(3);
+    for (u32 k = 0; k < kQF; ++k) {
+      qd.zh[k] = h_add(h_mul(shift_n, h_pow(w_q, k)), gl::P - 1);
+      qd.zh_inv[k] = h_pow(qd.zh[k], gl::P - 2);
+    }
+    qd.n_inv = h_pow(n, gl::P - 2);
+    qd.w_big = h_root_of_unity(log_big);
+  }
+  hipLaunchKernelGGL(k_quotient, dim3((big + 63) / 64), dim3(64), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
+                     (const u64*)c->d_z_lde, (const u64*)d_pi_hash, (const u64*)c->d_chal, (const u64*)c->d_kis,
+                     (const u64*)rt().d_rc, c->d_q_vals);
+  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(p2mt::coset_ifft_dev(c->d_q_vals, log_big, kNumCh, 7, c->d_q_coeffs));
+  P2MT_TRY(p2mt::commit_batch_dev(c->d_q_coeffs, 0, kNumQuot, log_n, kRateBits, kCapHeight, nullptr, c->d_q_lde, c->d_q_leaves,
+                                  c->n_digests ? c->d_q_dig : nullptr, d_q_cap));
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_q_cap, 64, c->d_chal + 3 * kNumCh, 2));  // zeta
+  u64 zeta[2];
+  P2MT_HIP(hipMemcpyAsync(zeta, c->d_chal + 3 * kNumCh, 16, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  {  // plonky2: ensure!(zeta^n != 1)
+    u64 a = zeta[0], b2 = zeta[1];
+    for (u32 k = 0; k < log_n; ++k) {
+      const u64 na = h_add(h_mul(a, a), h_mul(7, h_mul(b2, b2))), nb = h_mul(2, h_mul(a, b2));
+      a = na;
+      b2 = nb;
+    }
+    if (a == 1 && b2 == 0) return p2mt::fail(P2MT_EINVAL, "prove: opening point is in the subgroup");
+  }
+  // openings at zeta (every polynomial) and g zeta (the Z's), observed; then the FRI proof
+  p2mt_fri_oracle oracles[4] = {{c->d_cs_coeffs, c->d_cs_leaves, c->d_cs_dig, n_cs},
+                                {c->d_w_coeffs, c->d_w_leaves, c->d_w_dig, kNumWires},
+                                {c->d_z_coeffs, c->d_z_leaves, c->d_z_dig, kNumZs},
+                                {c->d_q_coeffs, c->d_q_leaves, c->d_q_dig, kNumQuot}};
+  std::vector<uint32_t> all_polys, next_polys;
+  for (u32 o = 0; o < 4; ++o)
+    for (u32 k = 0; k < oracles[o].n_polys; ++k) {
+      all_polys.push_back(o);
+      all_polys.push_back(k);
+    }
+  for (u32 k = 0; k < kNumCh; ++k) {
+    next_polys.push_back(2);
+    next_polys.push_back(k);
+  }
+  const u64 g = h_root_of_unity(log_n);
+  p2mt_fri_batch batches[2] = {{{zeta[0], zeta[1]}, all_polys.data(), all_polys.size() / 2},
+                               {{h_mul(zeta[0], g), h_mul(zeta[1], g)}, next_polys.data(), next_polys.size() / 2}};
+  P2MT_TRY(p2mt_fri_openings_dev(oracles, 4, batches, 2, log_n, c->d_open));
+  P2MT_TRY(p2mt_challenger_observe_dev(c->ch, c->d_open, 2 * n_open));
+  hipLaunchKernelGGL(k_opening_set, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs);
+  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(p2mt_fri_prove_openings_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri));
+  int err[2] = {0, 0};
+  P2MT_HIP(hipMemcpyAsync(proof_out, d_proof, c->proof_len * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return witness_status(c, err);
+}
+
+// intermediates of the last p2mt_circuit_prove on this circuit (parity tests)
+extern "C" int p2mt_circuit_prove_trace(const p2mt_circuit_data* c, int what, uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  const u64* src;
+  size_t words;
+  switch (what) {
+    case 0: src = c->d_w_vals, words = (size_t)kNumWires * c->n; break;
+    case 1: src = c->d_z_vals, words = (size_t)kNumZs * c->n; break;
+    case 2: src = c->d_q_coeffs, words = (size_t)kNumQuot * c->n; break;
+    case 3: src = c->d_chal, words = 8; break;
+    case 4: src = c->d_head + 4, words = 4; break;
+    default: return p2mt::fail(P2MT_EINVAL, "prove_trace: unknown item");
+  }
+  P2MT_HIP(hipMemcpyAsync(out, src, words * 8, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}

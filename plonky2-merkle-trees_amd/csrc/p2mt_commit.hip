@@ -634,10 +634,9 @@ extern "C" int p2mt_merkle_cap_commit(const uint64_t* leaves, size_t n, size_t w
 }
 
 // =================================================================== PolynomialBatch::from_values / from_coeffs
-extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_values, size_t n_polys, unsigned log_n,
-                                                unsigned rate_bits, unsigned cap_height, uint64_t* d_leaves_out,
-                                                uint64_t* d_digests_out, uint64_t* d_cap_out) {
-  P2MT_TRY(p2mt::ensure_init());
+int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_polys, unsigned log_n, unsigned rate_bits,
+                           unsigned cap_height, uint64_t* d_coeffs_out, uint64_t* d_lde_out, uint64_t* d_leaves_out,
+                           uint64_t* d_digests_out, uint64_t* d_cap_out) {
   if (!d_polys || !d_cap_out || n_polys == 0) return p2mt::fail(P2MT_EINVAL, "bad argument");
   const unsigned log_big = log_n + rate_bits;
   if (cap_height > log_big) return p2mt::fail(P2MT_EINVAL, "cap_height exceeds tree height");
@@ -648,16 +647,19 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
     u64* buf;
     P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8 * 2, (void**)&buf));
     u64* work = buf + n_polys * n;
+    u64* coeffs = d_coeffs_out ? d_coeffs_out : buf;
     P2MT_HIP(hipMemcpyAsync(work, d_polys, n_polys * n * 8, hipMemcpyDeviceToDevice, st));
     P2MT_TRY(ntt_dif_dev(work, log_n, n_polys, 1));
     const u64 n_inv = h_pow((u64)n % gl::P, gl::P - 2);
-    hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(n_polys * n)), dim3(kBlock), 0, st, (const u64*)work, buf, log_n, n_polys,
+    hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(n_polys * n)), dim3(kBlock), 0, st, (const u64*)work, coeffs, log_n, n_polys,
                        n_inv);
     P2MT_LAUNCH_CHECK();
-    d_coeffs = buf;
+    d_coeffs = coeffs;
+  } else if (d_coeffs_out && d_coeffs_out != d_polys) {
+    P2MT_HIP(hipMemcpyAsync(d_coeffs_out, d_polys, n_polys * n * 8, hipMemcpyDeviceToDevice, st));
   }
-  u64* lde;
-  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
+  u64* lde = d_lde_out;
+  if (!lde) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
   P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
   if (d_leaves_out) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
@@ -675,6 +677,36 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
     P2MT_DISPATCH(k_hash_columns, grid_for(big), kBlock, (const u64*)lde, n_polys, big, d_level0);
   }
   return merkle_levels_to_cap(d_level0, big, cap_height, cap_is_leaves ? nullptr : d_digests_out, d_cap_out);
+}
+
+extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_values, size_t n_polys, unsigned log_n,
+                                                unsigned rate_bits, unsigned cap_height, uint64_t* d_leaves_out,
+                                                uint64_t* d_digests_out, uint64_t* d_cap_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  return p2mt::commit_batch_dev(d_polys, is_values, n_polys, log_n, rate_bits, cap_height, nullptr, nullptr, d_leaves_out,
+                                d_digests_out, d_cap_out);
+}
+
+// PolynomialValues::coset_ifft(shift): plain IFFT gives c_k shift^k; the bit-reversal pass also divides by n shift^k.
+namespace {
+__global__ __launch_bounds__(kBlock) void k_bitrev_coset_scale(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_n,
+                                                               size_t n_polys, u64 n_inv, u64 shift_inv) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= (n_polys << log_n)) return;
+  const size_t poly = t >> log_n, q = t & (((size_t)1 << log_n) - 1);
+  const size_t r = log_n ? (__brevll(q) >> (64 - log_n)) : 0;
+  out[(poly << log_n) + r] = cmul(cmul(in[t], n_inv), gl::pow(shift_inv, r));
+}
+}  // namespace
+
+int p2mt::coset_ifft_dev(uint64_t* d_vals, unsigned log_n, size_t n_polys, uint64_t shift, uint64_t* d_coeffs_out) {
+  if (!d_vals || !d_coeffs_out || n_polys == 0 || log_n > 32) return p2mt::fail(P2MT_EINVAL, "coset_ifft: bad argument");
+  P2MT_TRY(ntt_dif_dev(d_vals, log_n, n_polys, 1));
+  const u64 n_inv = h_pow(((u64)1 << log_n) % gl::P, gl::P - 2), shift_inv = h_pow(shift % gl::P, gl::P - 2);
+  hipLaunchKernelGGL(k_bitrev_coset_scale, dim3(grid_for(n_polys << log_n)), dim3(kBlock), 0, rt().stream, (const u64*)d_vals,
+                     d_coeffs_out, log_n, n_polys, n_inv, shift_inv);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
 }
 
 extern "C" int p2mt_polynomial_batch_commit(const uint64_t* polys, int is_values, size_t n_polys, unsigned log_n,

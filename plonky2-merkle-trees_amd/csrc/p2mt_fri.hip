@@ -471,6 +471,21 @@ extern "C" int p2mt_challenger_observe(p2mt_challenger* c, const uint64_t* eleme
   return P2MT_OK;
 }
 
+extern "C" int p2mt_challenger_reset(p2mt_challenger* c) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_HIP(hipMemsetAsync(c->d, 0, sizeof(ChState), rt().stream));
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_challenger_duplex_dev(p2mt_challenger* c, const uint64_t* d_elements, size_t n_obs, uint64_t* d_out,
+                                          size_t n_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || (n_obs && !d_elements) || (n_out && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (n_obs == 0 && n_out == 0) return P2MT_OK;
+  return launch_challenger(c->d, d_elements, n_obs, d_out, n_out);
+}
+
 extern "C" int p2mt_challenger_get_challenges_dev(p2mt_challenger* c, size_t n, uint64_t* d_out) {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");

@@ -42,12 +42,12 @@ GL_DEV u64 gl_inv(u64 x) {
 
 // q[(c * num_chunks + k) * n + i]; *zero_den is set when a denominator product vanishes (plonky2 panics there)
 __global__ __launch_bounds__(kBlock) void k_pp_chunks(const u64* __restrict__ wires, const u64* __restrict__ sigmas,
-                                                      const u64* __restrict__ k_is, const u64* __restrict__ bg, u32 num_routed,
-                                                      u32 log_n, u32 chunk, u32 num_chunks, u64 w, u64* __restrict__ q,
-                                                      int* __restrict__ zero_den) {
+                                                      const u64* __restrict__ k_is, const u64* __restrict__ betas,
+                                                      const u64* __restrict__ gammas, u32 num_routed, u32 log_n, u32 chunk,
+                                                      u32 num_chunks, u64 w, u64* __restrict__ q, int* __restrict__ zero_den) {
   const u32 n = 1u << log_n, i = blockIdx.x * kBlock + threadIdx.x, k = blockIdx.y, c = blockIdx.z;
   if (i >= n) return;
-  const u64 beta = bg[2 * c], gamma = bg[2 * c + 1];
+  const u64 beta = betas[c], gamma = gammas[c];
   const u64 bx = gl::mul(beta, gl::pow(w, i));  // beta * x_i
   u64 num = 1, den = 1;
   const u32 j1 = min(num_routed, (k + 1) * chunk);
@@ -107,6 +107,24 @@ inline u64 h_pow(u64 a, u64 e) {
 
 }  // namespace
 
+int p2mt::partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_sigmas, const uint64_t* d_k_is,
+                                     const uint64_t* d_betas, const uint64_t* d_gammas, size_t num_challenges,
+                                     size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t* d_q, uint64_t* d_out,
+                                     int* d_zero_den) {
+  const size_t n = (size_t)1 << degree_bits;
+  const size_t num_chunks = (num_routed + chunk - 1) / chunk;
+  hipStream_t st = rt().stream;
+  u64 w = h_pow(7, (gl::P - 1) >> 32);  // primitive 2^degree_bits-th root of unity
+  for (unsigned i = degree_bits; i < 32; ++i) w = h_mul(w, w);
+  hipLaunchKernelGGL(k_pp_chunks, dim3(grid_for(n), (unsigned)num_chunks, (unsigned)num_challenges), dim3(kBlock), 0, st, d_wires,
+                     d_sigmas, d_k_is, d_betas, d_gammas, (u32)num_routed, degree_bits, chunk, (u32)num_chunks, w, d_q, d_zero_den);
+  P2MT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_pp_scan, dim3((unsigned)num_challenges), dim3(kScanBlock), 0, st, (const u64*)d_q, degree_bits,
+                     (u32)num_chunks, (u32)num_challenges, d_out);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_permutation_partial_products_dev(const uint64_t* d_wires, const uint64_t* d_sigmas, const uint64_t* k_is,
                                                      const uint64_t* betas, const uint64_t* gammas, size_t num_challenges,
                                                      size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t* d_out) {
@@ -116,7 +134,7 @@ extern "C" int p2mt_permutation_partial_products_dev(const uint64_t* d_wires, co
     return p2mt::fail(P2MT_EINVAL, "partial_products: bad shape (max_degree must be > 1)");
   const size_t n = (size_t)1 << degree_bits;
   const size_t num_chunks = (num_routed + chunk - 1) / chunk;
-  // scratch: q | k_is | (beta, gamma) pairs | zero-denominator flag
+  // scratch: q | k_is | betas | gammas | zero-denominator flag
   const size_t q_words = num_challenges * num_chunks * n;
   u64* ws;
   P2MT_TRY(p2mt::scratch_get(p2mt::kScratchPlonk, (q_words + num_routed + 2 * num_challenges + 1) * 8, (void**)&ws));
@@ -125,19 +143,13 @@ extern "C" int p2mt_permutation_partial_products_dev(const uint64_t* d_wires, co
   std::vector<u64> h(num_routed + 2 * num_challenges + 1, 0);
   for (size_t j = 0; j < num_routed; ++j) h[j] = k_is[j] % gl::P;
   for (size_t c = 0; c < num_challenges; ++c) {
-    h[num_routed + 2 * c] = betas[c] % gl::P;
-    h[num_routed + 2 * c + 1] = gammas[c] % gl::P;
+    h[num_routed + c] = betas[c] % gl::P;
+    h[num_routed + num_challenges + c] = gammas[c] % gl::P;
   }
   hipStream_t st = rt().stream;
   P2MT_HIP(hipMemcpyAsync(d_k, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
-  u64 w = h_pow(7, (gl::P - 1) >> 32);  // primitive 2^degree_bits-th root of unity
-  for (unsigned i = degree_bits; i < 32; ++i) w = h_mul(w, w);
-  hipLaunchKernelGGL(k_pp_chunks, dim3(grid_for(n), (unsigned)num_chunks, (unsigned)num_challenges), dim3(kBlock), 0, st, d_wires,
-                     d_sigmas, (const u64*)d_k, (const u64*)d_bg, (u32)num_routed, degree_bits, chunk, (u32)num_chunks, w, d_q, d_flag);
-  P2MT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_pp_scan, dim3((unsigned)num_challenges), dim3(kScanBlock), 0, st, (const u64*)d_q, degree_bits,
-                     (u32)num_chunks, (u32)num_challenges, d_out);
-  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(p2mt::partial_products_async_dev(d_wires, d_sigmas, d_k, d_bg, d_bg + num_challenges, num_challenges, num_routed,
+                                            degree_bits, chunk, d_q, d_out, d_flag));
   int flag = 0;
   P2MT_HIP(hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));

@@ -50,7 +50,7 @@ inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ul
 
 // Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
-enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCount };
+enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCircuit, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
 
 // RAII: run a scope on another stream, restore the library stream afterwards
@@ -89,6 +89,22 @@ int launch_merkle_level_dev(const uint64_t* d_in, uint64_t* d_out, size_t n_out)
 // d_out[p][brev(i)] = f_p(shift * w_N^i)
 int coset_lde_leaf_order_dev(const uint64_t* d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift, size_t n_polys,
                              uint64_t* d_out);
+
+// exported by p2mt_commit.hip: PolynomialBatch::from_values / from_coeffs keeping every intermediate the prover needs later.
+// d_coeffs_out [n_polys][n] (coefficients; with is_values = 0 the input IS the coefficient array and this may be null),
+// d_lde_out [n_polys][8n] poly-major in leaf order (the quotient kernel reads it), d_leaves_out [8n][n_polys] (FRI
+// queries), d_digests_out level-major, d_cap_out.  Null outputs go to grow-only scratch (or are skipped).
+int commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_polys, unsigned log_n, unsigned rate_bits,
+                     unsigned cap_height, uint64_t* d_coeffs_out, uint64_t* d_lde_out, uint64_t* d_leaves_out,
+                     uint64_t* d_digests_out, uint64_t* d_cap_out);
+// exported by p2mt_commit.hip: PolynomialValues::coset_ifft(shift) of n_polys rows of 2^log_n values given in natural
+// order (d_vals is used as workspace); coefficients in natural order to d_coeffs_out.
+int coset_ifft_dev(uint64_t* d_vals, unsigned log_n, size_t n_polys, uint64_t shift, uint64_t* d_coeffs_out);
+// exported by p2mt_plonk.hip: Z and partial products with every operand in device memory, nothing synchronised;
+// *d_zero_den is set to 1 on a zero denominator (where plonky2 panics).  d_k_is: [num_routed] canonical.
+int partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_sigmas, const uint64_t* d_k_is,
+                               const uint64_t* d_betas, const uint64_t* d_gammas, size_t num_challenges, size_t num_routed,
+                               unsigned degree_bits, unsigned chunk, uint64_t* d_q_scratch, uint64_t* d_out, int* d_zero_den);
 
 }  // namespace p2mt
 

@@ -114,7 +114,10 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 // a flagged wave redoing its node serially would set the duration of the whole (latency-bound) launch.
 // One permutation by the calling wave (all 64 lanes must call it): lane w < 12 passes state word w (any u64) and
 // receives word w of the permuted state (loose u64, exact); lanes >= 12 shadow lane 0 and their result is unused.
-GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
+// `hook(r, x)` sees this lane's state word at the start of round r, after the round constant and before the S-box --
+// the value plonky2's PoseidonGate keeps as a witness wire (p2mt_circuit.hip records it; the hashing kernels pass nothing).
+template <typename Hook>
+GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
   const unsigned lane = threadIdx.x & 63;
   const unsigned w = lane < 12 ? lane : 0;
   u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
@@ -126,7 +129,8 @@ GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
   x = gl::add_c(x, rcw[0]);
   // one round: S-box (every lane in a full round, lane 0 in a partial one), then this lane's MDS row with the
   // next round's constant folded into the two mad chains
-  auto round = [&](bool full, bool add, u64 c_fold) {
+  auto round = [&](int r, bool full, bool add, u64 c_fold) {
+    hook(r, x);
     const u64 y = poseidon_fast::exact::pow7(x);
     if (full || lane == 0) x = y;
     const u32 xl = (u32)x, xh = (u32)(x >> 32);
@@ -146,10 +150,13 @@ GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
     const u64 c_fold = c_next;
     if (r + 2 < POSEIDON_ROUNDS) c_next = rcw[12 * (r + 2)];
     const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
-    round(full, true, c_fold);
+    round(r, full, true, c_fold);
   }
-  round(true, false, 0);
+  round(POSEIDON_ROUNDS - 1, true, false, 0);
   return x;
+}
+GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
+  return permute_wave_hook(x, ctx, [](int, u64) {});
 }
 
 // out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
