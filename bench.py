@@ -10,7 +10,8 @@ N - popcount(N) of them.
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (weak scaling: every rank builds its own 2^LOG shard)
-  python bench.py --workload commit                       (secondary metric: commit phase of one prove, ms)
+  python bench.py --workload prove                        (BASELINE's second metric: ms/proof mmr_plonky2_verifier)
+  python bench.py --workload commit | fri                 (parts of a prove at the d = 12 shape: commit phase, opening proof)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
 """
@@ -348,6 +349,75 @@ def run_fri(args, torch, pkg, lib):
             "details": res}
 
 
+def run_prove(args, torch, pkg, lib):
+    """BASELINE.json's second metric: ms/proof of mmr_plonky2_verifier -- circuit_data.prove(pw)
+    (/root/reference/src/mmr/mmr_plonky2_verifier.rs:148) for one leaf of a 2^20-leaf MMR (config 3: 20 path elements,
+    1 peak -> 64-row circuit under standard_recursion_config).  One step = one complete prove from a PartialWitness held
+    on the host to the proof words back on the host: witness fill, 3 commitments, permutation argument, quotient
+    polynomials, openings, FRI (16-bit proof of work, 28 queries).  The MMR is built on the GPU and the membership proof
+    comes from the device-resident MMR (config 2)."""
+    Nn = pkg._native
+    leaves = splitmix_leaves(1 << 20, 0x5EED0000 + 3)
+    mmr = pkg.MMR.from_leaves(leaves)
+    root = mmr.bagging_the_peaks()
+    idx = 777777
+    pr = mmr.get_proof_normal_index(idx)
+    assert pr.verify(int(leaves[idx]), root)
+    t0 = time.perf_counter()
+    cd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(len(pr.siblings), len(pr.peaks))
+    build_ms = (time.perf_counter() - t0) * 1e3
+    case = (int(leaves[idx]), pr.siblings, pr.lefts, pr.peaks, root)
+    from circuit_cases import assign
+    pw = pkg.PartialWitness()
+    assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, case, pw.set_target)
+    proof = np.zeros(cd.info.proof_len, np.uint64)
+
+    def one():
+        Nn.check(lib.p2mt_circuit_prove(cd._h, pw._h, Nn.ptr(proof), proof.size))
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    out = {"metric": "ms/proof mmr_plonky2_verifier (prove, one leaf of a 2^20-leaf MMR)", "value": ms, "unit": "ms",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
+           "scaling": "replicas only", "vs_baseline": None, "dtype": "u64 (Goldilocks + quadratic extension)",
+           "data": "synthetic",
+           "config": {"workload": "mmr_plonky2_verifier circuit_data.prove(pw), standard_recursion_config, 20 path "
+                                  "elements + 1 peak, degree 2^%d, host PartialWitness -> host proof words" % cd.degree_bits,
+                      "proof_words": int(cd.info.proof_len), "circuit_build_ms": build_ms,
+                      "gate_rows": {k: int(v) for k, v in zip(("noop", "constant", "public_input", "arithmetic", "poseidon"),
+                                                              cd.info.gate_counts)}},
+           "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                        "note": "a 64-row circuit: ~100 dependent small launches (witness levels, 3 commits, challenger, "
+                                "quotient, FRI); no kernel is bandwidth- or issue-bound at this size; per-kernel split in "
+                                "profiles/"},
+           "public_inputs": [int(x) for x in proof[-4:]]}
+    if not args.no_cpu_baseline:
+        from oracle_lib import Oracle
+        from oracle import circuit as OC
+        o = Oracle()
+        ocd, oleaf, oproof_ts, opeak_ts = OC.verify_mmr_proof_circuit(o, len(pr.siblings), len(pr.peaks))
+        opw = {}
+        assign(oleaf, oproof_ts, opeak_ts, ocd.public_inputs, case, opw.__setitem__)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 40):
+            want = ocd.prove(opw)
+            reps += 1
+        cpu_ms = (time.perf_counter() - t0) * 1e3 / reps
+        assert np.array_equal(proof, want), "GPU proof != oracle proof"
+        assert ocd.verify(proof) == (True, 0), "oracle verifier rejects the GPU proof"
+        out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": "oracle/circuit.py + oracle/*.c prove of the same circuit and witness, %d proofs "
+                                         "(C restatement, 1 thread; ~75 %% of it is the 2^16-hash proof-of-work grind)" % reps,
+                               "cpu_over_gpu": cpu_ms / ms}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,7 +425,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-leaves", type=int, default=24, help="leaves per GPU = 2^this")
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
-    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri"])
+    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --single-device exist only to exercise the N>1 code "
@@ -392,6 +462,8 @@ def main():
         out = run_commit(args, torch, pkg, lib) if rank == 0 else None
     elif args.workload == "fri":
         out = run_fri(args, torch, pkg, lib) if rank == 0 else None
+    elif args.workload == "prove":
+        out = run_prove(args, torch, pkg, lib) if rank == 0 else None
     else:
         out = run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist)
     if rank == 0 and out is not None:
