@@ -551,3 +551,27 @@ def verify_mmr_proof_circuit(oracle, nr_merkle_proof_elms, nr_peaks):
     else:
         builder.register_public_inputs(peaks[0])
     return builder.build(), leaf_to_prove, proof_targets, peak_targets
+
+
+# ---- /root/reference/src/mmr/mmr_plonky2_verifier_1_recursion.rs:20-75 (the inner circuit of config 4)
+def verify_inner_merkle_proof_circuit(oracle, nr_merkle_proof_elms, nr_peaks):
+    """-> (circuit_data, leaf target, [(hash target, bool target)]); public inputs = the peaks (4 per peak)"""
+    builder = CircuitBuilder(oracle)
+    proof_targets = []
+    leaf_to_prove = builder.add_virtual_target()
+    next_hash = builder.hash_or_noop([leaf_to_prove])
+    for _ in range(nr_merkle_proof_elms):
+        elm = builder.add_virtual_hash()
+        on_left = builder.add_virtual_bool_target_safe()
+        proof_targets.append((elm, on_left))
+        option1 = builder.hash_or_noop(elm + next_hash)
+        option2 = builder.hash_or_noop(next_hash + elm)
+        next_hash = pick_hash(builder, option1, option2, on_left)
+    equals = []
+    for _ in range(nr_peaks):
+        peak = builder.add_virtual_hash()
+        builder.register_public_inputs(peak)
+        equals.append(equal(builder, peak, next_hash))
+    hash_in_peaks = or_list(builder, equals)
+    builder.connect(builder.one(), hash_in_peaks)
+    return builder.build(), leaf_to_prove, proof_targets

@@ -10,9 +10,10 @@ from ._native import P2mtError, P2mtPanic, lib
 from .hashing import (poseidon_gate_witness_batch, hash_no_pad, hash_no_pad_batch, hash_or_noop, hash_or_noop_batch, poseidon_permute_batch,
                       two_to_one, two_to_one_batch)
 from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_batch
-from . import circuit, commit, distributed, fri, mmr_plonky2_verifier, plonk
+from . import circuit, commit, distributed, fri, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion, plonk
 from .circuit import CircuitBuilder, CircuitData, PartialWitness
 from .mmr_plonky2_verifier import verify_mmr_proof_circuit
+from .mmr_plonky2_verifier_1_recursion import verify_inner_merkle_proof_circuit
 from .commit import MerkleCapTree, PolynomialBatch, coset_lde, fft, ifft
 from .distributed import ShardedMMR
 from .fri import Challenger, FriParams, eval_polys_ext, prove_openings

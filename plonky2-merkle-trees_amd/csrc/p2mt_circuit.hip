@@ -14,6 +14,8 @@
 // Nothing here is GEMM-shaped: 64-bit modular arithmetic on the integer VALU, latency-bound at these sizes (64..4096 rows).
 #include "tree_common.hip.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
 #include <new>
@@ -117,7 +119,7 @@ struct p2mt_circuit_data {
   u32 *d_set = nullptr, *d_wire_slot = nullptr, *d_pi_slot = nullptr, *d_lvl = nullptr;
   WOp* d_ops = nullptr;
   int* d_err = nullptr;  // [0] witness conflict (op index + 1, or -1 unset public input), [1] zero denominator
-  size_t init_cap = 0, ops_cap = 0;
+  size_t init_cap = 0, ops_cap = 0, lds_bytes = 0;  // lds_bytes != 0: the value table fits LDS (k_witness_lds)
   p2mt_challenger* ch = nullptr;
 };
 
@@ -274,14 +276,43 @@ GL_DEV u64 gl_inv(u64 x) {
   return gl::mul(sqn(t31, 33), t32);
 }
 
+// Where the value table lives while the generators run: global memory (any circuit size; agent-scope accesses so that
+// the waves of the workgroup see each other's writes) or LDS (circuits of up to ~18 k value slots, e.g. the 64-row ones:
+// a dependent level then costs an LDS round trip instead of an L2 one).
+struct GMem {
+  u64* vals;
+  u32* set;
+  GL_DEV u64 get(u32 s) const { return ld64(vals + s); }
+  GL_DEV bool is_set(u32 s) const { return ld32(set + s) != 0; }
+  GL_DEV void store(u32 s, u64 v) const {
+    st64(vals + s, v);
+    st32(set + s, 1);
+  }
+  GL_DEV void sync() const {
+    __threadfence();
+    __syncthreads();
+  }
+};
+struct LMem {
+  u64* vals;
+  uint8_t* set;
+  GL_DEV u64 get(u32 s) const { return vals[s]; }
+  GL_DEV bool is_set(u32 s) const { return set[s] != 0; }
+  GL_DEV void store(u32 s, u64 v) const {
+    vals[s] = v;
+    set[s] = 1;
+  }
+  GL_DEV void sync() const { __syncthreads(); }
+};
+
 // PartitionWitness::set_target: a slot already holding a value must agree (plonky2 panics otherwise)
-GL_DEV void put(u64* vals, u32* set, u32 slot, u64 v, int* err, u32 op_index) {
+template <typename Mem>
+GL_DEV void put(const Mem& m, u32 slot, u64 v, int* err, u32 op_index) {
   v = gl::canon(v);
-  if (ld32(set + slot)) {
-    if (ld64(vals + slot) != v) atomicCAS(err, 0, (int)op_index + 1);
+  if (m.is_set(slot)) {
+    if (m.get(slot) != v) atomicCAS(err, 0, (int)op_index + 1);
   } else {
-    st64(vals + slot, v);
-    st32(set + slot, 1);
+    m.store(slot, v);
   }
 }
 
@@ -295,21 +326,20 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
 
 // One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
 // and puts the PoseidonGate rows first).  PoseidonGenerator: one wavefront per row, lane w < 12 owns state word w.
-__global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                                                        u64* vals, u32* set, const u32* __restrict__ wire_slot, int* err,
-                                                        PermCtx ctx) {
+template <typename Mem>
+GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                       const u32* __restrict__ wire_slot, int* err, const PermCtx& ctx) {
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kBlock / 64;
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
     for (u32 o = s + wave; o < s + np; o += n_waves) {  // wave-uniform
       const u32* ws = wire_slot + (size_t)ops[o].a * kNumWires;
-      u64 x = lane < 12 ? ld64(vals + ws[lane]) : 0;
-      const u64 swap = ld64(vals + ws[24]);
+      u64 x = lane < 12 ? m.get(ws[lane]) : 0;
+      const u64 swap = m.get(ws[24]);
       const u64 partner = __shfl_xor((unsigned long long)x, 4);
       if (lane < 4) {  // delta_i = swap * (in[i+4] - in[i]); the permutation runs on the swapped state
         const u64 d = gl::canon(gl::mul(swap, fsub(partner, x)));
-        st64(vals + ws[25 + lane], d);
-        st32(set + ws[25 + lane], 1);
+        m.store(ws[25 + lane], d);
         x = gl::add(x, d);
       } else if (lane < 8) {
         x = fsub(x, gl::mul(swap, fsub(x, partner)));
@@ -322,24 +352,55 @@ __global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ 
           if (lane != 0) return;
           col = 65 + (r - 4);
         } else col = 87 + 12 * (r - 26) + lane;
-        st64(vals + ws[col], gl::canon(xv));
-        st32(set + ws[col], 1);
+        m.store(ws[col], gl::canon(xv));
       });
-      if (lane < 12) put(vals, set, ws[12 + lane], x, err, o);
+      if (lane < 12) put(m, ws[12 + lane], x, err, o);
     }
     for (u32 o = s + np + tid; o < e; o += kBlock) {
       const WOp op = ops[o];
       if (op.kind == GEN_ARITH) {
-        const u64 m0 = ld64(vals + op.a), m1 = ld64(vals + op.b), ad = ld64(vals + op.c);
-        put(vals, set, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
+        const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
+        put(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
       } else {  // EqualityGenerator
-        const u64 x = ld64(vals + op.a), y = ld64(vals + op.b);
-        put(vals, set, op.out, x == y ? 1 : 0, err, o);
-        put(vals, set, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
+        const u64 x = m.get(op.a), y = m.get(op.b);
+        put(m, op.out, x == y ? 1 : 0, err, o);
+        put(m, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
       }
     }
-    __threadfence();
-    __syncthreads();
+    m.sync();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                                                        u64* vals, u32* set, const u32* __restrict__ wire_slot, int* err,
+                                                        PermCtx ctx) {
+  run_levels(GMem{vals, set}, ops, lvl, n_levels, wire_slot, err, ctx);
+}
+
+// The whole witness fill in one launch with the value table in LDS: initial assignments, generator levels, and
+// full_witness (wires[col][row], public inputs) straight from LDS.
+__global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ pairs, u32 n_pairs, u32 n_slots,
+                                                        const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                                                        const u32* __restrict__ wire_slot, u32 log_n, u64* __restrict__ wires,
+                                                        const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
+                                                        int* err, PermCtx ctx) {
+  extern __shared__ __attribute__((aligned(16))) u64 sh[];
+  const LMem m{sh, reinterpret_cast<uint8_t*>(sh + n_slots)};
+  for (u32 k = threadIdx.x; k < n_slots; k += kBlock) m.set[k] = 0;
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < n_pairs; k += kBlock) m.store((u32)pairs[2 * k], pairs[2 * k + 1]);
+  __syncthreads();
+  run_levels(m, ops, lvl, n_levels, wire_slot, err, ctx);
+  const u32 n = 1u << log_n;
+  for (u32 t = threadIdx.x; t < kNumWires * n; t += kBlock) {
+    const u32 col = t >> log_n, row = t & (n - 1);
+    const u32 s = wire_slot[(size_t)row * kNumWires + col];
+    wires[t] = m.set[s] ? m.vals[s] : 0;
+  }
+  for (u32 t = threadIdx.x; t < n_pi; t += kBlock) {
+    const u32 s = pi_slot[t];
+    if (!m.set[s]) atomicCAS(err, 0, -1);
+    pi_out[t] = m.vals[s];
   }
 }
 
@@ -653,16 +714,23 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   const size_t n_pairs = pairs.size() / 2;
   if (n_pairs > c->init_cap) return p2mt::fail(P2MT_EINVAL, "prove: too many witness assignments");
   hipStream_t st = rt().stream;
-  P2MT_HIP(hipMemsetAsync(c->d_set, 0, (size_t)c->n_slots * 4, st));
   P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
   P2MT_HIP(hipMemcpyAsync(c->d_init, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, st));  // pageable: staged before return
+  u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
+  if (c->lds_bytes) {
+    hipLaunchKernelGGL(k_witness_lds, dim3(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
+                       (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_wire_slot, c->degree_bits,
+                       c->d_w_vals, (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, c->d_err, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  P2MT_HIP(hipMemsetAsync(c->d_set, 0, (size_t)c->n_slots * 4, st));
   hipLaunchKernelGGL(k_witness_init, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
                      c->d_set);
   P2MT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
                      c->d_set, (const u32*)c->d_wire_slot, c->d_err, p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
-  u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
   hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for((size_t)kNumWires * c->n)), dim3(kBlock), 0, st, (const u64*)c->d_vals,
                      (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->degree_bits, c->d_w_vals, (const u32*)c->d_pi_slot,
                      c->n_pi, d_pi_out, c->d_err);
@@ -959,6 +1027,16 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   const size_t n_open = n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
   c->proof_len = 3 * 64 + 2 * n_open + c->fri_len + c->n_pi;
 
+  {  // value table in LDS when it fits (160 KB per CU on gfx950; env P2MT_WITNESS_LDS=0 forces the global-memory path)
+    const size_t need = (size_t)c->n_slots * 9 + 16;
+    const char* e = getenv("P2MT_WITNESS_LDS");
+    if (need <= 160 * 1024 - 1024 && !(e && e[0] == '0')) {
+      c->lds_bytes = (need + 15) & ~(size_t)15;
+      if (c->lds_bytes > 64 * 1024)
+        P2MT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_witness_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)c->lds_bytes));
+    }
+  }
   // ---- device memory
   const size_t big = n << kRateBits;
   const size_t nd = c->n_digests = digests_count(big, kCapHeight);

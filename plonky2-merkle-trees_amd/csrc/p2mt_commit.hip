@@ -20,8 +20,7 @@
 //     coalesced 8-byte loads), so hashing never needs the transposed leaf-major matrix; the transpose to
 //     plonky2's leaf-major `leaves` is only produced when the caller asks for it.
 //   All of it is HBM/LDS-bound integer work: no MFMA.
-#include "poseidon_quad.hip.h"
-#include "runtime.h"
+#include "tree_common.hip.h"
 
 #include <map>
 #include <tuple>
@@ -331,6 +330,23 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restr
   } else if (ln.q == 1) {
     out[3] = gl::canon(x[0]);
   }
+}
+
+// The same leaf sponge with one wavefront per column (latency path for <= 2^12 leaves -- the 64-row circuits): lane k < 8
+// loads word k of each 8-word chunk, the chunk's permutation runs on 12 lanes (permute_wave, ~11 us instead of ~18 us
+// on a quad), so a 135-wide leaf costs 17 x 11 us.
+__global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restrict__ in, size_t w, size_t n_pts,
+                                                              u64* __restrict__ digests, p2mt::PermCtx ctx) {
+  const size_t col = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (col >= n_pts) return;  // wave-uniform
+  const unsigned lane = threadIdx.x & 63;
+  u64 x = 0;
+#pragma unroll 1
+  for (size_t off = 0; off < w; off += 8) {
+    if (lane < 8 && off + lane < w) x = in[(off + lane) * n_pts + col];
+    x = p2mt_dev::permute_wave(x, ctx);
+  }
+  if (lane < 4) digests[4 * col + lane] = gl::canon(x);
 }
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -669,7 +685,11 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   const bool cap_is_leaves = cap_height == log_big;
   u64* d_level0 = (d_digests_out && !cap_is_leaves) ? d_digests_out : nullptr;
   if (!d_level0) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, big * 32, (void**)&d_level0));
-  if (n_polys > 4 && big <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
+  if (n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_hash_columns_wave, dim3((unsigned)((big + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
+                       (const u64*)lde, n_polys, big, d_level0, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+  } else if (n_polys > 4 && big <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
     hipLaunchKernelGGL(k_hash_columns_quad, dim3(grid_for(4 * big)), dim3(kBlock), 0, st, (const u64*)lde, n_polys, big,
                        d_level0, p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();

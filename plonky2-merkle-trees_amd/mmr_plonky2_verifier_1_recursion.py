@@ -1,0 +1,39 @@
+"""Mirror of src/mmr/mmr_plonky2_verifier_1_recursion.rs: the INNER circuit (verify_inner_merkle_proof_circuit, :20-75),
+written against circuit.CircuitBuilder as the reference writes it against plonky2's.
+
+The OUTER circuit (complete_verification_circuit_with_inner_proof, :84-140) calls plonky2's in-circuit verifier
+(builder.verify_proof: CosetInterpolation / RandomAccess / Reducing / ArithmeticExtension / BaseSum / Exponentiation /
+PoseidonMds gates and their generators), which this library does not build yet; calling it raises."""
+from .circuit import CircuitBuilder
+from .mmr_plonky2_verifier import equal, or_list, pick_hash
+
+
+def verify_inner_merkle_proof_circuit(nr_merkle_proof_elms, nr_peaks):
+    """:20-75 -> (circuit_data, leaf target, [(HashOutTarget, BoolTarget)]); the public inputs are the peaks"""
+    proof_targets = []
+    builder = CircuitBuilder()
+    leaf_to_prove = builder.add_virtual_target()
+    next_hash = builder.hash_or_noop([leaf_to_prove])
+    for _ in range(nr_merkle_proof_elms):
+        merkle_proof_elm = builder.add_virtual_hash()
+        elm_on_left = builder.add_virtual_bool_target_safe()
+        proof_targets.append((merkle_proof_elm, elm_on_left))
+        option1 = builder.hash_or_noop(merkle_proof_elm + next_hash)
+        option2 = builder.hash_or_noop(next_hash + merkle_proof_elm)
+        next_hash = pick_hash(builder, option1, option2, elm_on_left)
+    equals = []
+    for _ in range(nr_peaks):
+        peak = builder.add_virtual_hash()
+        builder.register_public_inputs(peak)
+        equals.append(equal(builder, peak, next_hash))
+    hash_in_peaks = or_list(builder, equals)
+    builder.connect(builder.one(), hash_in_peaks)
+    data = builder.build()
+    return data, leaf_to_prove, proof_targets
+
+
+def complete_verification_circuit_with_inner_proof(inner_proof_circuit_data_common, nr_peaks):
+    """:84-140 -- needs plonky2's recursive verifier gadget (builder.verify_proof); not built."""
+    raise NotImplementedError("outer recursion circuit: builder.verify_proof (in-circuit plonky2 verifier) is not built; "
+                              "its commit and opening-proof stages at the d = 12 shape are covered by bench.py "
+                              "--workload commit / fri")

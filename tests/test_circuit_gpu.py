@@ -171,3 +171,38 @@ def test_gadgets_or_list(pkg):
             pw2.set_bool_target(t, v)
         with pytest.raises(pkg.P2mtPanic):
             cd2.prove(pw2)
+
+
+@pytest.mark.parametrize("n_leaves,idx", [(11, 6), (1 << 10, 5)])
+def test_inner_circuit_of_the_recursion(pkg, oracle, n_leaves, idx):
+    """Config 4's inner proof (mmr_plonky2_verifier_1_recursion.rs:20-75, driver :152-192): bit-exact vs the oracle."""
+    leaf, siblings, lefts, peaks, _ = mmr_case(oracle, n_leaves, idx)
+    gcd, gleaf, gproof_ts = pkg.verify_inner_merkle_proof_circuit(len(siblings), len(peaks))
+    ocd, oleaf, oproof_ts = OC.verify_inner_merkle_proof_circuit(oracle, len(siblings), len(peaks))
+    check_build(gcd, ocd)
+    pw, opw = pkg.PartialWitness(), {}
+    for setter, leaf_t, proof_ts, pis in ((pw.set_target, gleaf, gproof_ts, gcd.prover_only.public_inputs),
+                                          (opw.__setitem__, oleaf, oproof_ts, ocd.public_inputs)):
+        setter(leaf_t, leaf)
+        for (ht, bt), sib, left in zip(proof_ts, siblings, lefts):
+            for k in range(4):
+                setter(ht[k], int(sib[k]))
+            setter(bt, int(left))
+        for k, t in enumerate(pis):
+            setter(t, int(peaks.reshape(-1)[k]))
+    proof = check_prove(gcd, pw, ocd, opw)
+    assert np.array_equal(proof[-4 * len(peaks):], peaks.reshape(-1))
+
+
+def test_global_memory_witness_path(pkg, oracle, monkeypatch):
+    """Circuits whose value table does not fit LDS run the generators out of global memory (k_witness_run); force that
+    path on a small circuit and compare with the LDS path and the oracle."""
+    case = mmr_case(oracle, 100, 37)
+    gcd, pw, ocd, opw = build_both(pkg, oracle, case)
+    want = gcd.prove(pw)
+    monkeypatch.setenv("P2MT_WITNESS_LDS", "0")
+    gcd2, pw2, _, _ = build_both(pkg, oracle, case)
+    monkeypatch.delenv("P2MT_WITNESS_LDS")
+    assert np.array_equal(gcd2.generate_witness(pw2), ocd.generate_witness(opw)[0])
+    assert np.array_equal(gcd2.prove(pw2), want)
+    assert np.array_equal(want, ocd.prove(opw))

@@ -90,3 +90,21 @@ def test_unsatisfied_constraints_do_not_verify(oracle, kind, col):
     except ValueError:
         return  # zero denominator in the permutation argument: also a failure to prove
     assert cd.verify(proof)[0] is False
+
+
+@pytest.mark.parametrize("n_leaves,idx", [(11, 6), (1 << 10, 5)])
+def test_inner_circuit_of_the_recursion(oracle, n_leaves, idx):
+    """mmr_plonky2_verifier_1_recursion.rs:20-75 + its driver :152-192: peaks are the public inputs, no root hash."""
+    leaf, siblings, lefts, peaks, _ = mmr_case(oracle, n_leaves, idx)
+    cd, leaf_t, proof_ts = OC.verify_inner_merkle_proof_circuit(oracle, len(siblings), len(peaks))
+    assert len(cd.public_inputs) == 4 * len(peaks)
+    pw = {leaf_t: leaf}
+    for (ht, bt), sib, left in zip(proof_ts, siblings, lefts):
+        for k in range(4):
+            pw[ht[k]] = int(sib[k])
+        pw[bt] = int(left)
+    for k, t in enumerate(cd.public_inputs):
+        pw[t] = int(peaks.reshape(-1)[k])
+    proof = cd.prove(pw)
+    assert cd.verify(proof) == (True, 0)
+    assert np.array_equal(proof[-4 * len(peaks):], peaks.reshape(-1))
