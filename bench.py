@@ -397,6 +397,45 @@ def run_prove(args, torch, pkg, lib):
                                 "quotient, FRI); no kernel is bandwidth- or issue-bound at this size; per-kernel split in "
                                 "profiles/"},
            "public_inputs": [int(x) for x in proof[-4:]]}
+    if args.threads > 1:
+        # throughput: one prover per host thread (own stream, own circuit handle), all proving the same statement
+        import threading
+        counts, errs = [0] * args.threads, []
+        start, stop = threading.Barrier(args.threads + 1), threading.Event()
+
+        def worker(i):
+            try:
+                Nn.check(lib.p2mt_thread_stream_create())
+                wcd, wleaf, wproof_ts, wpeak_ts = pkg.verify_mmr_proof_circuit(len(pr.siblings), len(pr.peaks))
+                wpw = pkg.PartialWitness()
+                assign(wleaf, wproof_ts, wpeak_ts, wcd.prover_only.public_inputs, case, wpw.set_target)
+                wproof = np.zeros(wcd.info.proof_len, np.uint64)
+                for _ in range(3):
+                    Nn.check(lib.p2mt_circuit_prove(wcd._h, wpw._h, Nn.ptr(wproof), wproof.size))
+                start.wait()
+                while not stop.is_set():
+                    Nn.check(lib.p2mt_circuit_prove(wcd._h, wpw._h, Nn.ptr(wproof), wproof.size))
+                    counts[i] += 1
+                assert np.array_equal(wproof, proof)
+            except Exception as e:
+                errs.append(repr(e))
+                stop.set()
+
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(args.threads)]
+        for t in ths:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        time.sleep(3.0)
+        stop.set()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        assert not errs, errs
+        out["throughput"] = {"threads": args.threads, "proofs": int(sum(counts)), "seconds": dt,
+                             "proofs_per_s": sum(counts) / dt, "amortised_ms_per_proof": dt * 1e3 / max(sum(counts), 1),
+                             "note": "independent provers on one GPU, one per host thread and stream; `value` above stays the "
+                                     "single-proof latency"}
     if not args.no_cpu_baseline:
         from oracle_lib import Oracle
         from oracle import circuit as OC
@@ -427,6 +466,7 @@ def main():
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
     ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threads", type=int, default=8, help="--workload prove: concurrent provers for the throughput leg (1 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --single-device exist only to exercise the N>1 code "
                          "path on a 1-GPU box")

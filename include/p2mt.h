@@ -19,7 +19,8 @@
  *     device memory (hipMalloc / torch tensors), enqueue on the library stream and do not
  *     synchronise unless they return host-visible results.
  *   - Caller owns every buffer; device-resident state lives only behind opaque handles.
- *   - A handle is not thread-safe; distinct handles are independent.
+ *   - A handle is not thread-safe; distinct handles are independent and may be driven from distinct host threads
+ *     concurrently (the library stream, scratch buffers and p2mt_last_error() are per thread).
  *   - All hashing runs on the GPU.  There is no CPU fallback: without a HIP device every compute
  *     entry point returns P2MT_EHIP.
  */
@@ -47,7 +48,11 @@ typedef enum p2mt_status {
 /* ------------------------------------------------------------------ device / runtime control */
 int p2mt_init(int device);              /* select device, upload Poseidon tables; idempotent */
 int p2mt_device_count(void);            /* number of visible HIP devices (0 => nothing can run) */
-int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches (NULL = default stream) */
+int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches of the CALLING THREAD (NULL = default stream) */
+/* Give the calling host thread its own non-blocking stream (and, implicitly, its own scratch buffers): from then on its
+ * calls enqueue there.  This is how several provers run concurrently on one GPU -- one handle (MMR, circuit data,
+ * challenger) per thread; a 64-row prove occupies a few CUs for ~2.6 ms, so independent proofs overlap almost freely. */
+int p2mt_thread_stream_create(void);
 int p2mt_sync(void);                    /* hipStreamSynchronize on the library stream */
 const char *p2mt_last_error(void);
 /* Kernel variant for the Poseidon permutation.  mds 2 (default) = issue-optimised path (constants folded into the

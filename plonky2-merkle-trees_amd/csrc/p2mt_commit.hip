@@ -23,6 +23,7 @@
 #include "tree_common.hip.h"
 
 #include <map>
+#include <mutex>
 #include <tuple>
 
 using gl::u32;
@@ -360,6 +361,12 @@ Tables& tables() {
   static Tables t;
   return t;
 }
+// The tables are built once, on whichever thread needs them first, on that thread's stream: creation is serialised and
+// the stream is synchronised before the table is published to the other threads (concurrent provers, runtime.h).
+std::mutex& tables_mutex() {
+  static std::mutex m;
+  return m;
+}
 
 // host Goldilocks (table roots only: a handful of multiplications per call, no hashing)
 inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
@@ -376,6 +383,7 @@ inline u64 h_root_of_unity(unsigned log_n) {  // 7^((p-1)/2^32) squared down (pl
 }
 
 int get_twiddles(unsigned log_n, int inverse, const u64** out) {
+  std::lock_guard<std::mutex> lock(tables_mutex());
   auto key = std::make_pair(log_n, inverse);
   auto it = tables().twiddles.find(key);
   if (it == tables().twiddles.end()) {
@@ -386,6 +394,7 @@ int get_twiddles(unsigned log_n, int inverse, const u64** out) {
     if (inverse) root = h_pow(root, gl::P - 2);
     hipLaunchKernelGGL(k_powers, dim3(grid_for(count)), dim3(kBlock), 0, p2mt::rt().stream, d, root, count);
     P2MT_LAUNCH_CHECK();
+    P2MT_HIP(hipStreamSynchronize(p2mt::rt().stream));
     it = tables().twiddles.emplace(key, d).first;
   }
   *out = it->second;
@@ -394,6 +403,7 @@ int get_twiddles(unsigned log_n, int inverse, const u64** out) {
 
 // w^i for i in [0, n): the register-blocked kernels index it with products t * o that exceed n/2
 int get_full_twiddles(unsigned log_n, const u64** out) {
+  std::lock_guard<std::mutex> lock(tables_mutex());
   static std::map<unsigned, u64*> full;
   auto it = full.find(log_n);
   if (it == full.end()) {
@@ -402,6 +412,7 @@ int get_full_twiddles(unsigned log_n, const u64** out) {
     if (hipMalloc((void**)&d, count * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
     hipLaunchKernelGGL(k_powers, dim3(grid_for(count)), dim3(kBlock), 0, p2mt::rt().stream, d, h_root_of_unity(log_n), count);
     P2MT_LAUNCH_CHECK();
+    P2MT_HIP(hipStreamSynchronize(p2mt::rt().stream));
     it = full.emplace(log_n, d).first;
   }
   *out = it->second;
@@ -409,6 +420,7 @@ int get_full_twiddles(unsigned log_n, const u64** out) {
 }
 
 int get_coset_pows(unsigned log_n, unsigned rate_bits, u64 shift, const u64** out) {
+  std::lock_guard<std::mutex> lock(tables_mutex());
   auto key = std::make_tuple(log_n, rate_bits, shift);
   auto it = tables().coset_pows.find(key);
   if (it == tables().coset_pows.end()) {
@@ -421,6 +433,7 @@ int get_coset_pows(unsigned log_n, unsigned rate_bits, u64 shift, const u64** ou
       hipLaunchKernelGGL(k_powers, dim3(grid_for(n)), dim3(kBlock), 0, p2mt::rt().stream, d + j * n, base, n);
       P2MT_LAUNCH_CHECK();
     }
+    P2MT_HIP(hipStreamSynchronize(p2mt::rt().stream));
     it = tables().coset_pows.emplace(key, d).first;
   }
   *out = it->second;

@@ -17,10 +17,18 @@ struct PermCtx {
   uint64_t force_fallback;
 };
 
+// The library stream is per host thread: a thread that called p2mt_thread_stream_create() (or p2mt_set_stream) enqueues on
+// its own stream, every other thread on the default stream.  Together with per-thread scratch this makes distinct handles
+// usable from distinct threads concurrently (one prover per thread, SURVEY.md 8e "replicas").
+struct StreamRef {
+  operator hipStream_t() const;
+  StreamRef& operator=(hipStream_t s);
+};
+
 struct Runtime {
   bool initialised = false;
   int device = 0;
-  hipStream_t stream = nullptr;
+  StreamRef stream;
   int mds = 2;      // 0 = v_mad_u64_u32 MDS, 1 = v_dot2_u32_u16 MDS (exact variants), 2 = issue-optimised fast path
   int partial = 0;  // exact variants only: 0 = spec-form partial rounds, 1 = sparse form
   uint64_t* d_rc = nullptr;  // 360 round constants, device global memory
@@ -36,8 +44,9 @@ struct Runtime {
   static constexpr int kMaxProf = 256;
   hipEvent_t prof_ev[2 * kMaxProf] = {};
   int prof_n = 0;
-  char err[512] = {0};
 };
+char* err_buf();  // 512 bytes, per thread
+constexpr size_t kErrLen = 512;
 
 Runtime& rt();
 int fail_hip(hipError_t e, const char* what, const char* file, int line);
@@ -71,7 +80,7 @@ struct DevBuf {
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
       p = nullptr;
-      snprintf(rt().err, sizeof(rt().err), "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      snprintf(err_buf(), kErrLen, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
       return P2MT_ENOMEM;
     }
     return P2MT_OK;

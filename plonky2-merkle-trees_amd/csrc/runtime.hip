@@ -13,20 +13,31 @@ Runtime& rt() {
   return r;
 }
 
+namespace {
+thread_local hipStream_t tl_stream = nullptr;
+thread_local char tl_err[kErrLen] = {0};
+}  // namespace
+StreamRef::operator hipStream_t() const { return tl_stream; }
+StreamRef& StreamRef::operator=(hipStream_t s) {
+  tl_stream = s;
+  return *this;
+}
+char* err_buf() { return tl_err; }
+
 int fail_hip(hipError_t e, const char* what, const char* file, int line) {
-  snprintf(rt().err, sizeof(rt().err), "HIP error '%s' in %s (%s:%d)", hipGetErrorString(e), what, file, line);
+  snprintf(err_buf(), kErrLen, "HIP error '%s' in %s (%s:%d)", hipGetErrorString(e), what, file, line);
   (void)hipGetLastError();  // clear the sticky error
   return P2MT_EHIP;
 }
 
 int fail(int code, const char* msg) {
-  snprintf(rt().err, sizeof(rt().err), "%s", msg);
+  snprintf(err_buf(), kErrLen, "%s", msg);
   return code;
 }
 
 int scratch_get(int slot, size_t bytes, void** out) {
-  static void* ptr[kScratchCount] = {};
-  static size_t cap[kScratchCount] = {};
+  thread_local void* ptr[kScratchCount] = {};  // per thread: concurrent provers must not share scratch
+  thread_local size_t cap[kScratchCount] = {};
   if (bytes == 0) bytes = 8;
   if (bytes > cap[slot]) {
     if (ptr[slot]) {
@@ -124,6 +135,15 @@ extern "C" int p2mt_init(int device) {
   return P2MT_OK;
 }
 
+extern "C" int p2mt_thread_stream_create(void) {
+  P2MT_TRY(p2mt::ensure_init());
+  P2MT_HIP(hipSetDevice(rt().device));  // the current device is per thread too
+  hipStream_t s = nullptr;
+  P2MT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  rt().stream = s;
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_set_stream(void* hip_stream) {
   rt().stream = static_cast<hipStream_t>(hip_stream);
   return P2MT_OK;
@@ -135,7 +155,7 @@ extern "C" int p2mt_sync(void) {
   return P2MT_OK;
 }
 
-extern "C" const char* p2mt_last_error(void) { return rt().err; }
+extern "C" const char* p2mt_last_error(void) { return p2mt::err_buf(); }
 
 extern "C" int p2mt_set_variant(int mds, int partial) {
   if (mds < 0 || mds > 2 || partial < 0 || partial > 1) return p2mt::fail(P2MT_EINVAL, "variant out of range");

@@ -206,3 +206,45 @@ def test_global_memory_witness_path(pkg, oracle, monkeypatch):
     assert np.array_equal(gcd2.generate_witness(pw2), ocd.generate_witness(opw)[0])
     assert np.array_equal(gcd2.prove(pw2), want)
     assert np.array_equal(want, ocd.prove(opw))
+
+
+def test_d12_circuit_prove(pkg, oracle):
+    """A 4096-row circuit (1500 path elements: 3001 PoseidonGates, 751 ArithmeticGates): the degree of config 4's outer
+    circuit with real constraints -- global-memory witness path, register-blocked 2^12 LDE, two FRI reductions."""
+    case = synthetic_case(oracle, 1500, 3)
+    gcd, pw, ocd, opw = build_both(pkg, oracle, case)
+    assert gcd.degree_bits == 12
+    check_build(gcd, ocd)
+    check_prove(gcd, pw, ocd, opw)
+
+
+def test_concurrent_provers_on_threads(pkg, oracle):
+    """One prover per host thread, each on its own stream with its own circuit handle: proofs are the same words as
+    the sequential ones."""
+    import threading
+    cases = [synthetic_case(oracle, 20, 100 + i) for i in range(4)]
+    want = []
+    for case in cases:
+        gcd, pw, _, _ = build_both(pkg, oracle, case)
+        want.append(gcd.prove(pw))
+    got, errs = [None] * len(cases), []
+
+    def worker(i):
+        try:
+            pkg._native.check(pkg.lib().p2mt_thread_stream_create())
+            gcd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(20, 1)
+            pw = pkg.PartialWitness()
+            assign(leaf_t, proof_ts, peak_ts, gcd.prover_only.public_inputs, cases[i], pw.set_target)
+            for _ in range(5):
+                got[i] = gcd.prove(pw)
+        except Exception as e:  # surfaced below
+            errs.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
