@@ -432,7 +432,7 @@ def run_prove(args, torch, pkg, lib):
             t.join()
         dt = time.perf_counter() - t0
         assert not errs, errs
-        out["throughput"] = {"threads": args.threads, "proofs": int(sum(counts)), "seconds": dt,
+        out["throughput"] = {"threads": args.threads, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "proofs": int(sum(counts)), "seconds": dt,
                              "proofs_per_s": sum(counts) / dt, "amortised_ms_per_proof": dt * 1e3 / max(sum(counts), 1),
                              "note": "independent provers on one GPU, one per host thread and stream; `value` above stays the "
                                      "single-proof latency"}
@@ -466,13 +466,17 @@ def main():
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
     ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--threads", type=int, default=8, help="--workload prove: concurrent provers for the throughput leg (1 = skip)")
+    ap.add_argument("--threads", type=int, default=16, help="--workload prove: concurrent provers for the throughput leg (1 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --single-device exist only to exercise the N>1 code "
                          "path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="test only: every rank uses GPU 0")
     args = ap.parse_args()
 
+    if args.workload == "prove" and args.threads > 4:
+        # ROCm multiplexes streams onto 4 hardware queues by default; the concurrent-prover leg wants one per thread.
+        # Must be in the environment before the HIP runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.threads, 16)))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
