@@ -8,7 +8,9 @@
 //                                                  get_proof_normal_index, get_subtree_proof_elm}, MMR_proof::verify,
 //                                                  get_mmr_index, get_heights_bitmap_for_mmr_size
 // and, for the prover the reference drives through CircuitData::prove (mmr_plonky2_verifier.rs:148,
-// mmr_plonky2_verifier_1_recursion.rs:192,218), plonky2's PolynomialBatch, Challenger and prove_openings (FRI).
+// mmr_plonky2_verifier_1_recursion.rs:192,218), plonky2's PolynomialBatch, Challenger, prove_openings (FRI), and
+// CircuitBuilder / PartialWitness / CircuitData::prove with the reference's own circuit code on top
+//   src/mmr/common.rs : equal, or_list, pick_hash;  src/mmr/mmr_plonky2_verifier.rs : verify_mmr_proof_circuit.
 // Where the reference panics (assert!/unwrap/log2_strict) this throws p2mt::panic carrying the status code.
 // Getters take `this` by const reference instead of consuming `self` (Quirk Q7: callers no longer clone).
 // All hashing happens in libp2mt_hip.so on the GPU; this header only moves buffers.
@@ -322,6 +324,215 @@ inline std::vector<std::uint64_t> prove_openings(const std::vector<FriBatchInfo>
   std::vector<std::uint64_t> proof(total);
   check(p2mt_fri_prove_openings(o.data(), o.size(), b.data(), b.size(), &params, challenger.handle(), proof.data()));
   return proof;
+}
+
+// ---------------------------------------------------------------- plonky2 CircuitBuilder / CircuitData (plonk/circuit_builder.rs,
+// circuit_data.rs, iop/witness.rs) as the reference uses them at mmr_plonky2_verifier.rs:13-151
+using Target = p2mt_target;
+struct BoolTarget {
+  Target target;
+};
+struct HashOutTarget {
+  std::array<Target, 4> elements{};
+};
+
+class PartialWitness {  // PartialWitness::new() (:123)
+ public:
+  PartialWitness() { check(p2mt_pw_create(&h_)); }
+  ~PartialWitness() { p2mt_pw_destroy(h_); }
+  PartialWitness(const PartialWitness&) = delete;
+  PartialWitness& operator=(const PartialWitness&) = delete;
+  void set_target(Target t, GoldilocksField v) { check(p2mt_pw_set_target(h_, t, v)); }
+  void set_bool_target(BoolTarget t, bool v) { set_target(t.target, v ? 1 : 0); }
+  void set_hash_target(const HashOutTarget& t, const HashOut& v) {
+    for (int i = 0; i < 4; ++i) set_target(t.elements[i], v.elements[i]);
+  }
+  p2mt_partial_witness* handle() const { return h_; }
+
+ private:
+  p2mt_partial_witness* h_ = nullptr;
+};
+
+// ProofWithPublicInputs as the words p2mt_circuit_prove returns (field order of plonky2's serialisation, see p2mt.h)
+struct ProofWithPublicInputs {
+  std::vector<std::uint64_t> words;
+  std::vector<GoldilocksField> public_inputs;
+};
+
+class CircuitData {  // CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2>; prover data resident on the device
+ public:
+  explicit CircuitData(p2mt_circuit_data* h) : h_(h) {
+    check(p2mt_circuit_get_info(h_, &info));
+    prover_only.public_inputs.resize(info.num_public_inputs);
+    check(p2mt_circuit_public_inputs(h_, prover_only.public_inputs.data()));
+  }
+  ~CircuitData() { p2mt_circuit_destroy(h_); }
+  CircuitData(const CircuitData&) = delete;
+  CircuitData& operator=(const CircuitData&) = delete;
+  CircuitData(CircuitData&& o) noexcept : info(o.info), prover_only(std::move(o.prover_only)), h_(o.h_) { o.h_ = nullptr; }
+
+  ProofWithPublicInputs prove(const PartialWitness& pw) {  // circuit_data.prove(pw) (:148)
+    ProofWithPublicInputs p;
+    p.words.resize(info.proof_len);
+    check(p2mt_circuit_prove(h_, pw.handle(), p.words.data(), p.words.size()));
+    p.public_inputs.assign(p.words.end() - info.num_public_inputs, p.words.end());
+    return p;
+  }
+  HashOut circuit_digest() const {
+    HashOut d;
+    check(p2mt_circuit_constants_sigmas(h_, nullptr, nullptr, d.elements.data()));
+    return d;
+  }
+  p2mt_circuit_info info{};
+  struct {
+    std::vector<Target> public_inputs;
+  } prover_only;
+
+ private:
+  p2mt_circuit_data* h_ = nullptr;
+};
+
+class CircuitBuilder {  // CircuitBuilder::<F, 2>::new(CircuitConfig::standard_recursion_config()) (:30-31)
+ public:
+  CircuitBuilder() { check(p2mt_cb_create(&h_)); }
+  ~CircuitBuilder() { p2mt_cb_destroy(h_); }
+  CircuitBuilder(const CircuitBuilder&) = delete;
+  CircuitBuilder& operator=(const CircuitBuilder&) = delete;
+
+  Target add_virtual_target() { return out1(p2mt_cb_add_virtual_target); }
+  HashOutTarget add_virtual_hash() {
+    HashOutTarget h;
+    for (auto& e : h.elements) e = add_virtual_target();
+    return h;
+  }
+  BoolTarget add_virtual_bool_target_safe() { return BoolTarget{out1(p2mt_cb_add_virtual_bool_target_safe)}; }
+  Target constant(GoldilocksField c) {
+    Target t;
+    check(p2mt_cb_constant(h_, c, &t));
+    return t;
+  }
+  Target zero() { return constant(0); }
+  Target one() { return constant(1); }
+  void connect(Target x, Target y) { check(p2mt_cb_connect(h_, x, y)); }
+  Target mul(Target x, Target y) { return out3(p2mt_cb_mul, x, y); }
+  Target add(Target x, Target y) { return out3(p2mt_cb_add, x, y); }
+  Target sub(Target x, Target y) { return out3(p2mt_cb_sub, x, y); }
+  Target mul_add(Target x, Target y, Target z) {
+    Target t;
+    check(p2mt_cb_mul_add(h_, x, y, z, &t));
+    return t;
+  }
+  BoolTarget not_(BoolTarget b) {
+    Target t;
+    check(p2mt_cb_not(h_, b.target, &t));
+    return BoolTarget{t};
+  }
+  BoolTarget or_(BoolTarget a, BoolTarget b) { return BoolTarget{out3(p2mt_cb_or, a.target, b.target)}; }
+  BoolTarget is_equal(Target x, Target y) { return BoolTarget{out3(p2mt_cb_is_equal, x, y)}; }
+  HashOutTarget hash_or_noop(const std::vector<Target>& inputs) {  // hash_or_noop::<PoseidonHash>
+    HashOutTarget h;
+    check(p2mt_cb_hash_or_noop(h_, inputs.data(), inputs.size(), h.elements.data()));
+    return h;
+  }
+  HashOutTarget hash_n_to_hash_no_pad(const std::vector<Target>& inputs) {
+    HashOutTarget h;
+    check(p2mt_cb_hash_n_to_hash_no_pad(h_, inputs.data(), inputs.size(), h.elements.data()));
+    return h;
+  }
+  void register_public_inputs(const std::array<Target, 4>& t) { check(p2mt_cb_register_public_inputs(h_, t.data(), 4)); }
+  CircuitData build() {  // builder.build::<C>() (:89)
+    p2mt_circuit_data* c = nullptr;
+    check(p2mt_cb_build(h_, &c));
+    return CircuitData(c);
+  }
+
+ private:
+  Target out1(int (*f)(p2mt_circuit_builder*, p2mt_target*)) {
+    Target t;
+    check(f(h_, &t));
+    return t;
+  }
+  Target out3(int (*f)(p2mt_circuit_builder*, p2mt_target, p2mt_target, p2mt_target*), Target x, Target y) {
+    Target t;
+    check(f(h_, x, y, &t));
+    return t;
+  }
+  p2mt_circuit_builder* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- src/mmr/common.rs:5-58
+inline BoolTarget equal(CircuitBuilder& builder, const HashOutTarget& first, const HashOutTarget& second) {
+  const BoolTarget elm0 = builder.is_equal(first.elements[0], second.elements[0]);
+  const BoolTarget elm1 = builder.is_equal(first.elements[1], second.elements[1]);
+  const BoolTarget elm2 = builder.is_equal(first.elements[2], second.elements[2]);
+  const BoolTarget elm3 = builder.is_equal(first.elements[3], second.elements[3]);
+  const BoolTarget elm0_or_elm1 = builder.or_(elm0, elm1);
+  const BoolTarget elm2_or_elm3 = builder.or_(elm2, elm3);
+  return builder.or_(elm0_or_elm1, elm2_or_elm3);
+}
+inline BoolTarget or_list(CircuitBuilder& builder, const std::vector<BoolTarget>& ins) {
+  if (ins.empty()) throw panic(P2MT_EINVAL, "assert!(ins.len() > 0)");
+  if (ins.size() == 1) return ins[0];
+  if (ins.size() == 2) return builder.or_(ins[0], ins[1]);
+  std::vector<BoolTarget> pairs;
+  for (std::size_t i = 0; i < ins.size(); i += 2) pairs.push_back(i + 1 < ins.size() ? builder.or_(ins[i], ins[i + 1]) : ins[i]);
+  return or_list(builder, pairs);
+}
+inline HashOutTarget pick_hash(CircuitBuilder& builder, const HashOutTarget& option1, const HashOutTarget& option2,
+                               BoolTarget pick_left) {
+  const BoolTarget opposite = builder.not_(pick_left);
+  HashOutTarget out;
+  for (int i = 0; i < 4; ++i) {
+    const Target t = builder.mul(option2.elements[i], opposite.target);
+    out.elements[i] = builder.mul_add(option1.elements[i], pick_left.target, t);
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------- src/mmr/mmr_plonky2_verifier.rs:13-91
+struct MmrVerifierCircuit {
+  CircuitData data;
+  Target leaf_to_prove;
+  std::vector<std::pair<HashOutTarget, BoolTarget>> proof_targets;
+  std::vector<HashOutTarget> peak_targets;
+};
+inline MmrVerifierCircuit verify_mmr_proof_circuit(std::size_t nr_merkle_proof_elms, std::size_t nr_peaks) {
+  std::vector<std::pair<HashOutTarget, BoolTarget>> proof_targets;
+  std::vector<HashOutTarget> peak_targets;
+  CircuitBuilder builder;
+  const Target leaf_to_prove = builder.add_virtual_target();
+  HashOutTarget next_hash = builder.hash_or_noop({leaf_to_prove});
+  auto cat = [](const HashOutTarget& a, const HashOutTarget& b) {
+    std::vector<Target> v(a.elements.begin(), a.elements.end());
+    v.insert(v.end(), b.elements.begin(), b.elements.end());
+    return v;
+  };
+  for (std::size_t k = 0; k < nr_merkle_proof_elms; ++k) {
+    const HashOutTarget merkle_proof_elm = builder.add_virtual_hash();
+    const BoolTarget elm_on_left = builder.add_virtual_bool_target_safe();
+    proof_targets.emplace_back(merkle_proof_elm, elm_on_left);
+    const HashOutTarget option1 = builder.hash_or_noop(cat(merkle_proof_elm, next_hash));  // sibling on the left
+    const HashOutTarget option2 = builder.hash_or_noop(cat(next_hash, merkle_proof_elm));  // sibling on the right
+    next_hash = pick_hash(builder, option1, option2, elm_on_left);
+  }
+  std::vector<HashOutTarget> peaks;
+  std::vector<BoolTarget> equals;
+  for (std::size_t k = 0; k < nr_peaks; ++k) {
+    const HashOutTarget peak = builder.add_virtual_hash();
+    peaks.push_back(peak);
+    peak_targets.push_back(peak);
+    equals.push_back(equal(builder, peak, next_hash));
+  }
+  const BoolTarget hash_in_peaks = or_list(builder, equals);
+  builder.connect(builder.one(), hash_in_peaks.target);
+  if (peaks.size() > 1) {
+    std::vector<Target> all;
+    for (auto& p : peaks) all.insert(all.end(), p.elements.begin(), p.elements.end());
+    builder.register_public_inputs(builder.hash_n_to_hash_no_pad(all).elements);
+  } else {
+    builder.register_public_inputs(peaks.at(0).elements);
+  }
+  return MmrVerifierCircuit{builder.build(), leaf_to_prove, std::move(proof_targets), std::move(peak_targets)};
 }
 
 }  // namespace p2mt

@@ -154,6 +154,52 @@ static void test_challenger_and_fri() {
   REQUIRE(out[0] == 1210260379ull && out[1] == 490064140ull);
 }
 
+// mmr_plonky2_verifier.rs:102-151 (test_mmr_verifier) with fixed leaves 1, 2, 3 and leaf index 1: MMR -> proof -> circuit
+// -> witness -> prove.  The reference ends in plonky2's `circuit_data.verify(proof)`; here the proof words are compared
+// with the committed vector tests/golden/prove_vectors.json ("mmr_leaves_1_2_3_index_1", generated from the CPU
+// restatement, whose verifier accepts it).
+static void test_mmr_verifier_3leaves() {
+  const std::vector<GoldilocksField> leaves = {1, 2, 3};
+  MMR mmr = MMR::new_();
+  for (auto l : leaves) mmr.add_leaf(l);
+  const MMR_proof pr = mmr.get_proof(get_mmr_index(1));
+  const HashOut root = mmr.bagging_the_peaks();
+  REQUIRE(pr.verify(leaves[1], root));
+  MmrVerifierCircuit c = verify_mmr_proof_circuit(pr.merkle_proof.size(), pr.peaks.size());
+  PartialWitness pw;
+  pw.set_target(c.leaf_to_prove, leaves[1]);
+  for (std::size_t i = 0; i < pr.merkle_proof.size(); ++i) {
+    pw.set_hash_target(c.proof_targets[i].first, pr.merkle_proof[i].first);
+    pw.set_bool_target(c.proof_targets[i].second, pr.merkle_proof[i].second);
+  }
+  for (std::size_t i = 0; i < pr.peaks.size(); ++i) pw.set_hash_target(c.peak_targets[i], pr.peaks[i]);
+  for (int i = 0; i < 4; ++i) pw.set_target(c.data.prover_only.public_inputs[i], root.elements[i]);
+  const ProofWithPublicInputs proof = c.data.prove(pw);
+  REQUIRE(c.data.info.degree_bits == 4 && proof.words.size() == 9227);
+  REQUIRE(c.data.circuit_digest() == H(2387031506227268098ull, 3067738749168534497ull, 896570144414144072ull, 14594062208619418531ull));
+  REQUIRE(proof.public_inputs.size() == 4);
+  for (int i = 0; i < 4; ++i) REQUIRE(proof.public_inputs[i] == root.elements[i]);
+  REQUIRE(root == H(14051017894672733496ull, 17897758925374905203ull, 11557515652286392125ull, 12346532418229956107ull));
+  std::uint64_t acc = 0;
+  for (std::size_t i = 0; i < proof.words.size(); ++i) acc += (std::uint64_t)(i + 1) * proof.words[i];
+  REQUIRE(acc == 18040206062003008092ull);  // proof_weighted_checksum of the golden vector
+  // a wrong side bit contradicts the circuit: plonky2 panics in witness generation
+  PartialWitness bad;
+  bad.set_target(c.leaf_to_prove, leaves[1]);
+  for (std::size_t i = 0; i < pr.merkle_proof.size(); ++i) {
+    bad.set_hash_target(c.proof_targets[i].first, pr.merkle_proof[i].first);
+    bad.set_bool_target(c.proof_targets[i].second, !pr.merkle_proof[i].second);
+  }
+  for (std::size_t i = 0; i < pr.peaks.size(); ++i) bad.set_hash_target(c.peak_targets[i], pr.peaks[i]);
+  bool panicked = false;
+  try {
+    c.data.prove(bad);
+  } catch (const panic& e) {
+    panicked = e.code == P2MT_EINVAL;
+  }
+  REQUIRE(panicked);
+}
+
 int main() {
   if (p2mt_device_count() == 0) { std::fprintf(stderr, "no GPU: the product has no CPU fallback\n"); return 77; }
   check(p2mt_init(0));
@@ -166,6 +212,7 @@ int main() {
   test_mmr_add_leaf();
   test_get_proof();
   test_challenger_and_fri();
+  test_mmr_verifier_3leaves();
   std::puts("cpp mirror: 8 reference tests + prover pieces passed");
   return 0;
 }

@@ -248,3 +248,20 @@ def test_concurrent_provers_on_threads(pkg, oracle):
     assert not errs, errs
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def test_golden_prove_vectors(pkg, golden):
+    """The committed vectors (tests/golden/prove_vectors.json, generated from the oracle) through the HIP prover alone."""
+    import hashlib
+    for c in golden["prove_vectors"]["cases"]:
+        case = (c["leaf"], np.array(c["siblings"], np.uint64).reshape(-1, 4), np.array(c["lefts"], np.uint8),
+                np.array(c["peaks"], np.uint64).reshape(-1, 4), np.array(c["root"], np.uint64))
+        gcd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(len(case[1]), len(case[3]))
+        pw = pkg.PartialWitness()
+        assign(leaf_t, proof_ts, peak_ts, gcd.prover_only.public_inputs, case, pw.set_target)
+        assert gcd.degree_bits == c["degree_bits"]
+        assert [int(x) for x in gcd.constants_sigmas()[2]] == c["circuit_digest"]
+        proof = gcd.prove(pw)
+        assert proof.size == c["proof_len"]
+        assert hashlib.sha256(proof.astype("<u8").tobytes()).hexdigest() == c["proof_sha256"]
+        assert [int(x) for x in proof[-len(c["public_inputs"]):]] == c["public_inputs"]

@@ -108,3 +108,19 @@ def test_inner_circuit_of_the_recursion(oracle, n_leaves, idx):
     proof = cd.prove(pw)
     assert cd.verify(proof) == (True, 0)
     assert np.array_equal(proof[-4 * len(peaks):], peaks.reshape(-1))
+
+
+def test_golden_prove_vectors(oracle, golden):
+    """The committed vectors (tools/gen_prove_golden.py) still come out of the restatement: statement -> circuit digest
+    and proof words."""
+    import hashlib
+    for c in golden["prove_vectors"]["cases"]:
+        case = (c["leaf"], np.array(c["siblings"], np.uint64).reshape(-1, 4), np.array(c["lefts"], np.uint8),
+                np.array(c["peaks"], np.uint64).reshape(-1, 4), np.array(c["root"], np.uint64))
+        cd, pw = build_and_assign(oracle, case)
+        assert cd.degree_bits == c["degree_bits"] and [int(x) for x in cd.circuit_digest] == c["circuit_digest"]
+        proof = cd.prove(pw)
+        assert proof.size == c["proof_len"]
+        assert hashlib.sha256(proof.astype("<u8").tobytes()).hexdigest() == c["proof_sha256"]
+        assert [int(x) for x in proof[:8]] == c["proof_first_words"]
+        assert [int(x) for x in proof[-len(c["public_inputs"]):]] == c["public_inputs"]
