@@ -380,6 +380,12 @@ int p2mt_circuit_generate_witness(p2mt_circuit_data *c, const p2mt_partial_witne
  *   FriProof (layout at p2mt_fri_proof_len) | public_inputs [num_public_inputs]
  * Deterministic (the PublicInputGate's unused wires stay zero where plonky2 randomises them; smallest proof-of-work witness). */
 int p2mt_circuit_prove(p2mt_circuit_data *c, const p2mt_partial_witness *pw, uint64_t *proof_out, size_t proof_cap);
+/* circuit_data.verify(proof) (:150).  The transcript (Challenger) and every Merkle path (28 queries x (4 oracle rows + one
+ * coset per FRI layer), one wavefront each) run on the device; the field arithmetic (vanishing polynomial at zeta, FRI
+ * folding) is a few thousand extension-field multiplications on the host.  Returns 0 with *accepted = 1/0 and *reason (may
+ * be NULL): 0 ok, 10 malformed (length / non-canonical word), 11 vanishing polynomial != Z_H * quotient at zeta, 1 proof of
+ * work, 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 inconsistent layer value, 5 final polynomial. */
+int p2mt_circuit_verify(p2mt_circuit_data *c, const uint64_t *proof, size_t proof_len, int *accepted, int *reason);
 /* intermediates of the last prove (parity tests): 0 wires [135][n], 1 Z | partial products [20][n] (values), 2 quotient chunks
  * [16][n] (coefficients), 3 challenges {betas[2], gammas[2], alphas[2], zeta[2]}, 4 public_inputs_hash [4] */
 int p2mt_circuit_prove_trace(const p2mt_circuit_data *c, int what, uint64_t *out);

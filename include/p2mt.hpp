@@ -378,6 +378,12 @@ class CircuitData {  // CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2
     p.public_inputs.assign(p.words.end() - info.num_public_inputs, p.words.end());
     return p;
   }
+  // circuit_data.verify(proof) (:150): throws where plonky2 returns Err
+  void verify(const ProofWithPublicInputs& proof) {
+    int accepted = 0, reason = 0;
+    check(p2mt_circuit_verify(h_, proof.words.data(), proof.words.size(), &accepted, &reason));
+    if (!accepted) throw panic(P2MT_EINVAL, "proof rejected (reason " + std::to_string(reason) + ")");
+  }
   HashOut circuit_digest() const {
     HashOut d;
     check(p2mt_circuit_constants_sigmas(h_, nullptr, nullptr, d.elements.data()));

@@ -147,6 +147,7 @@ SIGNATURES = {
     "p2mt_circuit_generate_witness": (C.c_int, [voidp, voidp, voidp]),
     "p2mt_circuit_prove": (C.c_int, [voidp, voidp, voidp, C.c_size_t]),
     "p2mt_circuit_prove_trace": (C.c_int, [voidp, C.c_int, voidp]),
+    "p2mt_circuit_verify": (C.c_int, [voidp, voidp, C.c_size_t, intp, intp]),
 }
 
 

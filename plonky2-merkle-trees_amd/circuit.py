@@ -174,6 +174,18 @@ class CircuitData:
         N.check(N.lib().p2mt_circuit_prove(self._h, pw._h, N.ptr(proof), proof.size))
         return proof
 
+    def verify(self, proof, with_reason=False):
+        """circuit_data.verify(proof): raises P2mtPanic (plonky2 returns Err) unless the proof is accepted; with_reason=True
+        returns (accepted, reason) instead (reasons: include/p2mt.h)."""
+        p = N.as_u64(proof).reshape(-1)
+        acc, reason = C.c_int(0), C.c_int(0)
+        N.check(N.lib().p2mt_circuit_verify(self._h, N.ptr(p), p.size, C.byref(acc), C.byref(reason)))
+        if with_reason:
+            return bool(acc.value), reason.value
+        if not acc.value:
+            raise N.P2mtPanic(N.P2MT_EINVAL, "proof rejected (reason %d)" % reason.value)
+        return True
+
     def prove_trace(self):
         n = 1 << self.degree_bits
         out = {}

@@ -87,6 +87,7 @@ struct p2mt_circuit_builder {
   std::map<std::tuple<u64, u64, u64, u64, u64>, u64> arith_results;
   std::map<std::pair<u64, u64>, std::pair<u32, u32>> slots;  // (c0, c1) -> (row, next free operation)
   std::vector<u64> public_inputs;
+  bool built = false;  // build() consumes the builder, as plonky2's does
 };
 
 struct p2mt_partial_witness {
@@ -121,6 +122,10 @@ struct p2mt_circuit_data {
   int* d_err = nullptr;  // [0] witness conflict (op index + 1, or -1 unset public input), [1] zero denominator
   size_t init_cap = 0, ops_cap = 0, lds_bytes = 0;  // lds_bytes != 0: the value table fits LDS (k_witness_lds)
   p2mt_challenger* ch = nullptr;
+  // verifier scratch (allocated on the first p2mt_circuit_verify)
+  u64* d_verify = nullptr;
+  p2mt_challenger* vch = nullptr;
+  u64 k_is[kNumRouted] = {};
 };
 
 namespace {
@@ -575,6 +580,55 @@ __global__ __launch_bounds__(kBlock) void k_opening_set(const u64* __restrict__ 
   out[t] = fri_order[src];
 }
 
+// inverse of k_opening_set: the order the challenger observes (FriOpenings) from the proof's OpeningSet order
+__global__ __launch_bounds__(kBlock) void k_opening_unset(const u64* __restrict__ set_order, u64* __restrict__ out, u32 n_cs) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  const u32 a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot), total = a + 2 * kNumCh + tail;
+  if (t >= total) return;
+  u32 dst;
+  if (t < a) dst = t;
+  else if (t < a + 2 * kNumCh) dst = a + tail + (t - a);
+  else dst = t - 2 * kNumCh;
+  out[dst] = set_order[t];
+}
+
+// verify_merkle_proof_to_cap for every (query, tree) pair of a proof: one wavefront per pair hashes the opened row
+// (hash_or_noop) and folds the path on the 12-lanes-per-permutation layout; *bad = 1 + the first failing pair.
+struct VItem {
+  u32 leaf_off, width, index, sib_off, n_sib, cap_off;
+};
+__global__ __launch_bounds__(kBlock) void k_verify_merkle(const u64* __restrict__ words, const VItem* __restrict__ items, u32 n_items,
+                                                          int* bad, PermCtx ctx) {
+  const u32 item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= n_items) return;  // wave-uniform
+  const u32 lane = threadIdx.x & 63;
+  const VItem it = items[item];
+  u64 x = 0;
+  if (it.width <= 4) {
+    if (lane < it.width) x = gl::canon(words[it.leaf_off + lane]);
+  } else {
+#pragma unroll 1
+    for (u32 off = 0; off < it.width; off += 8) {
+      if (lane < 8 && off + lane < it.width) x = words[it.leaf_off + off + lane];
+      x = permute_wave(x, ctx);
+    }
+    x = gl::canon(x);
+  }
+  u32 index = it.index;
+#pragma unroll 1
+  for (u32 s = 0; s < it.n_sib; ++s, index >>= 1) {
+    const u64 up = __shfl_up((unsigned long long)x, 4);  // lanes 4..7 see the current digest
+    const u64 sib = lane < 8 ? words[it.sib_off + 4 * s + (lane & 3)] : 0;
+    const bool sib_left = index & 1;
+    u64 y = 0;
+    if (lane < 4) y = sib_left ? sib : x;
+    else if (lane < 8) y = sib_left ? up : sib;
+    x = gl::canon(permute_wave(y, ctx));
+  }
+  const bool mismatch = lane < 4 && x != words[it.cap_off + 4 * index + lane];
+  if (__any(mismatch) && lane == 0) atomicMin(bad, (int)item + 1);
+}
+
 size_t digests_count(size_t n, unsigned cap_height) {
   size_t c = 0;
   for (unsigned j = 0; ((size_t)n >> j) > ((size_t)1 << cap_height); ++j) c += n >> j;
@@ -873,6 +927,8 @@ extern "C" size_t p2mt_cb_num_gates(const p2mt_circuit_builder* b) { return b ? 
 extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (!c) return P2MT_OK;
   if (c->ch) p2mt_challenger_destroy(c->ch);
+  if (c->vch) p2mt_challenger_destroy(c->vch);
+  if (c->d_verify) (void)hipFree(c->d_verify);
   if (c->d_base) {
     (void)hipStreamSynchronize(rt().stream);
     (void)hipFree(c->d_base);
@@ -884,6 +940,8 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
 extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   CB_ARGS(b, out);
   P2MT_TRY(p2mt::ensure_init());
+  if (b->built) return p2mt::fail(P2MT_EINVAL, "build: this builder was already built (CircuitBuilder::build consumes self)");
+  b->built = true;
   // public-input hash routed into a PublicInputGate
   u64 pi_hash_t[4];
   P2MT_TRY(cb_hash_no_pad(b, b->public_inputs.data(), b->public_inputs.size(), pi_hash_t));
@@ -1075,6 +1133,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   std::vector<u32> pi_slot(c->n_pi);
   for (u32 k = 0; k < c->n_pi; ++k) pi_slot[k] = c->slot_of[target_index(c, c->public_inputs[k])];
   P2MT_HIP(hipMemcpyAsync(c->d_cs_vals, c->h_cs.data(), c->h_cs.size() * 8, hipMemcpyHostToDevice, st));
+  std::copy(k_is, k_is + kNumRouted, c->k_is);
   P2MT_HIP(hipMemcpyAsync(c->d_kis, k_is, sizeof k_is, hipMemcpyHostToDevice, st));
   P2MT_HIP(hipMemcpyAsync(c->d_wire_slot, c->slot_of.data(), n * kNumWires * 4, hipMemcpyHostToDevice, st));
   if (c->n_pi) P2MT_HIP(hipMemcpyAsync(c->d_pi_slot, pi_slot.data(), c->n_pi * 4, hipMemcpyHostToDevice, st));
@@ -1271,5 +1330,131 @@ extern "C" int p2mt_circuit_prove_trace(const p2mt_circuit_data* c, int what, ui
   }
   P2MT_HIP(hipMemcpyAsync(out, src, words * 8, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
+// ==================================================================================================== verify
+// circuit_data.verify(proof) (mmr_plonky2_verifier.rs:150): transcript and Merkle paths on the device (two launches chains and
+// two small copies), the field arithmetic on the host (p2mt_verify_host.hip).  *accepted = 1/0; *reason: 0 ok, 10 malformed
+// (length, non-canonical word), 11 vanishing polynomial != Z_H * quotient at zeta (or zeta in the subgroup), 1 proof of work,
+// 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 layer value inconsistent, 5 final polynomial.
+extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, size_t proof_len, int* accepted, int* reason) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || !proof || !accepted) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  int dummy = 0;
+  if (!reason) reason = &dummy;
+  *accepted = 0;
+  *reason = 10;
+  if (proof_len != c->proof_len) return P2MT_OK;
+  for (size_t k = 0; k < proof_len; ++k)
+    if (proof[k] >= gl::P) return P2MT_OK;
+  const u32 n_cs = c->n_cs, log_n = c->degree_bits, log_big = log_n + kRateBits, nred = c->fri.num_reductions;
+  const size_t n_open = n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
+  const size_t off_open = 192, off_fri = off_open + 2 * n_open, off_pi = c->proof_len - c->n_pi;
+  unsigned total_arity = 0;
+  for (u32 l = 0; l < nred; ++l) total_arity += c->fri.reduction_arity_bits[l];
+  const size_t final_len = (size_t)1 << (log_n - total_arity), nq = c->fri.num_query_rounds;
+  const size_t off_final = off_fri + c->fri_len - 1 - 2 * final_len;
+  // device layout: digest | pi_hash | proof | cs_cap | openings in transcript order | challenges | flag | items
+  const size_t max_items = nq * (4 + nred);
+  const size_t o_proof = 8, o_cscap = o_proof + c->proof_len, o_fo = o_cscap + 64, o_out = o_fo + 2 * n_open;
+  const size_t n_out = 8 + 2 + 2 * 8 + 1 + nq, o_flag = o_out + n_out + 1, o_items = o_flag + 1;
+  const size_t words = o_items + (max_items * sizeof(VItem) + 7) / 8 + 1;
+  hipStream_t st = rt().stream;
+  if (!c->d_verify) {
+    if (hipMalloc((void**)&c->d_verify, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(verify) failed");
+    P2MT_TRY(p2mt_challenger_create(&c->vch));
+  }
+  u64* dv = c->d_verify;
+  P2MT_HIP(hipMemcpyAsync(dv, c->digest, 32, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(dv + o_proof, proof, c->proof_len * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(dv + o_cscap, c->cs_cap, sizeof c->cs_cap, hipMemcpyHostToDevice, st));
+  if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(dv + o_proof + off_pi, 1, c->n_pi, 0, dv + 4));
+  else P2MT_HIP(hipMemsetAsync(dv + 4, 0, 32, st));
+  // the whole transcript depends only on the proof: enqueue it in one go
+  u64* d_out = dv + o_out;
+  P2MT_TRY(p2mt_challenger_reset(c->vch));
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv, 8 + 64, d_out, 2 * kNumCh));                       // betas, gammas
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + 64, 64, d_out + 2 * kNumCh, kNumCh));    // alphas
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + 128, 64, d_out + 3 * kNumCh, 2));         // zeta
+  hipLaunchKernelGGL(k_opening_unset, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)(dv + o_proof + off_open),
+                     dv + o_fo, n_cs);
+  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_fo, 2 * n_open, d_out + 8, 2));                    // FRI alpha
+  for (u32 l = 0; l < nred; ++l)
+    P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + off_fri + 64 * l, 64, d_out + 10 + 2 * l, 2));  // FRI betas
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + off_final, 2 * final_len + 1, d_out + 26, 1));    // PoW response
+  P2MT_TRY(p2mt_challenger_get_challenges_dev(c->vch, nq, d_out + 27));                                      // query indices
+  std::vector<u64> out(n_out), pi_hash(4);
+  P2MT_HIP(hipMemcpyAsync(out.data(), d_out, n_out * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(pi_hash.data(), dv + 4, 32, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  const u64 *betas = &out[0], *gammas = &out[kNumCh], *alphas = &out[2 * kNumCh], *zeta = &out[3 * kNumCh];
+
+  p2mt::VerifyDesc vd{};
+  vd.degree_bits = log_n, vd.num_wires = kNumWires, vd.num_routed = kNumRouted, vd.num_constants = kNumConsts;
+  vd.num_selectors = c->num_selectors, vd.num_challenges = kNumCh, vd.quotient_degree_factor = kQF, vd.n_kinds = c->n_kinds;
+  for (u32 g = 0; g < G_KINDS; ++g) vd.kind[g] = c->kind[g], vd.sel[g] = c->sel[g], vd.gs[g] = c->gs[g], vd.ge[g] = c->ge[g];
+  *reason = 11;
+  if (!p2mt::verify_openings_host(vd, c->k_is, zeta, proof + off_open, pi_hash.data(), betas, gammas, alphas)) return P2MT_OK;
+  *reason = 1;
+  if (c->fri.proof_of_work_bits && (out[26] >> (64 - c->fri.proof_of_work_bits)) != 0) return P2MT_OK;
+
+  // Merkle paths of every query: oracle rows against the four caps, layer cosets against the layer caps
+  const size_t big = (size_t)1 << log_big;
+  const uint64_t n_polys[4] = {n_cs, kNumWires, kNumZs, kNumQuot};
+  const u32 cap_off[4] = {(u32)o_cscap, (u32)o_proof, (u32)o_proof + 64, (u32)o_proof + 128};
+  std::vector<VItem> items;
+  std::vector<u64> x_indices(nq);
+  std::vector<char> is_layer;
+  size_t w = o_proof + off_fri + (size_t)nred * 64;
+  for (size_t q = 0; q < nq; ++q) {
+    size_t x_index = (size_t)(out[27 + q] % big);
+    x_indices[q] = x_index;
+    for (u32 o = 0; o < 4; ++o) {
+      items.push_back(VItem{(u32)w, (u32)n_polys[o], (u32)x_index, (u32)(w + n_polys[o]), log_big - kCapHeight, cap_off[o]});
+      is_layer.push_back(0);
+      w += n_polys[o] + 4 * (size_t)(log_big - kCapHeight);
+    }
+    unsigned log_sz = log_big;
+    for (u32 l = 0; l < nred; ++l) {
+      const unsigned ab = c->fri.reduction_arity_bits[l];
+      const size_t arity = (size_t)1 << ab;
+      x_index >>= ab;
+      const u32 n_sib = log_sz - ab - kCapHeight;
+      items.push_back(VItem{(u32)w, (u32)(2 * arity), (u32)x_index, (u32)(w + 2 * arity), n_sib, (u32)(o_proof + off_fri + 64 * l)});
+      is_layer.push_back(1);
+      w += 2 * arity + 4 * (size_t)n_sib;
+      log_sz -= ab;
+    }
+  }
+  int* d_flag = reinterpret_cast<int*>(dv + o_flag);
+  VItem* d_items = reinterpret_cast<VItem*>(dv + o_items);
+  const int big_flag = 0x7FFFFFFF;
+  P2MT_HIP(hipMemcpyAsync(d_flag, &big_flag, sizeof big_flag, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(VItem), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_verify_merkle, dim3((unsigned)((items.size() + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
+                     (const u64*)dv, (const VItem*)d_items, (u32)items.size(), d_flag, p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  int flag = 0;
+  P2MT_HIP(hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  if (flag != big_flag) {
+    *reason = is_layer[(size_t)flag - 1] ? 4 : 2;
+    return P2MT_OK;
+  }
+  // openings in transcript order for the FRI arithmetic (host reorder of the OpeningSet)
+  std::vector<u64> fo(2 * n_open);
+  {
+    const u64* so = proof + off_open;
+    const size_t a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot);
+    std::copy(so, so + a, fo.begin());
+    std::copy(so + a + 2 * kNumCh, so + a + 2 * kNumCh + tail, fo.begin() + a);
+    std::copy(so + a, so + a + 2 * kNumCh, fo.begin() + a + tail);
+  }
+  const int r = p2mt::verify_fri_queries_host(c->fri, n_polys, 4, kNumCh, zeta, fo.data(), &out[8], &out[10], proof + off_fri,
+                                              c->fri_len, x_indices.data());
+  *reason = r;
+  *accepted = r == 0;
   return P2MT_OK;
 }

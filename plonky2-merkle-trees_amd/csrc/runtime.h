@@ -115,6 +115,17 @@ int partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_sigmas
                                const uint64_t* d_betas, const uint64_t* d_gammas, size_t num_challenges, size_t num_routed,
                                unsigned degree_bits, unsigned chunk, uint64_t* d_q_scratch, uint64_t* d_out, int* d_zero_den);
 
+// exported by p2mt_verify_host.hip: the field arithmetic of CircuitData::verify (the hashing runs on the device)
+struct VerifyDesc {
+  uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, n_kinds;
+  uint32_t kind[5], sel[5], gs[5], ge[5];
+};
+int verify_openings_host(const VerifyDesc& d, const uint64_t* k_is, const uint64_t zeta[2], const uint64_t* openings,
+                         const uint64_t pi_hash[4], const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas);
+int verify_fri_queries_host(const p2mt_fri_params& p, const uint64_t* n_polys, size_t n_oracles, size_t n_next,
+                            const uint64_t zeta[2], const uint64_t* openings, const uint64_t alpha[2], const uint64_t* betas,
+                            const uint64_t* fri_proof, size_t fri_len, const uint64_t* x_indices);
+
 }  // namespace p2mt
 
 #define P2MT_HIP(x)                                                           \

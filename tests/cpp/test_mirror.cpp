@@ -183,6 +183,16 @@ static void test_mmr_verifier_3leaves() {
   std::uint64_t acc = 0;
   for (std::size_t i = 0; i < proof.words.size(); ++i) acc += (std::uint64_t)(i + 1) * proof.words[i];
   REQUIRE(acc == 18040206062003008092ull);  // proof_weighted_checksum of the golden vector
+  c.data.verify(proof);                      // circuit_data.verify(proof) (:150)
+  ProofWithPublicInputs forged = proof;
+  forged.words[200] ^= 1;
+  bool rejected = false;
+  try {
+    c.data.verify(forged);
+  } catch (const panic&) {
+    rejected = true;
+  }
+  REQUIRE(rejected);
   // a wrong side bit contradicts the circuit: plonky2 panics in witness generation
   PartialWitness bad;
   bad.set_target(c.leaf_to_prove, leaves[1]);
