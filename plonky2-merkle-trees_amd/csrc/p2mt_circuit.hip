@@ -31,7 +31,7 @@ namespace {
 // CircuitConfig::standard_recursion_config() (mmr_plonky2_verifier.rs:30)
 constexpr u32 kNumWires = 135, kNumRouted = 80, kNumConsts = 2, kNumCh = 2, kQF = 8, kRateBits = 3, kCapHeight = 4;
 constexpr u32 kNumChunks = (kNumRouted + kQF - 1) / kQF, kNumProds = kNumChunks - 1, kNumOps = kNumRouted / 4;
-constexpr u32 kNumZs = kNumCh * (1 + kNumProds), kNumQuot = kNumCh * kQF;
+constexpr u32 kNumZs = kNumCh * (1 + kNumProds), kNumQuot = kNumCh * kQF, kNumGateConstraints = 123;
 enum { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_POSEIDON, G_KINDS };
 // plonky2 sorts the gate types by (degree, id): Noop(0) < Constant(1) < PublicInput(1) < Arithmetic(3) < Poseidon(7), which
 // is the enum order
@@ -434,137 +434,201 @@ struct QDesc {
   u64 n_inv, w_big;
 };
 
-// compute_quotient_polys + eval_vanishing_poly_base: one lane per point x_i = 7 w^i of the LDE coset.  The committed batches
-// are read poly-major in leaf order ([poly][brev(i)]: coalesced over lanes); the quotient values go out in natural order for
-// the coset IFFT.  terms: L_0(x)(Z_c - 1) | partial-product checks | gate constraints (filtered), reduced with powers of
-// alpha_c (running power, so nothing is stored per term).
-__global__ __launch_bounds__(64) void k_quotient(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
-                                                 const u64* __restrict__ zl, const u64* __restrict__ pi_hash,
-                                                 const u64* __restrict__ chal, const u64* __restrict__ k_is,
-                                                 const u64* __restrict__ rc, u64* __restrict__ qvals) {
+// compute_quotient_polys + eval_vanishing_poly_base on the LDE coset x_i = 7 w^i.  A workgroup owns 64 points; its four
+// wavefronts split every point's work by ROLE (wave-uniform branches, so nothing diverges) and meet in LDS:
+//   role 0  PoseidonGate: the transition out of the first half + the 22-round partial chain (the one sequential piece)
+//   role 1  PoseidonGate: input layer, full rounds 0-2 of the first half, first full round of the second half; 2 pp chunks
+//   role 2  PoseidonGate: last three full rounds; Arithmetic / Constant / PublicInput gates; L_0(x)(Z - 1); 4 pp chunks
+//   role 3  14 of the 20 partial-product checks
+// (every full round is independent of the others because its S-box inputs are wires; only the partial rounds chain).
+// terms: L_0 (Z_c - 1) | partial-product checks | gate constraints (filtered), reduced with powers of alpha_c from a table
+// built once per workgroup in LDS.  The committed batches are read poly-major in leaf order ([poly][brev(i)]: coalesced
+// over lanes); the quotient values go out in natural order for the coset IFFT.
+constexpr u32 kNumTerms = kNumCh + kNumCh * kNumChunks + kNumGateConstraints;
+__global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
+                                                  const u64* __restrict__ zl, const u64* __restrict__ pi_hash,
+                                                  const u64* __restrict__ chal, const u64* __restrict__ k_is,
+                                                  const u64* __restrict__ rc, u64* __restrict__ qvals) {
+  __shared__ u64 apow[kNumCh][kNumTerms];
+  __shared__ u64 part[4][64][kNumCh];
   const u32 log_big = d.log_n + 3, big = 1u << log_big;
-  const u32 r = blockIdx.x * 64 + threadIdx.x;
-  if (r >= big) return;
+  const u32 role = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32 r_raw = blockIdx.x * 64 + lane;
+  const bool valid = r_raw < big;
+  const u32 r = valid ? r_raw : big - 1;
+  for (u32 k = threadIdx.x; k < kNumCh * kNumTerms; k += 256) {
+    const u32 c = k / kNumTerms, e = k % kNumTerms;
+    apow[c][e] = gl::canon(gl::pow(chal[2 * kNumCh + c], e));
+  }
+  __syncthreads();
   const u32 i = __brev(r) >> (32 - log_big);
   const u32 r_next = __brev((i + kQF) & (big - 1)) >> (32 - log_big);
-  const u64 x = gl::mul(7, gl::pow(d.w_big, i));
   auto CS = [&](u32 j) { return cs[(size_t)j * big + r]; };
   auto W = [&](u32 j) { return wl[(size_t)j * big + r]; };
   auto Z = [&](u32 j) { return zl[(size_t)j * big + r]; };
   auto ZN = [&](u32 j) { return zl[(size_t)j * big + r_next]; };
-  u64 alpha[kNumCh], acc[kNumCh], ap[kNumCh];
+  u64 acc[kNumCh], gacc[kNumCh];
 #pragma unroll
-  for (u32 c = 0; c < kNumCh; ++c) {
-    alpha[c] = chal[2 * kNumCh + c];
-    acc[c] = 0;
-    ap[c] = 1;
-  }
-  auto term = [&](u64 t) {
+  for (u32 c = 0; c < kNumCh; ++c) acc[c] = gacc[c] = 0;
+  auto T = [&](u32 k, u64 t) {  // term k of the vanishing polynomial
 #pragma unroll
-    for (u32 c = 0; c < kNumCh; ++c) {
-      acc[c] = gl::mul_add(ap[c], t, acc[c]);
-      ap[c] = gl::mul(ap[c], alpha[c]);
-    }
+    for (u32 c = 0; c < kNumCh; ++c) acc[c] = gl::mul_add(apow[c][k], t, acc[c]);
   };
-  {  // L_0(x) (Z_c(x) - 1), L_0(x) = (x^n - 1) / (n (x - 1))
-    const u64 l0 = gl::mul(gl::mul(d.zh[i & (kQF - 1)], d.n_inv), gl_inv(gl::canon(gl::sub_c(x, 1))));
-    for (u32 c = 0; c < kNumCh; ++c) term(gl::mul(l0, gl::sub_c(Z(c), 1)));
-  }
-  const u32 sig0 = d.num_selectors + kNumConsts;
-  for (u32 c = 0; c < kNumCh; ++c) {  // check_partial_products
-    const u64 beta = chal[c], gamma = chal[kNumCh + c], bx = gl::mul(beta, x);
-#pragma unroll 1
-    for (u32 q = 0; q < kNumChunks; ++q) {
-      u64 num = 1, den = 1;
-#pragma unroll 1
-      for (u32 j = q * kQF; j < (q + 1) * kQF && j < kNumRouted; ++j) {
-        const u64 wg = gl::add(W(j), gamma);
-        num = gl::mul(num, gl::mul_add(bx, k_is[j], wg));
-        den = gl::mul(den, gl::mul_add(beta, CS(sig0 + j), wg));
-      }
-      const u64 prev = q == 0 ? Z(c) : Z(kNumCh + c * kNumProds + q - 1);
-      const u64 next = q == kNumProds ? ZN(c) : Z(kNumCh + c * kNumProds + q);
-      term(fsub(gl::mul(prev, num), gl::mul(next, den)));
-    }
-  }
-  // gate constraints: sum_g filter_g(selector) * sum_j alpha^j c_{g,j}, shifted by the alpha power reached so far
-  u64 head[kNumCh], ap0[kNumCh], tot[kNumCh];
+  auto G = [&](u32 j, u64 t) {  // constraint j of the gate being evaluated (filtered when the gate is closed)
 #pragma unroll
-  for (u32 c = 0; c < kNumCh; ++c) {
-    head[c] = acc[c];
-    ap0[c] = ap[c];
-    tot[c] = 0;
-  }
-  for (u32 g = 0; g < d.n_kinds; ++g) {
-#pragma unroll
-    for (u32 c = 0; c < kNumCh; ++c) {
-      acc[c] = 0;
-      ap[c] = 1;
-    }
-    const u32 kind = d.kind[g];
-    if (kind == G_NOOP) continue;
-    if (kind == G_CONSTANT) {
-      for (u32 j = 0; j < kNumConsts; ++j) term(gl::sub_c(CS(d.num_selectors + j), W(j)));
-    } else if (kind == G_PUBLIC_INPUT) {
-      for (u32 j = 0; j < 4; ++j) term(gl::sub_c(W(j), pi_hash[j]));
-    } else if (kind == G_ARITHMETIC) {
-      const u64 c0 = CS(d.num_selectors), c1 = CS(d.num_selectors + 1);
-#pragma unroll 1
-      for (u32 o = 0; o < kNumOps; ++o) {
-        const u64 prod = gl::mul(gl::mul(W(4 * o), W(4 * o + 1)), c0);
-        term(fsub(W(4 * o + 3), gl::mul_add(W(4 * o + 2), c1, prod)));
-      }
-    } else {  // PoseidonGate
-      const u64 swap = W(24);
-      term(gl::mul(swap, gl::sub_c(swap, 1)));
-      u64 s[12];
-#pragma unroll
-      for (u32 k = 0; k < 4; ++k) {
-        const u64 lhs = W(k), rhs = W(k + 4), delta = W(25 + k);
-        term(fsub(gl::mul(swap, gl::sub_c(rhs, lhs)), delta));
-        s[k] = gl::add(lhs, delta);
-        s[k + 4] = gl::sub_c(rhs, delta);
-      }
-#pragma unroll
-      for (u32 k = 8; k < 12; ++k) s[k] = W(k);
-#pragma unroll 1
-      for (u32 rd = 0; rd < POSEIDON_ROUNDS; ++rd) {
-#pragma unroll
-        for (u32 k = 0; k < 12; ++k) s[k] = gl::add_c(s[k], rc[12 * rd + k]);
-        if (rd >= 4 && rd < 26) {
-          const u64 in = W(65 + rd - 4);
-          term(fsub(s[0], in));
-          s[0] = gl::pow7(in);
-        } else {
-          if (rd != 0) {
-            const u32 base = rd < 4 ? 29 + 12 * (rd - 1) : 87 + 12 * (rd - 26);
-#pragma unroll
-            for (u32 k = 0; k < 12; ++k) {
-              const u64 in = W(base + k);
-              term(fsub(s[k], in));
-              s[k] = in;
-            }
-          }
-#pragma unroll
-          for (u32 k = 0; k < 12; ++k) s[k] = gl::pow7(s[k]);
-        }
-        poseidon::mds_layer<poseidon::MDS_MAD64>(s);
-      }
-#pragma unroll
-      for (u32 k = 0; k < 12; ++k) term(fsub(s[k], W(12 + k)));
-    }
-    // compute_filter
+    for (u32 c = 0; c < kNumCh; ++c) gacc[c] = gl::mul_add(apow[c][kNumCh + kNumCh * kNumChunks + j], t, gacc[c]);
+  };
+  auto close_gate = [&](u32 g) {  // compute_filter, then acc += filter * gate sum
     const u64 sv = CS(d.sel[g]);
     u64 f = 1;
     for (u32 k = d.gs[g]; k < d.ge[g]; ++k)
       if (k != g) f = gl::mul(f, fsub((u64)k, sv));
     if (d.num_selectors > 1) f = gl::mul(f, fsub(kUnusedSelector, sv));
 #pragma unroll
-    for (u32 c = 0; c < kNumCh; ++c) tot[c] = gl::mul_add(f, acc[c], tot[c]);
-  }
-  const u64 zh_inv = d.zh_inv[i & (kQF - 1)];
+    for (u32 c = 0; c < kNumCh; ++c) {
+      acc[c] = gl::mul_add(f, gacc[c], acc[c]);
+      gacc[c] = 0;
+    }
+  };
+  int g_of[G_KINDS];  // position of each gate type in the circuit's sorted list, -1 if absent
 #pragma unroll
-  for (u32 c = 0; c < kNumCh; ++c) qvals[(size_t)c * big + i] = gl::canon(gl::mul(gl::mul_add(tot[c], ap0[c], head[c]), zh_inv));
+  for (u32 k = 0; k < G_KINDS; ++k) g_of[k] = -1;
+  for (u32 g = 0; g < d.n_kinds; ++g) g_of[d.kind[g]] = (int)g;
+  const u32 sig0 = d.num_selectors + kNumConsts;
+  // partial-product check `idx` = challenge * 10 + chunk (term kNumCh + idx)
+  auto pp_check = [&](u32 idx) {
+    const u32 c = idx / kNumChunks, q = idx % kNumChunks;
+    const u64 x = gl::mul(7, gl::pow(d.w_big, i));
+    const u64 beta = chal[c], gamma = chal[kNumCh + c], bx = gl::mul(beta, x);
+    u64 num = 1, den = 1;
+#pragma unroll 1
+    for (u32 j = q * kQF; j < (q + 1) * kQF && j < kNumRouted; ++j) {
+      const u64 wg = gl::add(W(j), gamma);
+      num = gl::mul(num, gl::mul_add(bx, k_is[j], wg));
+      den = gl::mul(den, gl::mul_add(beta, CS(sig0 + j), wg));
+    }
+    const u64 prev = q == 0 ? Z(c) : Z(kNumCh + c * kNumProds + q - 1);
+    const u64 next = q == kNumProds ? ZN(c) : Z(kNumCh + c * kNumProds + q);
+    T(kNumCh + idx, fsub(gl::mul(prev, num), gl::mul(next, den)));
+  };
+  // one full round of the PoseidonGate from its S-box inputs: S-box, MDS, next round's constants (none after the last
+  // round), constraints j0.. against the wires starting at cmp
+  auto full_step = [&](u64 (&s)[12], const u64* rc_next, u32 cmp, u32 j0) {
+#pragma unroll
+    for (u32 k = 0; k < 12; ++k) s[k] = gl::pow7(s[k]);
+    poseidon::mds_layer<poseidon::MDS_MAD64>(s);
+    if (rc_next) {
+#pragma unroll
+      for (u32 k = 0; k < 12; ++k) s[k] = gl::add_c(s[k], rc_next[k]);
+    }
+#pragma unroll
+    for (u32 k = 0; k < 12; ++k) G(j0 + k, fsub(s[k], W(cmp + k)));
+  };
+  auto load_row = [&](u64 (&s)[12], u32 base) {
+#pragma unroll
+    for (u32 k = 0; k < 12; ++k) s[k] = W(base + k);
+  };
+  const int gp = g_of[G_POSEIDON];
+  if (role == 0) {
+    if (gp >= 0) {
+      u64 s[12];
+      load_row(s, 53);  // S-box inputs of full round 3
+#pragma unroll
+      for (u32 k = 0; k < 12; ++k) s[k] = gl::pow7(s[k]);
+      poseidon::mds_layer<poseidon::MDS_MAD64>(s);
+#pragma unroll
+      for (u32 k = 0; k < 12; ++k) s[k] = gl::add_c(s[k], rc[48 + k]);
+#pragma unroll 1
+      for (u32 pr = 0; pr < POSEIDON_PARTIAL_ROUNDS; ++pr) {
+        const u64 in = W(65 + pr);
+        G(41 + pr, fsub(s[0], in));
+        s[0] = gl::pow7(in);
+        poseidon::mds_layer<poseidon::MDS_MAD64>(s);
+        const u64* rcn = rc + 12 * (5 + pr);
+#pragma unroll
+        for (u32 k = 0; k < 12; ++k) s[k] = gl::add_c(s[k], rcn[k]);
+      }
+#pragma unroll
+      for (u32 k = 0; k < 12; ++k) G(63 + k, fsub(s[k], W(87 + k)));
+      close_gate((u32)gp);
+    }
+  } else if (role == 1) {
+    if (gp >= 0) {
+      const u64 swap = W(24);
+      G(0, gl::mul(swap, gl::sub_c(swap, 1)));
+      u64 s[12];
+#pragma unroll
+      for (u32 k = 0; k < 4; ++k) {
+        const u64 lhs = W(k), rhs = W(k + 4), delta = W(25 + k);
+        G(1 + k, fsub(gl::mul(swap, gl::sub_c(rhs, lhs)), delta));
+        s[k] = gl::add(lhs, delta);
+        s[k + 4] = gl::sub_c(rhs, delta);
+      }
+#pragma unroll
+      for (u32 k = 8; k < 12; ++k) s[k] = W(k);
+#pragma unroll
+      for (u32 k = 0; k < 12; ++k) s[k] = gl::add_c(s[k], rc[k]);
+      full_step(s, rc + 12, 29, 5);
+      load_row(s, 29);
+      full_step(s, rc + 24, 41, 17);
+      load_row(s, 41);
+      full_step(s, rc + 36, 53, 29);
+      load_row(s, 87);
+      full_step(s, rc + 12 * 27, 99, 75);
+      close_gate((u32)gp);
+    }
+    pp_check(18);
+    pp_check(19);
+  } else if (role == 2) {
+    if (gp >= 0) {
+      u64 s[12];
+      load_row(s, 99);
+      full_step(s, rc + 12 * 28, 111, 87);
+      load_row(s, 111);
+      full_step(s, rc + 12 * 29, 123, 99);
+      load_row(s, 123);
+      full_step(s, nullptr, 12, 111);
+      close_gate((u32)gp);
+    }
+    if (g_of[G_ARITHMETIC] >= 0) {
+      const u64 c0 = CS(d.num_selectors), c1 = CS(d.num_selectors + 1);
+#pragma unroll 1
+      for (u32 o = 0; o < kNumOps; ++o) {
+        const u64 prod = gl::mul(gl::mul(W(4 * o), W(4 * o + 1)), c0);
+        G(o, fsub(W(4 * o + 3), gl::mul_add(W(4 * o + 2), c1, prod)));
+      }
+      close_gate((u32)g_of[G_ARITHMETIC]);
+    }
+    if (g_of[G_CONSTANT] >= 0) {
+      for (u32 j = 0; j < kNumConsts; ++j) G(j, gl::sub_c(CS(d.num_selectors + j), W(j)));
+      close_gate((u32)g_of[G_CONSTANT]);
+    }
+    if (g_of[G_PUBLIC_INPUT] >= 0) {
+      for (u32 j = 0; j < 4; ++j) G(j, gl::sub_c(W(j), pi_hash[j]));
+      close_gate((u32)g_of[G_PUBLIC_INPUT]);
+    }
+    {  // L_0(x) (Z_c(x) - 1), L_0(x) = (x^n - 1) / (n (x - 1))
+      const u64 x = gl::mul(7, gl::pow(d.w_big, i));
+      const u64 l0 = gl::mul(gl::mul(d.zh[i & (kQF - 1)], d.n_inv), gl_inv(gl::canon(gl::sub_c(x, 1))));
+      for (u32 c = 0; c < kNumCh; ++c) T(c, gl::mul(l0, gl::sub_c(Z(c), 1)));
+    }
+#pragma unroll 1
+    for (u32 idx = 14; idx < 18; ++idx) pp_check(idx);
+  } else {
+#pragma unroll 1
+    for (u32 idx = 0; idx < 14; ++idx) pp_check(idx);
+  }
+#pragma unroll
+  for (u32 c = 0; c < kNumCh; ++c) part[role][lane][c] = acc[c];
+  __syncthreads();
+  if (role == 0 && valid) {
+    const u64 zh_inv = d.zh_inv[i & (kQF - 1)];
+#pragma unroll
+    for (u32 c = 0; c < kNumCh; ++c) {
+      const u64 sum = gl::add(gl::add(part[0][lane][c], part[1][lane][c]), gl::add(part[2][lane][c], part[3][lane][c]));
+      qvals[(size_t)c * big + i] = gl::canon(gl::mul(sum, zh_inv));
+    }
+  }
 }
 
 // OpeningSet order (constants | sigmas | wires | zs | zs_next | partial products | quotient) from the FriOpenings order the
@@ -1264,7 +1328,7 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
     qd.n_inv = h_pow(n, gl::P - 2);
     qd.w_big = h_root_of_unity(log_big);
   }
-  hipLaunchKernelGGL(k_quotient, dim3((big + 63) / 64), dim3(64), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
+  hipLaunchKernelGGL(k_quotient, dim3((big + 63) / 64), dim3(256), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
                      (const u64*)c->d_z_lde, (const u64*)d_pi_hash, (const u64*)c->d_chal, (const u64*)c->d_kis,
                      (const u64*)rt().d_rc, c->d_q_vals);
   P2MT_LAUNCH_CHECK();
