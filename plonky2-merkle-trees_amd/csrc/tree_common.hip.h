@@ -110,14 +110,16 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 // state word i, the twelve S-boxes of a full round run in parallel, and the MDS row of lane r is two mad chains
 // over the words broadcast with v_readlane (SGPR operands) against that lane's row of constants.  All 30 rounds
 // are unrolled with the lane's round constants preloaded, so a node takes ~3.5k instructions instead of ~28k.
-// Used for levels of <= 2^12 nodes; bit-identical to the lane-per-hash kernels.  Exact arithmetic (no sticky flag):
-// a flagged wave redoing its node serially would set the duration of the whole (latency-bound) launch.
+// Used for levels of <= 2^12 nodes; bit-identical to the lane-per-hash kernels.  The flag-form primitives are tried first
+// (~10 % fewer instructions per round); a wave whose sticky flag is set (probability ~4e-4 per permutation) redoes THIS
+// permutation with the exact form on the same 12 lanes -- one more 11 us, not the 60 us serial redo of the lane-per-hash
+// layout that once set the duration of whole latency-bound launches.
 // One permutation by the calling wave (all 64 lanes must call it): lane w < 12 passes state word w (any u64) and
 // receives word w of the permuted state (loose u64, exact); lanes >= 12 shadow lane 0 and their result is unused.
 // `hook(r, x)` sees this lane's state word at the start of round r, after the round constant and before the S-box --
 // the value plonky2's PoseidonGate keeps as a witness wire (p2mt_circuit.hip records it; the hashing kernels pass nothing).
-template <typename Hook>
-GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
+template <bool EXACT, typename Hook>
+GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky) {
   const unsigned lane = threadIdx.x & 63;
   const unsigned w = lane < 12 ? lane : 0;
   u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
@@ -131,7 +133,9 @@ GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
   // next round's constant folded into the two mad chains
   auto round = [&](int r, bool full, bool add, u64 c_fold) {
     hook(r, x);
-    const u64 y = poseidon_fast::exact::pow7(x);
+    u64 y;
+    if constexpr (EXACT) y = poseidon_fast::exact::pow7(x);
+    else y = poseidon_fast::pow7(x, sticky);
     if (full || lane == 0) x = y;
     const u32 xl = (u32)x, xh = (u32)(x >> 32);
     u64 al = add ? (u64)(u32)c_fold : 0, ah = add ? (u64)(u32)(c_fold >> 32) : 0;
@@ -143,7 +147,13 @@ GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
     }
     ah = poseidon_fast::add32((u32)(al >> 32), ah);
     const u64 val = ((u64)(u32)ah << 32) | (u32)al;
-    x = poseidon_fast::exact::fold96((u32)(ah >> 32), val);
+    if constexpr (EXACT) {
+      x = poseidon_fast::exact::fold96((u32)(ah >> 32), val);
+    } else {
+      u64 cm;
+      x = poseidon_fast::mad_eps_carry((u32)(ah >> 32), val, cm);  // top * EPS + val; wraps with probability ~2^-22
+      sticky |= cm;
+    }
   };
 #pragma unroll 1
   for (int r = 0; r < POSEIDON_ROUNDS - 1; ++r) {
@@ -154,6 +164,13 @@ GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
   }
   round(POSEIDON_ROUNDS - 1, true, false, 0);
   return x;
+}
+template <typename Hook>
+GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
+  u64 sticky = ctx.force_fallback;  // lane masks OR-ed on the scalar pipe: wave-uniform
+  const u64 y = permute_wave_impl<false>(x, ctx, hook, sticky);
+  if (__builtin_expect(sticky != 0, 0)) return permute_wave_impl<true>(x, ctx, hook, sticky);
+  return y;
 }
 GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
   return permute_wave_hook(x, ctx, [](int, u64) {});

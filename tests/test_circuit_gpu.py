@@ -318,3 +318,18 @@ def test_verify_config3_and_d12(pkg, oracle):
             bad = proof.copy()
             bad[pos] ^= np.uint64(1 << 7)
             assert gcd.verify(bad, with_reason=True)[0] is False
+
+
+def test_prove_with_exact_redo_forced(pkg, oracle):
+    """permute_wave tries the flag-form arithmetic and redoes a flagged permutation exactly; force the redo on every
+    permutation (transcript, witness rows, leaf sponges, Merkle levels, verifier paths): same proof, still accepted."""
+    case = mmr_case(oracle, 11, 6)
+    gcd, pw, ocd, opw = build_both(pkg, oracle, case)
+    want = gcd.prove(pw)
+    pkg._native.check(pkg.lib().p2mt_debug_force_fallback(1))
+    try:
+        got = gcd.prove(pw)
+        ok = gcd.verify(got, with_reason=True)
+    finally:
+        pkg._native.check(pkg.lib().p2mt_debug_force_fallback(0))
+    assert np.array_equal(got, want) and ok == (True, 0)
