@@ -379,6 +379,8 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
 __global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
                                                         u64* vals, u32* set, const u32* __restrict__ wire_slot, int* err,
                                                         PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   run_levels(GMem{vals, set}, ops, lvl, n_levels, wire_slot, err, ctx);
 }
 
@@ -389,6 +391,8 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
                                                         const u32* __restrict__ wire_slot, u32 log_n, u64* __restrict__ wires,
                                                         const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
                                                         int* err, PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   extern __shared__ __attribute__((aligned(16))) u64 sh[];
   const LMem m{sh, reinterpret_cast<uint8_t*>(sh + n_slots)};
   for (u32 k = threadIdx.x; k < n_slots; k += kBlock) m.set[k] = 0;
@@ -663,6 +667,8 @@ struct VItem {
 };
 __global__ __launch_bounds__(kBlock) void k_verify_merkle(const u64* __restrict__ words, const VItem* __restrict__ items, u32 n_items,
                                                           int* bad, PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   const u32 item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const u32 lane = threadIdx.x & 63;
@@ -1152,7 +1158,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   {  // value table in LDS when it fits (160 KB per CU on gfx950; env P2MT_WITNESS_LDS=0 forces the global-memory path)
     const size_t need = (size_t)c->n_slots * 9 + 16;
     const char* e = getenv("P2MT_WITNESS_LDS");
-    if (need <= 160 * 1024 - 1024 && !(e && e[0] == '0')) {
+    if (need <= 160 * 1024 - 4096 && !(e && e[0] == '0')) {  // minus the static round-constant table
       c->lds_bytes = (need + 15) & ~(size_t)15;
       if (c->lds_bytes > 64 * 1024)
         P2MT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_witness_lds), hipFuncAttributeMaxDynamicSharedMemorySize,

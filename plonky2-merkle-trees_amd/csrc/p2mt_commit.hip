@@ -338,6 +338,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restr
 // on a quad), so a 135-wide leaf costs 17 x 11 us.
 __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restrict__ in, size_t w, size_t n_pts,
                                                               u64* __restrict__ digests, p2mt::PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
   const size_t col = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (col >= n_pts) return;  // wave-uniform
   const unsigned lane = threadIdx.x & 63;

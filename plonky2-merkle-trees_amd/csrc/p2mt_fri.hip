@@ -69,6 +69,8 @@ static_assert(sizeof(ChState) == 8 * (12 + 8 + 8) + 8, "layout shared with p2mt_
 __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, const u64* __restrict__ obs, u32 n_obs,
                                                    u64* __restrict__ sq, u32 n_sq, PermCtx ctx) {
   __shared__ u64 s_in[8], s_out[8];
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   const unsigned lane = threadIdx.x;
   u64 x = lane < 12 ? st->state[lane] : 0;
   u32 n_in = st->n_in, n_out = st->n_out;  // wave-uniform
@@ -87,13 +89,41 @@ __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, con
     __syncthreads();
     n_out = 8;
   };
+  u32 i = 0;
 #pragma unroll 1
-  for (u32 i = 0; i < n_obs; ++i) {
+  for (; i < n_obs && n_in != 0; ++i) {  // top up a partly filled input buffer element by element
     n_out = 0;  // observe_element: buffered outputs are stale
     if (lane == 0) s_in[n_in] = gl::canon(obs[i]);
     n_in += 1;
     __syncthreads();
     if (n_in == 8) duplex();
+  }
+  if (i < n_obs) {
+    // whole 8-element chunks straight from memory into the state (lane k < 8 = word k), the next chunk prefetched under
+    // the permutation: one coalesced load per duplexing instead of eight dependent ones
+    u64 nxt = (lane < 8 && i + lane < n_obs) ? obs[i + lane] : 0;
+    bool any = false;
+#pragma unroll 1
+    while (i + 8 <= n_obs) {
+      const u64 cur = nxt;
+      if (lane < 8 && i + 8 + lane < n_obs) nxt = obs[i + 8 + lane];
+      if (lane < 8) x = gl::canon(cur);
+      x = permute_wave(x, ctx);
+      i += 8;
+      any = true;
+    }
+    __syncthreads();
+    if (any) {
+      if (lane < 8) s_out[lane] = gl::canon(x);
+      n_out = 8;
+    }
+    const u32 rem = n_obs - i;  // < 8 trailing elements stay buffered
+    if (rem) {
+      if (lane < rem) s_in[lane] = gl::canon(nxt);
+      n_in = rem;
+      n_out = 0;
+    }
+    __syncthreads();
   }
 #pragma unroll 1
   for (u32 k = 0; k < n_sq; ++k) {

@@ -65,6 +65,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in
 // len/8 single-lane ones (~60 us each).
 __global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
                                                            u64* __restrict__ out, PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   const size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= n) return;  // wave-uniform
   const unsigned lane = threadIdx.x & 63;
@@ -189,6 +191,8 @@ __global__ __launch_bounds__(kBlock) void k_verify_merkle_proof(const u64* __res
 // level-major tree level: out[j] = two_to_one(in[2j], in[2j+1])
 __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
                                                               PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   const size_t j = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (j >= n_out) return;  // wave-uniform
   two_to_one_wave(in + 8 * j, in + 8 * j + 4, out + 4 * j, ctx);

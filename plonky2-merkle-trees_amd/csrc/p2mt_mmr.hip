@@ -159,6 +159,8 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
 // MMR level (post-order, in place): node j of height h
 __global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
                                                            PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
   const size_t j = j0 + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (j >= j1) return;  // wave-uniform
   const size_t pos = node_pos(((j + 1) << h) - 1, h);

@@ -118,13 +118,27 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 // receives word w of the permuted state (loose u64, exact); lanes >= 12 shadow lane 0 and their result is unused.
 // `hook(r, x)` sees this lane's state word at the start of round r, after the round constant and before the S-box --
 // the value plonky2's PoseidonGate keeps as a witness wire (p2mt_circuit.hip records it; the hashing kernels pass nothing).
+// Copy the 360 round constants into LDS (all threads of the workgroup must call it) and return a context that reads them
+// from there: a wave-permutation fetches one constant per round and lane, and an LDS round trip hides under one round
+// where an L2 one does not (measured: ~2 us of exposed load latency per 10.5 us permutation).
+GL_DEV PermCtx stage_round_constants(u64* lds /*[360]*/, const PermCtx& ctx) {
+  for (unsigned k = threadIdx.x; k < 360; k += blockDim.x) lds[k] = ctx.rc[k];
+  __syncthreads();
+  return PermCtx{lds, ctx.force_fallback};
+}
+
 template <bool EXACT, typename Hook>
 GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky) {
   const unsigned lane = threadIdx.x & 63;
   const unsigned w = lane < 12 ? lane : 0;
-  u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0])
+  u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0]), picked out of two packed
+               // immediates (bytes 17,15,41,16,2,28,13,13 | 39,18,34,20) instead of a per-lane table load
 #pragma unroll
-  for (int c = 0; c < 12; ++c) kk[c] = (u32)POSEIDON_MDS_CIRC[(c + 12 - w) % 12] + ((w == 0 && c == 0) ? 8u : 0u);
+  for (int c = 0; c < 12; ++c) {
+    const unsigned idx = (unsigned)c >= w ? (unsigned)c - w : (unsigned)c + 12 - w;
+    const u64 word = idx < 8 ? 0x0D0D1C0210290F11ull : 0x14221227ull;
+    kk[c] = (u32)((word >> (8 * (idx & 7))) & 0xFF) + ((w == 0 && c == 0) ? 8u : 0u);
+  }
 
   const u64* rcw = ctx.rc + w;     // this lane's column of the round-constant table
   u64 c_next = rcw[12];            // constant of round r+1, fetched one round ahead (hidden under the S-box)
