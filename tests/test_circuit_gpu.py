@@ -333,3 +333,83 @@ def test_prove_with_exact_redo_forced(pkg, oracle):
     finally:
         pkg._native.check(pkg.lib().p2mt_debug_force_fallback(0))
     assert np.array_equal(got, want) and ok == (True, 0)
+
+
+def _random_program(rng, n_ops):
+    """A random straight-line circuit over the builder surface the reference uses (and a bit more): a list of
+    (op, operand indices / immediates); operands index the list of targets created so far."""
+    prog = [("input", int(rng.integers(0, P, dtype=np.uint64))) for _ in range(4)]
+    prog += [("bool_input", int(rng.integers(0, 2))) for _ in range(3)]
+    kinds = ["add", "sub", "mul", "mul_add", "mul_sub", "not", "or", "is_equal", "is_equal_same", "const", "arith", "hash",
+             "hash_or_noop", "input"]
+    n_bool = lambda: None
+    for _ in range(n_ops):
+        k = kinds[int(rng.integers(0, len(kinds)))]
+        n = len(prog)
+        pick = lambda: int(rng.integers(0, n))
+        if k in ("add", "sub", "mul", "is_equal"):
+            prog.append((k, pick(), pick()))
+        elif k == "is_equal_same":
+            a = pick()
+            prog.append(("is_equal", a, a))
+        elif k in ("mul_add", "mul_sub"):
+            prog.append((k, pick(), pick(), pick()))
+        elif k in ("not", "or"):
+            bools = [i for i, op in enumerate(prog) if op[0] in ("bool_input", "not", "or", "is_equal")]
+            prog.append((k, bools[int(rng.integers(0, len(bools)))], bools[int(rng.integers(0, len(bools)))]))
+        elif k == "const":
+            prog.append((k, int(rng.integers(0, 4)) if rng.integers(0, 2) else int(rng.integers(0, P, dtype=np.uint64))))
+        elif k == "arith":
+            prog.append((k, int(rng.integers(0, 3)), int(rng.integers(0, P, dtype=np.uint64)), pick(), pick(), pick()))
+        elif k in ("hash", "hash_or_noop"):
+            prog.append((k, [pick() for _ in range(int(rng.integers(1, 20)))], int(rng.integers(0, 4))))
+        else:
+            prog.append(("input", int(rng.integers(0, P, dtype=np.uint64))))
+    outs = [int(i) for i in rng.integers(0, len(prog), size=int(rng.integers(0, 7)))]
+    return prog, outs
+
+
+def _run_program(b, prog, outs, set_target):
+    """Build `prog` through builder `b` (product mirror or oracle: same method names); returns the circuit data."""
+    t = []
+    for op in prog:
+        k = op[0]
+        if k == "input":
+            x = b.add_virtual_target()
+            set_target(x, op[1])
+        elif k == "bool_input":
+            x = b.add_virtual_bool_target_safe()
+            set_target(x, op[1])
+        elif k in ("add", "sub", "mul", "is_equal"):
+            x = getattr(b, k)(t[op[1]], t[op[2]])
+        elif k in ("mul_add", "mul_sub"):
+            x = getattr(b, k)(t[op[1]], t[op[2]], t[op[3]])
+        elif k == "not":
+            x = b.not_(t[op[1]])
+        elif k == "or":
+            x = b.or_(t[op[1]], t[op[2]])
+        elif k == "const":
+            x = b.constant(op[1])
+        elif k == "arith":
+            x = b.arithmetic(op[1], op[2], t[op[3]], t[op[4]], t[op[5]])
+        else:
+            h = (b.hash_n_to_hash_no_pad if k == "hash" else b.hash_or_noop)([t[i] for i in op[1]])
+            x = h[op[2]]
+        t.append(x)
+    if outs:
+        b.register_public_inputs([t[i] for i in outs])
+    return b.build()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_circuits_match_the_oracle(pkg, oracle, seed):
+    """Fuzz the builder (constant folding, operation cache, slot packing, copy classes, selectors) and the prover on random
+    straight-line circuits: constants_sigmas / digest / witness / proof words equal the oracle's, both verifiers accept."""
+    rng = np.random.default_rng(1000 + seed)
+    prog, outs = _random_program(rng, int(rng.integers(5, 120)))
+    pw, opw = pkg.PartialWitness(), {}
+    gcd = _run_program(pkg.CircuitBuilder(), prog, outs, pw.set_target)
+    ocd = _run_program(OC.CircuitBuilder(oracle), prog, outs, opw.__setitem__)
+    check_build(gcd, ocd)
+    proof = check_prove(gcd, pw, ocd, opw)
+    assert gcd.verify(proof, with_reason=True) == (True, 0)
