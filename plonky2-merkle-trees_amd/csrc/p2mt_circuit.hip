@@ -37,6 +37,7 @@ enum { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_POSEIDON, G_KINDS
 // is the enum order
 constexpr u32 kGateDegree[G_KINDS] = {0, 1, 1, 3, 7};
 constexpr u64 kWireFlag = 1ull << 63, kUnusedSelector = 0xFFFFFFFFull;
+constexpr u32 kNoSlot = 0xFFFFFFFFu;  // a wire nothing reads: no entry in the value table
 
 inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
 inline u64 h_add(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % gl::P); }
@@ -331,20 +332,24 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
 
 // One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
 // and puts the PoseidonGate rows first).  PoseidonGenerator: one wavefront per row, lane w < 12 owns state word w.
+// The PoseidonGate's non-routed wires (delta and S-box inputs: 110 of the row's 135) are never read by a generator nor
+// copy-constrained, so they have no value slot: they go straight into the wire matrix.
 template <typename Mem>
 GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                       const u32* __restrict__ wire_slot, int* err, const PermCtx& ctx) {
+                       const u32* __restrict__ wire_slot, u64* __restrict__ wires, u32 log_n, int* err, const PermCtx& ctx) {
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kBlock / 64;
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
     for (u32 o = s + wave; o < s + np; o += n_waves) {  // wave-uniform
-      const u32* ws = wire_slot + (size_t)ops[o].a * kNumWires;
+      const u32 row = ops[o].a;
+      const u32* ws = wire_slot + (size_t)row * kNumWires;
+      u64* wrow = wires + row;  // wire (row, col) = wrow[col << log_n]
       u64 x = lane < 12 ? m.get(ws[lane]) : 0;
       const u64 swap = m.get(ws[24]);
       const u64 partner = __shfl_xor((unsigned long long)x, 4);
       if (lane < 4) {  // delta_i = swap * (in[i+4] - in[i]); the permutation runs on the swapped state
         const u64 d = gl::canon(gl::mul(swap, fsub(partner, x)));
-        m.store(ws[25 + lane], d);
+        wrow[(size_t)(25 + lane) << log_n] = d;
         x = gl::add(x, d);
       } else if (lane < 8) {
         x = fsub(x, gl::mul(swap, fsub(x, partner)));
@@ -357,7 +362,7 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
           if (lane != 0) return;
           col = 65 + (r - 4);
         } else col = 87 + 12 * (r - 26) + lane;
-        m.store(ws[col], gl::canon(xv));
+        wrow[(size_t)col << log_n] = gl::canon(xv);
       });
       if (lane < 12) put(m, ws[12 + lane], x, err, o);
     }
@@ -377,11 +382,11 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
 }
 
 __global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                                                        u64* vals, u32* set, const u32* __restrict__ wire_slot, int* err,
-                                                        PermCtx ctx) {
+                                                        u64* vals, u32* set, const u32* __restrict__ wire_slot,
+                                                        u64* __restrict__ wires, u32 log_n, int* err, PermCtx ctx) {
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
-  run_levels(GMem{vals, set}, ops, lvl, n_levels, wire_slot, err, ctx);
+  run_levels(GMem{vals, set}, ops, lvl, n_levels, wire_slot, wires, log_n, err, ctx);
 }
 
 // The whole witness fill in one launch with the value table in LDS: initial assignments, generator levels, and
@@ -399,12 +404,12 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
   __syncthreads();
   for (u32 k = threadIdx.x; k < n_pairs; k += kBlock) m.store((u32)pairs[2 * k], pairs[2 * k + 1]);
   __syncthreads();
-  run_levels(m, ops, lvl, n_levels, wire_slot, err, ctx);
+  run_levels(m, ops, lvl, n_levels, wire_slot, wires, log_n, err, ctx);
   const u32 n = 1u << log_n;
   for (u32 t = threadIdx.x; t < kNumWires * n; t += kBlock) {
     const u32 col = t >> log_n, row = t & (n - 1);
     const u32 s = wire_slot[(size_t)row * kNumWires + col];
-    wires[t] = m.set[s] ? m.vals[s] : 0;
+    if (s != kNoSlot && m.set[s]) wires[t] = m.vals[s];  // everything else: zero-filled before the launch, or written above
   }
   for (u32 t = threadIdx.x; t < n_pi; t += kBlock) {
     const u32 s = pi_slot[t];
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_scatter(const u64* __restric
   if (t >= kNumWires * n) return;
   const u32 col = t >> log_n, row = t & (n - 1);
   const u32 s = wire_slot[(size_t)row * kNumWires + col];
-  wires[t] = set[s] ? vals[s] : 0;
+  if (s != kNoSlot && set[s]) wires[t] = vals[s];
 }
 
 // ------------------------------------------------------------------------------------------------ quotient (device)
@@ -735,7 +740,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
     for (size_t gi = 0; gi < c->gens.size(); ++gi) {
       if (done[gi]) continue;
       const Gen& g = c->gens[gi];
-      u32 ins[13], outs[123];
+      u32 ins[13], outs[12];
       u32 n_in = 0, n_out = 0;
       WOp op{};
       op.kind = (u32)g.kind;
@@ -760,8 +765,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
       } else {  // PoseidonGenerator
         for (u32 k = 0; k < 12; ++k) ins[n_in++] = slot_w(g.row, k);
         ins[n_in++] = slot_w(g.row, 24);
-        for (u32 k = 12; k < kNumWires; ++k)
-          if (k != 24) outs[n_out++] = slot_w(g.row, k);
+        for (u32 k = 12; k < 24; ++k) outs[n_out++] = slot_w(g.row, k);
         op.a = g.row;
       }
       int level = 0;
@@ -823,6 +827,7 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   for (const auto& sv : pw->sets) {
     if (!valid_target(c, sv.first)) return p2mt::fail(P2MT_EINVAL, "prove: witness sets a target that is not part of this circuit");
     const u32 slot = c->slot_of[target_index(c, sv.first)];
+    if (slot == kNoSlot) return p2mt::fail(P2MT_EINVAL, "prove: witness sets a wire that no generator or copy constraint uses");
     auto it = seen.find(slot);
     if (it != seen.end()) {
       if (it->second != sv.second) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values");
@@ -841,6 +846,7 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
   P2MT_HIP(hipMemcpyAsync(c->d_init, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, st));  // pageable: staged before return
   u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
+  P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
   if (c->lds_bytes) {
     hipLaunchKernelGGL(k_witness_lds, dim3(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
                        (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_wire_slot, c->degree_bits,
@@ -853,7 +859,7 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
                      c->d_set);
   P2MT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
-                     c->d_set, (const u32*)c->d_wire_slot, c->d_err, p2mt::perm_ctx());
+                     c->d_set, (const u32*)c->d_wire_slot, c->d_w_vals, c->degree_bits, c->d_err, p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for((size_t)kNumWires * c->n)), dim3(kBlock), 0, st, (const u64*)c->d_vals,
                      (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->degree_bits, c->d_w_vals, (const u32*)c->d_pi_slot,
@@ -1108,24 +1114,55 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
     const u32 a = find(target_index(c, cp.first)), d = find(target_index(c, cp.second));
     if (a != d) parent[d] = a;
   }
-  c->slot_of.assign(n_targets, 0);
+  // classes of targets under the copy constraints (all of them: sigma needs every routed wire's class) ...
+  std::vector<u32> cls(n_targets, 0);
+  u32 n_cls = 0;
   {
-    std::vector<u32> slot_of_rep(n_targets, 0xFFFFFFFFu);
+    std::vector<u32> cls_of_rep(n_targets, kNoSlot);
     for (size_t k = 0; k < n_targets; ++k) {
       const u32 r = find((u32)k);
-      if (slot_of_rep[r] == 0xFFFFFFFFu) slot_of_rep[r] = c->n_slots++;
-      c->slot_of[k] = slot_of_rep[r];
+      if (cls_of_rep[r] == kNoSlot) cls_of_rep[r] = n_cls++;
+      cls[k] = cls_of_rep[r];
     }
+  }
+  // ... and a value slot only for the classes something reads or sets: virtual targets, copy-constrained wires, generator
+  // inputs / outputs, constants, public inputs.  Unused wires and the PoseidonGate's 110 non-routed wires get none, which
+  // keeps the table of a 64-row circuit at ~2 k slots (18 KB) and lets circuits of a few hundred rows stay in LDS.
+  {
+    std::vector<char> active(n_cls, 0);
+    auto mark = [&](u64 t) { active[cls[target_index(c, t)]] = 1; };
+    for (u64 v = 0; v < b->n_virtual; ++v) mark(v);
+    for (const auto& cp : b->copies) {
+      mark(cp.first);
+      mark(cp.second);
+    }
+    for (const auto& g : b->gens) {
+      if (g.kind == GEN_ARITH) {
+        for (u32 k = 0; k < 4; ++k) mark(wire_t(g.row, 4 * g.i + k));
+      } else if (g.kind == GEN_EQUALITY) {
+        mark(g.x), mark(g.y), mark(g.eq), mark(g.inv);
+      } else if (g.kind == GEN_POSEIDON) {
+        for (u32 k = 0; k < 25; ++k) mark(wire_t(g.row, k));
+      } else {
+        mark(wire_t(g.row, g.i));
+      }
+    }
+    for (u64 t : b->public_inputs) mark(t);
+    std::vector<u32> slot_of_cls(n_cls, kNoSlot);
+    for (u32 k = 0; k < n_cls; ++k)
+      if (active[k]) slot_of_cls[k] = c->n_slots++;
+    c->slot_of.resize(n_targets);
+    for (size_t k = 0; k < n_targets; ++k) c->slot_of[k] = slot_of_cls[cls[k]];
   }
   u64 k_is[kNumRouted];
   k_is[0] = 1;
   for (u32 j = 1; j < kNumRouted; ++j) k_is[j] = h_mul(k_is[j - 1], 7);
   {
     // members of every class in row-major order; sigma sends a wire to the next member of its class (cyclically)
-    std::vector<u32> first(c->n_slots, 0xFFFFFFFFu), last(c->n_slots, 0xFFFFFFFFu), next(n * kNumRouted, 0);
+    std::vector<u32> first(n_cls, 0xFFFFFFFFu), last(n_cls, 0xFFFFFFFFu), next(n * kNumRouted, 0);
     for (size_t row = 0; row < n; ++row)
       for (u32 col = 0; col < kNumRouted; ++col) {
-        const u32 s = c->slot_of[row * kNumWires + col], id = (u32)(row * kNumRouted + col);
+        const u32 s = cls[row * kNumWires + col], id = (u32)(row * kNumRouted + col);
         if (first[s] == 0xFFFFFFFFu) first[s] = id;
         else next[last[s]] = id;
         last[s] = id;
