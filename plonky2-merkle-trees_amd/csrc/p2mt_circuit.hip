@@ -96,7 +96,7 @@ struct p2mt_partial_witness {
 };
 
 struct p2mt_circuit_data {
-  u32 degree_bits = 0, n = 0, num_selectors = 0, n_kinds = 0, n_cs = 0, n_slots = 0, n_pi = 0;
+  u32 degree_bits = 0, n = 0, num_selectors = 0, n_kinds = 0, n_cs = 0, n_slots = 0, n_pi = 0, n_act = 0;
   u32 kind[G_KINDS] = {}, sel[G_KINDS] = {}, gs[G_KINDS] = {}, ge[G_KINDS] = {}, counts[G_KINDS] = {};
   u64 n_virtual = 0;
   std::vector<Gen> gens;
@@ -118,7 +118,7 @@ struct p2mt_circuit_data {
   u64 *d_z_vals = nullptr, *d_z_coeffs = nullptr, *d_z_lde = nullptr, *d_z_leaves = nullptr, *d_z_dig = nullptr, *d_pp_q = nullptr;
   u64 *d_q_vals = nullptr, *d_q_coeffs = nullptr, *d_q_lde = nullptr, *d_q_leaves = nullptr, *d_q_dig = nullptr;
   u64 *d_head = nullptr, *d_open = nullptr, *d_chal = nullptr, *d_kis = nullptr, *d_vals = nullptr, *d_init = nullptr;
-  u32 *d_set = nullptr, *d_wire_slot = nullptr, *d_pi_slot = nullptr, *d_lvl = nullptr;
+  u32 *d_set = nullptr, *d_wire_slot = nullptr, *d_pi_slot = nullptr, *d_lvl = nullptr, *d_pslots = nullptr, *d_prows = nullptr;
   WOp* d_ops = nullptr;
   int* d_err = nullptr;  // [0] witness conflict (op index + 1, or -1 unset public input), [1] zero denominator
   size_t init_cap = 0, ops_cap = 0, lds_bytes = 0;  // lds_bytes != 0: the value table fits LDS (k_witness_lds)
@@ -333,41 +333,76 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
 // One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
 // and puts the PoseidonGate rows first).  PoseidonGenerator: one wavefront per row, lane w < 12 owns state word w.
 // The PoseidonGate's non-routed wires (delta and S-box inputs: 110 of the row's 135) are never read by a generator nor
-// copy-constrained, so they have no value slot: they go straight into the wire matrix.
+// copy-constrained, so they have no value slot and are not computed here at all: the level loop is a dependency chain, and
+// recording them costs ~40 % on top of every chained permutation.  k_poseidon_rows recomputes every row in parallel, with
+// the recording hook, once the wire matrix holds the rows' inputs.
 template <typename Mem>
 GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                       const u32* __restrict__ wire_slot, u64* __restrict__ wires, u32 log_n, int* err, const PermCtx& ctx) {
+                       const u32* __restrict__ pslots, u64* __restrict__ wires, u32 log_n, int* err, const PermCtx& ctx) {
+  // A level should cost its LDS reads, its arithmetic and a barrier, not a chain of global-memory round trips: the level
+  // bounds sit in LDS (when they fit), the generator records are staged into LDS a chunk of whole levels at a time (one
+  // exposed load latency per <= 512 generators instead of one per level), and each wavefront's PoseidonGate row for level
+  // l + 1 is looked up while level l runs.
+  constexpr u32 kLvlLds = 1024, kChunk = 512;
+  __shared__ u32 lvl_lds[2 * kLvlLds + 1];
+  __shared__ WOp ops_lds[kChunk];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kBlock / 64;
+  const u32* L = lvl;
+  if (n_levels <= kLvlLds) {
+    for (u32 k = tid; k < 2 * n_levels + 1; k += kBlock) lvl_lds[k] = lvl[k];
+    __syncthreads();
+    L = lvl_lds;
+  }
+  u32 ch_begin = 0, ch_end = 0;  // generators [ch_begin, ch_end) are in ops_lds
+  auto OP = [&](u32 o) -> WOp { return (o >= ch_begin && o < ch_end) ? ops_lds[o - ch_begin] : ops[o]; };
+  auto stage = [&](u32 l) {  // all threads, between two barriers of the level loop
+    const u32 s = L[2 * l], e = L[2 * l + 2];
+    if (e <= ch_end && s >= ch_begin) return;
+    ch_begin = ch_end = 0;
+    if (e - s > kChunk) return;  // a level wider than the chunk is read from global memory
+    u32 last = l;
+    while (last + 1 < n_levels && L[2 * (last + 2)] - s <= kChunk) ++last;
+    const u32 end = L[2 * (last + 1)];
+    for (u32 k = tid; k < end - s; k += kBlock) ops_lds[k] = ops[s + k];
+    __syncthreads();
+    ch_begin = s;
+    ch_end = end;
+  };
+  auto lookup = [&](u32 l, u32& row, u32& ps) {  // this wavefront's first PoseidonGate row of level l
+    const u32 s = L[2 * l], np = L[2 * l + 1];
+    if (wave < np) {
+      const WOp po = OP(s + wave);
+      row = po.a;
+      ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;
+    }
+  };
+  u32 cur_row = 0, cur_ps = 0, nxt_row = 0, nxt_ps = 0;
+  if (n_levels) {
+    stage(0);
+    lookup(0, cur_row, cur_ps);
+  }
   for (u32 l = 0; l < n_levels; ++l) {
-    const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
+    const u32 s = L[2 * l], np = L[2 * l + 1], e = L[2 * l + 2];
+    if (l + 1 < n_levels && L[2 * (l + 1) + 2] <= ch_end) lookup(l + 1, nxt_row, nxt_ps);  // else: after the next staging
     for (u32 o = s + wave; o < s + np; o += n_waves) {  // wave-uniform
-      const u32 row = ops[o].a;
-      const u32* ws = wire_slot + (size_t)row * kNumWires;
-      u64* wrow = wires + row;  // wire (row, col) = wrow[col << log_n]
-      u64 x = lane < 12 ? m.get(ws[lane]) : 0;
-      const u64 swap = m.get(ws[24]);
-      const u64 partner = __shfl_xor((unsigned long long)x, 4);
-      if (lane < 4) {  // delta_i = swap * (in[i+4] - in[i]); the permutation runs on the swapped state
-        const u64 d = gl::canon(gl::mul(swap, fsub(partner, x)));
-        wrow[(size_t)(25 + lane) << log_n] = d;
-        x = gl::add(x, d);
-      } else if (lane < 8) {
-        x = fsub(x, gl::mul(swap, fsub(x, partner)));
+      u32 row = cur_row, ps = cur_ps;
+      if (o != s + wave) {  // more PoseidonGate rows in this level than wavefronts
+        const WOp po = OP(o);
+        row = po.a;
+        ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;
       }
-      x = permute_wave_hook(x, ctx, [&](int r, u64 xv) {
-        if (lane >= 12 || r == 0) return;
-        u32 col;
-        if (r < 4) col = 29 + 12 * (r - 1) + lane;
-        else if (r < 26) {
-          if (lane != 0) return;
-          col = 65 + (r - 4);
-        } else col = 87 + 12 * (r - 26) + lane;
-        wrow[(size_t)col << log_n] = gl::canon(xv);
-      });
-      if (lane < 12) put(m, ws[12 + lane], x, err, o);
+      const u32 swap_slot = __shfl(ps, 24), out_slot = __shfl(ps, (lane + 12) & 31);
+      (void)row;
+      u64 x = lane < 12 ? m.get(ps) : 0;
+      const u64 swap = m.get(swap_slot);
+      const u64 partner = __shfl_xor((unsigned long long)x, 4);
+      if (lane < 4) x = gl::add(x, gl::mul(swap, fsub(partner, x)));       // the permutation runs on the swapped state
+      else if (lane < 8) x = fsub(x, gl::mul(swap, fsub(x, partner)));
+      x = permute_wave(x, ctx);  // outputs only: the row's delta / S-box wires are filled afterwards (k_poseidon_rows)
+      if (lane < 12) put(m, out_slot, x, err, o);
     }
     for (u32 o = s + np + tid; o < e; o += kBlock) {
-      const WOp op = ops[o];
+      const WOp op = OP(o);
       if (op.kind == GEN_ARITH) {
         const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
         put(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
@@ -378,22 +413,32 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
       }
     }
     m.sync();
+    if (l + 1 < n_levels) {
+      if (L[2 * (l + 1) + 2] <= ch_end) {
+        cur_row = nxt_row;
+        cur_ps = nxt_ps;
+      } else {
+        stage(l + 1);
+        lookup(l + 1, cur_row, cur_ps);
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                                                        u64* vals, u32* set, const u32* __restrict__ wire_slot,
+                                                        u64* vals, u32* set, const u32* __restrict__ pslots,
                                                         u64* __restrict__ wires, u32 log_n, int* err, PermCtx ctx) {
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
-  run_levels(GMem{vals, set}, ops, lvl, n_levels, wire_slot, wires, log_n, err, ctx);
+  run_levels(GMem{vals, set}, ops, lvl, n_levels, pslots, wires, log_n, err, ctx);
 }
 
 // The whole witness fill in one launch with the value table in LDS: initial assignments, generator levels, and
 // full_witness (wires[col][row], public inputs) straight from LDS.
 __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ pairs, u32 n_pairs, u32 n_slots,
                                                         const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                                                        const u32* __restrict__ wire_slot, u32 log_n, u64* __restrict__ wires,
+                                                        const u32* __restrict__ pslots, const u32* __restrict__ wire_slot, u32 n_act,
+                                                        u32 log_n, u64* __restrict__ wires,
                                                         const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
                                                         int* err, PermCtx ctx) {
   __shared__ u64 rc_lds[360];
@@ -404,12 +449,12 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
   __syncthreads();
   for (u32 k = threadIdx.x; k < n_pairs; k += kBlock) m.store((u32)pairs[2 * k], pairs[2 * k + 1]);
   __syncthreads();
-  run_levels(m, ops, lvl, n_levels, wire_slot, wires, log_n, err, ctx);
-  const u32 n = 1u << log_n;
-  for (u32 t = threadIdx.x; t < kNumWires * n; t += kBlock) {
-    const u32 col = t >> log_n, row = t & (n - 1);
-    const u32 s = wire_slot[(size_t)row * kNumWires + col];
-    if (s != kNoSlot && m.set[s]) wires[t] = m.vals[s];  // everything else: zero-filled before the launch, or written above
+  run_levels(m, ops, lvl, n_levels, pslots, wires, log_n, err, ctx);
+  // full_witness: only the wires that own a slot (list of (wire index, slot) pairs); everything else was zero-filled before
+  // the launch or written by the PoseidonGate rows above
+  for (u32 k = threadIdx.x; k < n_act; k += kBlock) {
+    const u32 t = wire_slot[2 * k], s = wire_slot[2 * k + 1];
+    if (m.set[s]) wires[t] = m.vals[s];
   }
   for (u32 t = threadIdx.x; t < n_pi; t += kBlock) {
     const u32 s = pi_slot[t];
@@ -418,21 +463,52 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
   }
 }
 
-// PartitionWitness::full_witness: wires[col][row] = value of the wire's class (0 if nothing set it) + the public inputs
+// PartitionWitness::full_witness for the global-memory path: wires[col][row] of every wire that owns a slot + the public inputs
 __global__ __launch_bounds__(kBlock) void k_witness_scatter(const u64* __restrict__ vals, const u32* __restrict__ set,
-                                                            const u32* __restrict__ wire_slot, u32 log_n, u64* __restrict__ wires,
+                                                            const u32* __restrict__ act, u32 n_act, u64* __restrict__ wires,
                                                             const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
                                                             int* err) {
-  const u32 t = blockIdx.x * kBlock + threadIdx.x, n = 1u << log_n;
-  if (t < n_pi) {
-    const u32 s = pi_slot[t];
+  const u32 k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < n_pi) {
+    const u32 s = pi_slot[k];
     if (!set[s]) atomicCAS(err, 0, -1);
-    pi_out[t] = vals[s];
+    pi_out[k] = vals[s];
   }
-  if (t >= kNumWires * n) return;
-  const u32 col = t >> log_n, row = t & (n - 1);
-  const u32 s = wire_slot[(size_t)row * kNumWires + col];
-  if (s != kNoSlot && set[s]) wires[t] = vals[s];
+  if (k >= n_act) return;
+  const u32 t = act[2 * k], s = act[2 * k + 1];
+  if (set[s]) wires[t] = vals[s];
+}
+
+// PoseidonGenerator's non-routed outputs for every PoseidonGate row at once: one wavefront per row reads the row's inputs and
+// swap bit from the wire matrix and replays the permutation with a hook that stores delta (wires 25-28) and every S-box
+// input (wires 29-134).
+__global__ __launch_bounds__(kBlock) void k_poseidon_rows(const u32* __restrict__ rows, u32 n_rows, u64* __restrict__ wires,
+                                                          u32 log_n, PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
+  const u32 k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= n_rows) return;  // wave-uniform
+  u64* wrow = wires + rows[k];  // wire (row, col) = wrow[col << log_n]
+  u64 x = lane < 12 ? wrow[(size_t)lane << log_n] : 0;
+  const u64 swap = wrow[(size_t)24 << log_n];
+  const u64 partner = __shfl_xor((unsigned long long)x, 4);
+  if (lane < 4) {  // delta_i = swap * (in[i+4] - in[i])
+    const u64 d = gl::canon(gl::mul(swap, fsub(partner, x)));
+    wrow[(size_t)(25 + lane) << log_n] = d;
+    x = gl::add(x, d);
+  } else if (lane < 8) {
+    x = fsub(x, gl::mul(swap, fsub(x, partner)));
+  }
+  (void)permute_wave_hook(x, ctx, [&](int r, u64 xv) {
+    if (lane >= 12 || r == 0) return;
+    u32 col;
+    if (r < 4) col = 29 + 12 * (r - 1) + lane;
+    else if (r < 26) {
+      if (lane != 0) return;
+      col = 65 + (r - 4);
+    } else col = 87 + 12 * (r - 26) + lane;
+    wrow[(size_t)col << log_n] = gl::canon(xv);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ quotient (device)
@@ -733,6 +809,8 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
     WOp op;
   };
   std::vector<Item> items;
+  std::vector<u32> pslots;  // per PoseidonGate row: the value slots of wires 0..24 (inputs, outputs, swap), padded to 32
+  u32 n_poseidon = 0;
   std::vector<char> done(c->gens.size(), 0);
   size_t remaining = c->gens.size();
   while (remaining) {
@@ -779,6 +857,11 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
       ++level;
       for (u32 k = 0; k < n_out; ++k)
         if (set_level[outs[k]] < 0) set_level[outs[k]] = level;
+      if (g.kind == GEN_POSEIDON) {  // only now: a generator that is not ready yet is visited again in a later pass
+        op.b = n_poseidon++;
+        pslots.resize((size_t)n_poseidon * 32, 0);
+        for (u32 k = 0; k < 25; ++k) pslots[(size_t)op.b * 32 + k] = slot_w(g.row, k);
+      }
       items.push_back(Item{level, op});
       done[gi] = 1;
       ++progressed;
@@ -807,8 +890,18 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
   P2MT_HIP(hipStreamSynchronize(st));  // the previous schedule may still be in use
   if (!ops.empty()) P2MT_HIP(hipMemcpy(c->d_ops, ops.data(), ops.size() * sizeof(WOp), hipMemcpyHostToDevice));
   P2MT_HIP(hipMemcpy(c->d_lvl, lvl.data(), lvl.size() * 4, hipMemcpyHostToDevice));
+  if (!pslots.empty()) P2MT_HIP(hipMemcpy(c->d_pslots, pslots.data(), pslots.size() * 4, hipMemcpyHostToDevice));
   c->sched_inputs = input_slots;
   c->sched_valid = true;
+  return P2MT_OK;
+}
+
+int fill_poseidon_rows(p2mt_circuit_data* c) {
+  const u32 n_rows = c->counts[G_POSEIDON];
+  if (!n_rows) return P2MT_OK;
+  hipLaunchKernelGGL(k_poseidon_rows, dim3((n_rows + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, rt().stream,
+                     (const u32*)c->d_prows, n_rows, c->d_w_vals, c->degree_bits, p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
 
@@ -849,23 +942,24 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
   if (c->lds_bytes) {
     hipLaunchKernelGGL(k_witness_lds, dim3(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
-                       (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_wire_slot, c->degree_bits,
+                       (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_pslots, (const u32*)c->d_wire_slot,
+                       c->n_act, c->degree_bits,
                        c->d_w_vals, (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, c->d_err, p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
-    return P2MT_OK;
+    return fill_poseidon_rows(c);
   }
   P2MT_HIP(hipMemsetAsync(c->d_set, 0, (size_t)c->n_slots * 4, st));
   hipLaunchKernelGGL(k_witness_init, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
                      c->d_set);
   P2MT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
-                     c->d_set, (const u32*)c->d_wire_slot, c->d_w_vals, c->degree_bits, c->d_err, p2mt::perm_ctx());
+                     c->d_set, (const u32*)c->d_pslots, c->d_w_vals, c->degree_bits, c->d_err, p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for((size_t)kNumWires * c->n)), dim3(kBlock), 0, st, (const u64*)c->d_vals,
-                     (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->degree_bits, c->d_w_vals, (const u32*)c->d_pi_slot,
-                     c->n_pi, d_pi_out, c->d_err);
+  hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for(std::max<size_t>(c->n_act, c->n_pi))), dim3(kBlock), 0, st,
+                     (const u64*)c->d_vals, (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->n_act, c->d_w_vals,
+                     (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, c->d_err);
   P2MT_LAUNCH_CHECK();
-  return P2MT_OK;
+  return fill_poseidon_rows(c);
 }
 
 int witness_status(p2mt_circuit_data* c, const int* err) {
@@ -1195,7 +1289,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   {  // value table in LDS when it fits (160 KB per CU on gfx950; env P2MT_WITNESS_LDS=0 forces the global-memory path)
     const size_t need = (size_t)c->n_slots * 9 + 16;
     const char* e = getenv("P2MT_WITNESS_LDS");
-    if (need <= 160 * 1024 - 4096 && !(e && e[0] == '0')) {  // minus the static round-constant table
+    if (need <= 160 * 1024 - 36 * 1024 && !(e && e[0] == '0')) {  // minus the static round-constant, level and generator tables
       c->lds_bytes = (need + 15) & ~(size_t)15;
       if (c->lds_bytes > 64 * 1024)
         P2MT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_witness_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1221,9 +1315,10 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   const size_t o_vals = carve(c->n_slots), o_set = carve((c->n_slots + 1) / 2);
   c->init_cap = c->const_inits.size() + n_targets;
   const size_t o_init = carve(2 * c->init_cap);
-  const size_t o_wslot = carve((n * kNumWires + 1) / 2), o_pislot = carve((c->n_pi + 2) / 2);
+  const size_t o_wslot = carve(n * kNumWires + 1), o_pislot = carve((c->n_pi + 2) / 2);
   c->ops_cap = c->gens.size();
   const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2), o_err = carve(1);
+  const size_t o_pslots = carve((size_t)c->counts[G_POSEIDON] * 16 + 16), o_prows = carve(c->counts[G_POSEIDON] / 2 + 1);
   if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");
   u64* base = c->d_base;
   c->d_cs_vals = base + bc.vals, c->d_cs_coeffs = base + bc.coeffs, c->d_cs_lde = base + bc.lde, c->d_cs_leaves = base + bc.leaves, c->d_cs_dig = base + bc.dig;
@@ -1235,6 +1330,8 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   c->d_vals = base + o_vals, c->d_set = (u32*)(base + o_set), c->d_init = base + o_init;
   c->d_wire_slot = (u32*)(base + o_wslot), c->d_pi_slot = (u32*)(base + o_pislot);
   c->d_ops = (WOp*)(base + o_ops), c->d_lvl = (u32*)(base + o_lvl), c->d_err = (int*)(base + o_err);
+  c->d_pslots = (u32*)(base + o_pslots);
+  c->d_prows = (u32*)(base + o_prows);
   hipStream_t st = rt().stream;
   P2MT_HIP(hipMemsetAsync(c->d_base, 0, words * 8, st));
   std::vector<u32> pi_slot(c->n_pi);
@@ -1242,7 +1339,26 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   P2MT_HIP(hipMemcpyAsync(c->d_cs_vals, c->h_cs.data(), c->h_cs.size() * 8, hipMemcpyHostToDevice, st));
   std::copy(k_is, k_is + kNumRouted, c->k_is);
   P2MT_HIP(hipMemcpyAsync(c->d_kis, k_is, sizeof k_is, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(c->d_wire_slot, c->slot_of.data(), n * kNumWires * 4, hipMemcpyHostToDevice, st));
+  {
+    std::vector<u32> prows;
+    for (size_t row = 0; row < n; ++row)
+      if (b->gates[row].kind == G_POSEIDON) prows.push_back((u32)row);
+    if (!prows.empty()) P2MT_HIP(hipMemcpy(c->d_prows, prows.data(), prows.size() * 4, hipMemcpyHostToDevice));
+  }
+  {  // (wire index in the [col][row] matrix, slot) of every wire that owns a slot
+    std::vector<u32> act;
+    for (u32 col = 0; col < kNumWires; ++col)
+      for (size_t row = 0; row < n; ++row) {
+        const u32 sl = c->slot_of[row * kNumWires + col];
+        if (sl != kNoSlot) {
+          act.push_back((u32)(col * n + row));
+          act.push_back(sl);
+        }
+      }
+    c->n_act = (u32)(act.size() / 2);
+    if (c->n_act) P2MT_HIP(hipMemcpyAsync(c->d_wire_slot, act.data(), act.size() * 4, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipStreamSynchronize(st));  // `act` dies here
+  }
   if (c->n_pi) P2MT_HIP(hipMemcpyAsync(c->d_pi_slot, pi_slot.data(), c->n_pi * 4, hipMemcpyHostToDevice, st));
   // constants_sigmas commitment and the circuit digest = hash_no_pad(cap || hash_no_pad([]) || degree_bits)
   u64* d_cap = c->d_head + 8;  // borrowed: the proof buffer is not in use yet
