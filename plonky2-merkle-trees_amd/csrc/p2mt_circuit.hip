@@ -1343,7 +1343,10 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
     std::vector<u32> prows;
     for (size_t row = 0; row < n; ++row)
       if (b->gates[row].kind == G_POSEIDON) prows.push_back((u32)row);
-    if (!prows.empty()) P2MT_HIP(hipMemcpy(c->d_prows, prows.data(), prows.size() * 4, hipMemcpyHostToDevice));
+    if (!prows.empty()) {  // on the library stream, behind the zero-fill of the allocation above
+      P2MT_HIP(hipMemcpyAsync(c->d_prows, prows.data(), prows.size() * 4, hipMemcpyHostToDevice, st));
+      P2MT_HIP(hipStreamSynchronize(st));  // `prows` dies here
+    }
   }
   {  // (wire index in the [col][row] matrix, slot) of every wire that owns a slot
     std::vector<u32> act;

@@ -352,6 +352,39 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restr
   if (lane < 4) digests[4 * col + lane] = gl::canon(x);
 }
 
+// The last <= 5 levels below the cap in ONE launch: a workgroup of 16 wavefronts owns one cap entry's subtree (<= 32 input
+// nodes), a wavefront hashes one node per level, levels hand over through LDS.  Same latency as one launch per level (a
+// level is one wave-permutation either way) but a fifth of the launches -- what limits concurrent provers is the number of
+// dispatch packets, not the CUs.  in: 2^cap subtrees of 2^log_sub nodes each; next: where the level after `in` goes in the
+// level-major digest array (null = the caller keeps no digests); cap: the 2^cap results.
+__global__ __launch_bounds__(1024) void k_merkle_top(const u64* __restrict__ in, unsigned log_sub, u64* __restrict__ next,
+                                                     size_t n_in, u64* __restrict__ cap, p2mt::PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  __shared__ u64 buf[2][16][4];
+  ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
+  const unsigned c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u64* src = in + ((size_t)c << log_sub) * 4;
+  size_t lvl_off = 0;  // offset of level t in `next`, in nodes
+  for (unsigned t = 1; t <= log_sub; ++t) {
+    const unsigned cnt = 1u << (log_sub - t);
+    if (wave < cnt) {
+      u64 x = 0;
+      if (lane < 8) {
+        const unsigned child = 2 * wave + (lane >> 2), word = lane & 3;
+        x = t == 1 ? src[4 * child + word] : buf[t & 1][child][word];
+      }
+      x = gl::canon(p2mt_dev::permute_wave(x, ctx));
+      if (lane < 4) {
+        buf[(t + 1) & 1][wave][lane] = x;
+        if (t == log_sub) cap[4 * (size_t)c + lane] = x;
+        else if (next) next[4 * (lvl_off + ((size_t)c << (log_sub - t)) + wave) + lane] = x;
+      }
+    }
+    lvl_off += n_in >> t;
+    __syncthreads();
+  }
+}
+
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 // ---------------------------------------------------------------- host-side table cache (per process / device)
@@ -616,6 +649,13 @@ static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u6
   u64* ping = nullptr;  // ping-pong rows when the caller does not want digests
   if (!d_digests_out) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchPing, n * 32, (void**)&ping));
   for (unsigned level = 0; level < (unsigned)k - cap_height; ++level) {
+    const unsigned remaining = (unsigned)k - cap_height - level;
+    if (remaining >= 2 && remaining <= 5 && rt().mds == 2 && rt().use_quad) {  // the top of the tree in one launch
+      hipLaunchKernelGGL(k_merkle_top, dim3(1u << cap_height), dim3(1024), 0, rt().stream, (const u64*)cur, remaining,
+                         d_digests_out ? next_store : nullptr, cur_n, d_cap_out, p2mt::perm_ctx());
+      P2MT_LAUNCH_CHECK();
+      return P2MT_OK;
+    }
     const bool last = level + 1 == (unsigned)k - cap_height;
     u64* dst = last ? d_cap_out : (d_digests_out ? next_store : ping + (level & 1 ? 0 : 4 * (n / 2)));
     P2MT_TRY(p2mt::launch_merkle_level_dev(cur, dst, cur_n / 2));
