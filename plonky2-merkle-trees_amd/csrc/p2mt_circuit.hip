@@ -1459,7 +1459,7 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
 
   // witness, public-input hash, wires commitment
   P2MT_TRY(fill_witness(c, pw));
-  P2MT_HIP(hipMemcpyAsync(d_digest, c->digest, 32, hipMemcpyHostToDevice, st));
+  // (the circuit digest has been sitting at d_head[0..4) since build(): nothing to upload)
   if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(d_pi, 1, c->n_pi, 0, d_pi_hash));
   else P2MT_HIP(hipMemsetAsync(d_pi_hash, 0, 32, st));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_w_vals, 1, kNumWires, log_n, kRateBits, kCapHeight, c->d_w_coeffs, c->d_w_lde, c->d_w_leaves,

@@ -109,6 +109,26 @@ __global__ __launch_bounds__(kBlock) void k_bitrev_scale(const u64* __restrict__
   out[(poly << log_n) + r] = v;
 }
 
+// Whole inverse transform of one polynomial (n <= 2^12) in one launch: values in natural order -> LDS, inverse DIF, and
+// the bit-reversal back to natural order fused with the 1/n (and, for coset_ifft, shift^-k) scaling.  Replaces the
+// copy + DIF + bit-reversal launches of the small circuits, where the launch count is what limits concurrent provers.
+__global__ __launch_bounds__(kBlock) void k_ifft_small(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_n,
+                                                       const u64* __restrict__ tw_inv, u64 n_inv, u64 shift_inv) {
+  extern __shared__ __attribute__((aligned(16))) u64 buf[];
+  const unsigned n = 1u << log_n;
+  const u64* src = in + ((size_t)blockIdx.x << log_n);
+  u64* dst = out + ((size_t)blockIdx.x << log_n);
+  for (unsigned i = threadIdx.x; i < n; i += kBlock) buf[i] = gl::canon(src[i]);
+  __syncthreads();
+  if (log_n) lds_dif(buf, log_n, 0, tw_inv);
+  for (unsigned q = threadIdx.x; q < n; q += kBlock) {
+    const unsigned r = brev32(q, log_n);
+    u64 v = cmul(buf[q], n_inv);
+    if (shift_inv != 1) v = cmul(v, gl::pow(shift_inv, r));
+    dst[r] = v;
+  }
+}
+
 // ---------------------------------------------------------------- coset LDE, one workgroup per (poly, coset)
 // coeffs [n_polys][n] natural; out [n_polys][n << r] in LEAF ORDER: out[p][brev_r(j) * n + q] = DIF position q of
 // NTT_n[c_m * cp[j][m]], cp[j][m] = (shift * w_N^j)^m.
@@ -714,7 +734,16 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   const size_t n = (size_t)1 << log_n, big = (size_t)1 << log_big;
   hipStream_t st = rt().stream;
   const u64* d_coeffs = d_polys;
-  if (is_values) {  // IFFT: DIF with inverse roots, then bit-reversal + 1/n
+  if (is_values && log_n <= kLdsLog) {  // IFFT in one launch
+    u64* coeffs = d_coeffs_out;
+    if (!coeffs) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8, (void**)&coeffs));
+    const u64* twi;
+    P2MT_TRY(get_twiddles(log_n, 1, &twi));
+    hipLaunchKernelGGL(k_ifft_small, dim3((unsigned)n_polys), dim3(kBlock), (size_t)8 << log_n, st, d_polys, coeffs, log_n, twi,
+                       h_pow((u64)n % gl::P, gl::P - 2), (u64)1);
+    P2MT_LAUNCH_CHECK();
+    d_coeffs = coeffs;
+  } else if (is_values) {  // IFFT: DIF with inverse roots, then bit-reversal + 1/n
     u64* buf;
     P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8 * 2, (void**)&buf));
     u64* work = buf + n_polys * n;
@@ -776,8 +805,16 @@ __global__ __launch_bounds__(kBlock) void k_bitrev_coset_scale(const u64* __rest
 
 int p2mt::coset_ifft_dev(uint64_t* d_vals, unsigned log_n, size_t n_polys, uint64_t shift, uint64_t* d_coeffs_out) {
   if (!d_vals || !d_coeffs_out || n_polys == 0 || log_n > 32) return p2mt::fail(P2MT_EINVAL, "coset_ifft: bad argument");
-  P2MT_TRY(ntt_dif_dev(d_vals, log_n, n_polys, 1));
   const u64 n_inv = h_pow(((u64)1 << log_n) % gl::P, gl::P - 2), shift_inv = h_pow(shift % gl::P, gl::P - 2);
+  if (log_n <= kLdsLog) {
+    const u64* twi;
+    P2MT_TRY(get_twiddles(log_n, 1, &twi));
+    hipLaunchKernelGGL(k_ifft_small, dim3((unsigned)n_polys), dim3(kBlock), (size_t)8 << log_n, rt().stream, (const u64*)d_vals,
+                       d_coeffs_out, log_n, twi, n_inv, shift_inv);
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  P2MT_TRY(ntt_dif_dev(d_vals, log_n, n_polys, 1));
   hipLaunchKernelGGL(k_bitrev_coset_scale, dim3(grid_for(n_polys << log_n)), dim3(kBlock), 0, rt().stream, (const u64*)d_vals,
                      d_coeffs_out, log_n, n_polys, n_inv, shift_inv);
   P2MT_LAUNCH_CHECK();
