@@ -446,6 +446,8 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) u64 sh[];
   const LMem m{sh, reinterpret_cast<uint8_t*>(sh + n_slots)};
   for (u32 k = threadIdx.x; k < n_slots; k += kBlock) m.set[k] = 0;
+  for (u32 t = threadIdx.x; t < (kNumWires << log_n); t += kBlock) wires[t] = 0;  // wires nothing sets are zero
+  if (threadIdx.x < 2) err[threadIdx.x] = 0;
   __syncthreads();
   for (u32 k = threadIdx.x; k < n_pairs; k += kBlock) m.store((u32)pairs[2 * k], pairs[2 * k + 1]);
   __syncthreads();
@@ -936,10 +938,12 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   const size_t n_pairs = pairs.size() / 2;
   if (n_pairs > c->init_cap) return p2mt::fail(P2MT_EINVAL, "prove: too many witness assignments");
   hipStream_t st = rt().stream;
-  P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
   P2MT_HIP(hipMemcpyAsync(c->d_init, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, st));  // pageable: staged before return
   u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
-  P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
+  if (!c->lds_bytes) {
+    P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
+    P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
+  }
   if (c->lds_bytes) {
     hipLaunchKernelGGL(k_witness_lds, dim3(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
                        (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_pslots, (const u32*)c->d_wire_slot,

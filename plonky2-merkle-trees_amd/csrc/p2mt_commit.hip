@@ -357,7 +357,8 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restr
 // loads word k of each 8-word chunk, the chunk's permutation runs on 12 lanes (permute_wave, ~11 us instead of ~18 us
 // on a quad), so a 135-wide leaf costs 17 x 11 us.
 __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restrict__ in, size_t w, size_t n_pts,
-                                                              u64* __restrict__ digests, p2mt::PermCtx ctx) {
+                                                              u64* __restrict__ digests, u64* __restrict__ leaves,
+                                                              p2mt::PermCtx ctx) {
   __shared__ u64 rc_lds[360];
   ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
   const size_t col = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -366,7 +367,10 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restr
   u64 x = 0;
 #pragma unroll 1
   for (size_t off = 0; off < w; off += 8) {
-    if (lane < 8 && off + lane < w) x = in[(off + lane) * n_pts + col];
+    if (lane < 8 && off + lane < w) {
+      x = in[(off + lane) * n_pts + col];
+      if (leaves) leaves[col * w + off + lane] = x;  // the leaf-major copy the FRI queries read (saves the transpose launch)
+    }
     x = p2mt_dev::permute_wave(x, ctx);
   }
   if (lane < 4) digests[4 * col + lane] = gl::canon(x);
@@ -761,7 +765,8 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   u64* lde = d_lde_out;
   if (!lde) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
   P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
-  if (d_leaves_out) {
+  const bool wave_sponge = n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad;
+  if (d_leaves_out && !wave_sponge) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
                        (const u64*)lde, d_leaves_out, n_polys, big);
     P2MT_LAUNCH_CHECK();
@@ -769,9 +774,9 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   const bool cap_is_leaves = cap_height == log_big;
   u64* d_level0 = (d_digests_out && !cap_is_leaves) ? d_digests_out : nullptr;
   if (!d_level0) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, big * 32, (void**)&d_level0));
-  if (n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad) {
+  if (wave_sponge) {
     hipLaunchKernelGGL(k_hash_columns_wave, dim3((unsigned)((big + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
-                       (const u64*)lde, n_polys, big, d_level0, p2mt::perm_ctx());
+                       (const u64*)lde, n_polys, big, d_level0, d_leaves_out, p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
   } else if (n_polys > 4 && big <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
     hipLaunchKernelGGL(k_hash_columns_quad, dim3(grid_for(4 * big)), dim3(kBlock), 0, st, (const u64*)lde, n_polys, big,
