@@ -6,11 +6,13 @@
 //   host   CircuitBuilder under CircuitConfig::standard_recursion_config() restricted to the gate set those circuits use
 //          (NoopGate, ConstantGate, PublicInputGate, ArithmeticGate, PoseidonGate); build(): selector / constant / sigma
 //          polynomials and their commitment; the generator schedule (levels of independent generators).
-//   device witness fill (k_witness_run: one workgroup interprets the levelled generator list, one wavefront per PoseidonGate
-//          row with the 12-lanes-per-permutation layout recording every S-box input wire), wires commitment, challenger,
-//          Z / partial products, the quotient polynomials (k_quotient: one lane per point of the 8n-point LDE coset evaluates
-//          every gate's constraints, the permutation checks and L_0 (Z - 1), combined with powers of alpha and divided by
-//          Z_H), coset IFFT, quotient commitment, openings and the FRI proof (p2mt_fri.hip).
+//   device witness fill (k_witness_lds / k_witness_run: one workgroup interprets the levelled generator list out of an LDS or
+//          global value table, one wavefront per PoseidonGate row on the 12-lanes-per-permutation layout; k_poseidon_rows then
+//          replays every row in parallel to record its S-box input wires), wires commitment, challenger, Z / partial
+//          products, the quotient polynomials (k_quotient: four role-wavefronts per 64 points of the 8n-point LDE coset
+//          evaluate every gate's constraints, the permutation checks and L_0 (Z - 1), combined with powers of alpha and
+//          divided by Z_H), coset IFFT, quotient commitment, openings and the FRI proof (p2mt_fri.hip);
+//          verify: transcript and Merkle paths (k_verify_merkle) here, the field arithmetic in p2mt_verify_host.hip.
 // Nothing here is GEMM-shaped: 64-bit modular arithmetic on the integer VALU, latency-bound at these sizes (64..4096 rows).
 #include "tree_common.hip.h"
 
