@@ -413,3 +413,26 @@ def test_random_circuits_match_the_oracle(pkg, oracle, seed):
     check_build(gcd, ocd)
     proof = check_prove(gcd, pw, ocd, opw)
     assert gcd.verify(proof, with_reason=True) == (True, 0)
+
+
+def _multi_peak_case(oracle, n_siblings, n_peaks, which, seed):
+    """n_siblings path elements folding to peak `which` of n_peaks peaks; root = hash_no_pad of all peak words (> 1 peak)."""
+    leaf, siblings, lefts, peak, _ = synthetic_case(oracle, n_siblings, seed)
+    rng = np.random.default_rng(seed + 7)
+    peaks = rng.integers(0, P, size=(n_peaks, 4), dtype=np.uint64)
+    peaks[which] = peak[0]
+    root = oracle.hash_or_noop(peaks.reshape(-1))
+    return leaf, siblings, lefts, peaks, root
+
+
+@pytest.mark.parametrize("n_siblings,n_peaks,which", [(0, 1, 0), (1, 1, 0), (2, 3, 1), (5, 2, 0), (9, 4, 3), (13, 5, 2),
+                                                      (26, 1, 0), (27, 2, 1), (31, 7, 6), (40, 3, 0), (63, 2, 1)])
+def test_circuit_shape_sweep(pkg, oracle, n_siblings, n_peaks, which):
+    """verify_mmr_proof_circuit over the shapes MMR sizes up to 2^63 produce (0..63 path elements, 1..7 peaks): 16..256-row
+    circuits, one or two selector groups, bagging with one or several permutations; everything bit-exact vs the oracle."""
+    case = _multi_peak_case(oracle, n_siblings, n_peaks, which, 500 + n_siblings)
+    gcd, pw, ocd, opw = build_both(pkg, oracle, case)
+    check_build(gcd, ocd)
+    proof = check_prove(gcd, pw, ocd, opw)
+    assert gcd.verify(proof, with_reason=True) == (True, 0)
+    assert [int(x) for x in proof[-4:]] == [int(x) for x in case[4]]
