@@ -17,6 +17,7 @@
 #include "tree_common.hip.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <map>
@@ -127,6 +128,9 @@ struct p2mt_circuit_data {
   p2mt_challenger* ch = nullptr;
   // verifier scratch (allocated on the first p2mt_circuit_verify)
   u64* d_verify = nullptr;
+  // pinned host staging: [0..2) zeta, [2..4) err flags, [8..8+proof_len) proof, then the witness assignments (H2D)
+  u64* h_pin = nullptr;
+  size_t pin_pairs_off = 0;
   p2mt_challenger* vch = nullptr;
   u64 k_is[kNumRouted] = {};
 };
@@ -940,7 +944,8 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   const size_t n_pairs = pairs.size() / 2;
   if (n_pairs > c->init_cap) return p2mt::fail(P2MT_EINVAL, "prove: too many witness assignments");
   hipStream_t st = rt().stream;
-  P2MT_HIP(hipMemcpyAsync(c->d_init, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, st));  // pageable: staged before return
+  std::copy(pairs.begin(), pairs.end(), c->h_pin + c->pin_pairs_off);  // pinned: a DMA copy, no blit kernel on the queue
+  P2MT_HIP(hipMemcpyAsync(c->d_init, c->h_pin + c->pin_pairs_off, pairs.size() * 8, hipMemcpyHostToDevice, st));
   u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
   if (!c->lds_bytes) {
     P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
@@ -1105,6 +1110,7 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (c->ch) p2mt_challenger_destroy(c->ch);
   if (c->vch) p2mt_challenger_destroy(c->vch);
   if (c->d_verify) (void)hipFree(c->d_verify);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->d_base) {
     (void)hipStreamSynchronize(rt().stream);
     (void)hipFree(c->d_base);
@@ -1326,6 +1332,9 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2), o_err = carve(1);
   const size_t o_pslots = carve((size_t)c->counts[G_POSEIDON] * 16 + 16), o_prows = carve(c->counts[G_POSEIDON] / 2 + 1);
   if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");
+  c->pin_pairs_off = 8 + c->proof_len;
+  if (hipHostMalloc((void**)&c->h_pin, (c->pin_pairs_off + 2 * c->init_cap) * 8, hipHostMallocDefault) != hipSuccess)
+    return p2mt::fail(P2MT_ENOMEM, "hipHostMalloc(circuit staging) failed");
   u64* base = c->d_base;
   c->d_cs_vals = base + bc.vals, c->d_cs_coeffs = base + bc.coeffs, c->d_cs_lde = base + bc.lde, c->d_cs_leaves = base + bc.leaves, c->d_cs_dig = base + bc.dig;
   c->d_w_vals = base + bw.vals, c->d_w_coeffs = base + bw.coeffs, c->d_w_lde = base + bw.lde, c->d_w_leaves = base + bw.leaves, c->d_w_dig = base + bw.dig;
@@ -1504,9 +1513,9 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   P2MT_TRY(p2mt::commit_batch_dev(c->d_q_coeffs, 0, kNumQuot, log_n, kRateBits, kCapHeight, nullptr, c->d_q_lde, c->d_q_leaves,
                                   c->n_digests ? c->d_q_dig : nullptr, d_q_cap));
   P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_q_cap, 64, c->d_chal + 3 * kNumCh, 2));  // zeta
-  u64 zeta[2];
-  P2MT_HIP(hipMemcpyAsync(zeta, c->d_chal + 3 * kNumCh, 16, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(c->h_pin, c->d_chal + 3 * kNumCh, 16, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
+  const u64 zeta[2] = {c->h_pin[0], c->h_pin[1]};
   {  // plonky2: ensure!(zeta^n != 1)
     u64 a = zeta[0], b2 = zeta[1];
     for (u32 k = 0; k < log_n; ++k) {
@@ -1539,10 +1548,12 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   hipLaunchKernelGGL(k_opening_set, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs);
   P2MT_LAUNCH_CHECK();
   P2MT_TRY(p2mt_fri_prove_openings_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri));
-  int err[2] = {0, 0};
-  P2MT_HIP(hipMemcpyAsync(proof_out, d_proof, c->proof_len * 8, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(c->h_pin + 8, d_proof, c->proof_len * 8, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(c->h_pin + 2, c->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
+  std::copy(c->h_pin + 8, c->h_pin + 8 + c->proof_len, proof_out);
+  int err[2];
+  memcpy(err, c->h_pin + 2, sizeof err);
   return witness_status(c, err);
 }
 
