@@ -436,3 +436,16 @@ def test_circuit_shape_sweep(pkg, oracle, n_siblings, n_peaks, which):
     proof = check_prove(gcd, pw, ocd, opw)
     assert gcd.verify(proof, with_reason=True) == (True, 0)
     assert [int(x) for x in proof[-4:]] == [int(x) for x in case[4]]
+
+
+def test_build_refuses_more_than_4096_rows(pkg):
+    """The commit kernels cover degree_bits <= 12: a circuit that pads to 2^13 rows is refused at build() (status -1), not
+    silently mis-proved."""
+    b = pkg.CircuitBuilder()
+    x = b.add_virtual_target()
+    h = [x] * 5
+    for _ in range(4097):
+        h = b.hash_n_to_hash_no_pad(h + [x])
+    assert b.num_gates() == 4097
+    with pytest.raises(pkg.P2mtPanic):
+        b.build()
