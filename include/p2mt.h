@@ -53,6 +53,11 @@ int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches of
  * calls enqueue there.  This is how several provers run concurrently on one GPU -- one handle (MMR, circuit data,
  * challenger) per thread; a 64-row prove occupies a few CUs for ~2.6 ms, so independent proofs overlap almost freely. */
 int p2mt_thread_stream_create(void);
+/* Process-wide kernel-selection policy.  0 (default) = latency: small batches of hashes run on the 12-lanes-per-permutation
+ * layout (one proof as fast as possible; a wavefront then uses 12 of its 64 lanes).  1 = throughput: leaf sponges, Merkle
+ * levels and the proof-of-work grind use the 4-lanes / 1-lane-per-hash layouts instead -- a single proof gets slower, but
+ * concurrent provers stop competing for SIMD issue slots.  Results are bit-identical in both modes. */
+int p2mt_set_throughput_mode(int on);
 int p2mt_sync(void);                    /* hipStreamSynchronize on the library stream */
 const char *p2mt_last_error(void);
 /* Kernel variant for the Poseidon permutation.  mds 2 (default) = issue-optimised path (constants folded into the
@@ -254,6 +259,9 @@ int p2mt_challenger_get_challenges_dev(p2mt_challenger *c, size_t n, uint64_t *d
 /* observe + squeeze in one launch (the duplex the prover performs after every commitment), and a reset to Challenger::new() */
 int p2mt_challenger_reset(p2mt_challenger *c);
 int p2mt_challenger_duplex_dev(p2mt_challenger *c, const uint64_t *d_elements, size_t n_obs, uint64_t *d_out, size_t n_out);
+/* the same from a fresh transcript (Challenger::new() + observe + squeeze in one launch) */
+int p2mt_challenger_restart_duplex_dev(p2mt_challenger *c, const uint64_t *d_elements, size_t n_obs, uint64_t *d_out,
+                                       size_t n_out);
 /* state words for tests/checkpoints: sponge_state[12] | input_buffer[8] | output_buffer[8] | n_in | n_out */
 #define P2MT_CHALLENGER_STATE_WORDS 30
 int p2mt_challenger_get_state(const p2mt_challenger *c, uint64_t *out);

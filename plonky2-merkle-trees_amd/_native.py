@@ -28,6 +28,7 @@ SIGNATURES = {
     "p2mt_device_count": (C.c_int, []),
     "p2mt_set_stream": (C.c_int, [voidp]),
     "p2mt_thread_stream_create": (C.c_int, []),
+    "p2mt_set_throughput_mode": (C.c_int, [C.c_int]),
     "p2mt_sync": (C.c_int, []),
     "p2mt_last_error": (C.c_char_p, []),
     "p2mt_set_variant": (C.c_int, [C.c_int, C.c_int]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "p2mt_challenger_set_state": (C.c_int, [voidp, voidp]),
     "p2mt_challenger_reset": (C.c_int, [voidp]),
     "p2mt_challenger_duplex_dev": (C.c_int, [voidp, voidp, C.c_size_t, voidp, C.c_size_t]),
+    "p2mt_challenger_restart_duplex_dev": (C.c_int, [voidp, voidp, C.c_size_t, voidp, C.c_size_t]),
     "p2mt_eval_polys_ext": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_eval_polys_ext_dev": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_fri_openings": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, C.c_uint, voidp]),

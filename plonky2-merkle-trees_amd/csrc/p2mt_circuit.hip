@@ -1323,16 +1323,16 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   auto carve_batch = [&](size_t polys) { return Batch{carve(polys * n), carve(polys * n), carve(polys * big), carve(polys * big), carve(4 * (nd ? nd : 1))}; };
   const Batch bc = carve_batch(n_cs), bw = carve_batch(kNumWires), bz = carve_batch(kNumZs), bq = carve_batch(kNumQuot);
   const size_t o_qvals = carve(kNumCh * big), o_ppq = carve((size_t)kNumCh * kNumChunks * n);
-  const size_t o_head = carve(8 + c->proof_len), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
+  const size_t o_head = carve(8 + c->proof_len + 1), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
   const size_t o_vals = carve(c->n_slots), o_set = carve((c->n_slots + 1) / 2);
   c->init_cap = c->const_inits.size() + n_targets;
   const size_t o_init = carve(2 * c->init_cap);
   const size_t o_wslot = carve(n * kNumWires + 1), o_pislot = carve((c->n_pi + 2) / 2);
   c->ops_cap = c->gens.size();
-  const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2), o_err = carve(1);
+  const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2);
   const size_t o_pslots = carve((size_t)c->counts[G_POSEIDON] * 16 + 16), o_prows = carve(c->counts[G_POSEIDON] / 2 + 1);
   if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");
-  c->pin_pairs_off = 8 + c->proof_len;
+  c->pin_pairs_off = 8 + c->proof_len + 1;
   if (hipHostMalloc((void**)&c->h_pin, (c->pin_pairs_off + 2 * c->init_cap) * 8, hipHostMallocDefault) != hipSuccess)
     return p2mt::fail(P2MT_ENOMEM, "hipHostMalloc(circuit staging) failed");
   u64* base = c->d_base;
@@ -1344,7 +1344,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   c->d_head = base + o_head, c->d_open = base + o_open, c->d_chal = base + o_chal, c->d_kis = base + o_kis;
   c->d_vals = base + o_vals, c->d_set = (u32*)(base + o_set), c->d_init = base + o_init;
   c->d_wire_slot = (u32*)(base + o_wslot), c->d_pi_slot = (u32*)(base + o_pislot);
-  c->d_ops = (WOp*)(base + o_ops), c->d_lvl = (u32*)(base + o_lvl), c->d_err = (int*)(base + o_err);
+  c->d_ops = (WOp*)(base + o_ops), c->d_lvl = (u32*)(base + o_lvl), c->d_err = (int*)(base + o_head + 8 + c->proof_len);
   c->d_pslots = (u32*)(base + o_pslots);
   c->d_prows = (u32*)(base + o_prows);
   hipStream_t st = rt().stream;
@@ -1480,8 +1480,7 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   P2MT_TRY(p2mt::commit_batch_dev(c->d_w_vals, 1, kNumWires, log_n, kRateBits, kCapHeight, c->d_w_coeffs, c->d_w_lde, c->d_w_leaves,
                                   c->n_digests ? c->d_w_dig : nullptr, d_w_cap));
   // challenger: circuit digest, public-input hash, wires cap -> betas, gammas
-  P2MT_TRY(p2mt_challenger_reset(c->ch));
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_digest, 8 + 64, c->d_chal, 2 * kNumCh));
+  P2MT_TRY(p2mt_challenger_restart_duplex_dev(c->ch, d_digest, 8 + 64, c->d_chal, 2 * kNumCh));
   // Z and partial products, committed with Z at the front
   P2MT_TRY(p2mt::partial_products_async_dev(c->d_w_vals, c->d_cs_vals + (size_t)(c->num_selectors + kNumConsts) * n, c->d_kis,
                                             c->d_chal, c->d_chal + kNumCh, kNumCh, kNumRouted, log_n, kQF, c->d_pp_q, c->d_z_vals,
@@ -1548,12 +1547,12 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   hipLaunchKernelGGL(k_opening_set, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs);
   P2MT_LAUNCH_CHECK();
   P2MT_TRY(p2mt_fri_prove_openings_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri));
-  P2MT_HIP(hipMemcpyAsync(c->h_pin + 8, d_proof, c->proof_len * 8, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipMemcpyAsync(c->h_pin + 2, c->d_err, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  // the error flags sit right behind the proof words: one copy brings both back
+  P2MT_HIP(hipMemcpyAsync(c->h_pin + 8, d_proof, (c->proof_len + 1) * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   std::copy(c->h_pin + 8, c->h_pin + 8 + c->proof_len, proof_out);
   int err[2];
-  memcpy(err, c->h_pin + 2, sizeof err);
+  memcpy(err, c->h_pin + 8 + c->proof_len, sizeof err);
   return witness_status(c, err);
 }
 
@@ -1616,8 +1615,7 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
   else P2MT_HIP(hipMemsetAsync(dv + 4, 0, 32, st));
   // the whole transcript depends only on the proof: enqueue it in one go
   u64* d_out = dv + o_out;
-  P2MT_TRY(p2mt_challenger_reset(c->vch));
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv, 8 + 64, d_out, 2 * kNumCh));                       // betas, gammas
+  P2MT_TRY(p2mt_challenger_restart_duplex_dev(c->vch, dv, 8 + 64, d_out, 2 * kNumCh));               // betas, gammas
   P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + 64, 64, d_out + 2 * kNumCh, kNumCh));    // alphas
   P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + 128, 64, d_out + 3 * kNumCh, 2));         // zeta
   hipLaunchKernelGGL(k_opening_unset, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)(dv + o_proof + off_open),

@@ -674,7 +674,7 @@ static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u6
   if (!d_digests_out) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchPing, n * 32, (void**)&ping));
   for (unsigned level = 0; level < (unsigned)k - cap_height; ++level) {
     const unsigned remaining = (unsigned)k - cap_height - level;
-    if (remaining >= 2 && remaining <= 5 && rt().mds == 2 && rt().use_quad) {  // the top of the tree in one launch
+    if (remaining >= 2 && remaining <= 5 && rt().mds == 2 && rt().use_quad && !rt().throughput) {  // the top of the tree in one launch
       hipLaunchKernelGGL(k_merkle_top, dim3(1u << cap_height), dim3(1024), 0, rt().stream, (const u64*)cur, remaining,
                          d_digests_out ? next_store : nullptr, cur_n, d_cap_out, p2mt::perm_ctx());
       P2MT_LAUNCH_CHECK();
@@ -765,7 +765,7 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   u64* lde = d_lde_out;
   if (!lde) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
   P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
-  const bool wave_sponge = n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad;
+  const bool wave_sponge = n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad && !rt().throughput;
   if (d_leaves_out && !wave_sponge) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
                        (const u64*)lde, d_leaves_out, n_polys, big);

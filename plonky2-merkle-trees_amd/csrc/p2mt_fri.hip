@@ -67,16 +67,17 @@ static_assert(sizeof(ChState) == 8 * (12 + 8 + 8) + 8, "layout shared with p2mt_
 
 // Observe obs[0..n_obs), then squeeze n_sq challenges into sq.  One wavefront; lane w < 12 owns sponge word w.
 __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, const u64* __restrict__ obs, u32 n_obs,
-                                                   u64* __restrict__ sq, u32 n_sq, PermCtx ctx) {
+                                                   u64* __restrict__ sq, u32 n_sq, u32 fresh, PermCtx ctx) {
   __shared__ u64 s_in[8], s_out[8];
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   const unsigned lane = threadIdx.x;
-  u64 x = lane < 12 ? st->state[lane] : 0;
-  u32 n_in = st->n_in, n_out = st->n_out;  // wave-uniform
+  // fresh: start from Challenger::new() (zero sponge, empty buffers) without a separate reset launch
+  u64 x = (lane < 12 && !fresh) ? st->state[lane] : 0;
+  u32 n_in = fresh ? 0 : st->n_in, n_out = fresh ? 0 : st->n_out;  // wave-uniform
   if (lane < 8) {
-    s_in[lane] = st->in[lane];
-    s_out[lane] = st->out[lane];
+    s_in[lane] = fresh ? 0 : st->in[lane];
+    s_out[lane] = fresh ? 0 : st->out[lane];
   }
   __syncthreads();
   // duplexing(): overwrite the first n_in words with the buffered inputs, permute, refill the output buffer
@@ -437,9 +438,10 @@ size_t digests_count(size_t rows, unsigned cap_height) {
   return c;
 }
 
-int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, size_t n_sq) {
+int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, size_t n_sq, bool fresh = false) {
   if (n_obs > 0xFFFFFFFFull || n_sq > 0xFFFFFFFFull) return p2mt::fail(P2MT_EINVAL, "challenger: too many elements");
-  hipLaunchKernelGGL(k_challenger, dim3(1), dim3(64), 0, rt().stream, st, d_obs, (u32)n_obs, d_sq, (u32)n_sq, p2mt::perm_ctx());
+  hipLaunchKernelGGL(k_challenger, dim3(1), dim3(64), 0, rt().stream, st, d_obs, (u32)n_obs, d_sq, (u32)n_sq, fresh ? 1u : 0u,
+                     p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
@@ -514,6 +516,13 @@ extern "C" int p2mt_challenger_duplex_dev(p2mt_challenger* c, const uint64_t* d_
   if (!c || (n_obs && !d_elements) || (n_out && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n_obs == 0 && n_out == 0) return P2MT_OK;
   return launch_challenger(c->d, d_elements, n_obs, d_out, n_out);
+}
+
+extern "C" int p2mt_challenger_restart_duplex_dev(p2mt_challenger* c, const uint64_t* d_elements, size_t n_obs, uint64_t* d_out,
+                                                  size_t n_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || (n_obs && !d_elements) || (n_out && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  return launch_challenger(c->d, d_elements, n_obs, d_out, n_out, true);
 }
 
 extern "C" int p2mt_challenger_get_challenges_dev(p2mt_challenger* c, size_t n, uint64_t* d_out) {
@@ -820,7 +829,7 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
       if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
       P2MT_HIP(hipMemsetAsync(d_wit, 0xFF, 8, st));
       P2MT_HIP(hipMemcpyAsync(d_saved, ch->d, sizeof(ChState), hipMemcpyDeviceToDevice, st));
-      if (rt().mds == 2 && rt().use_quad && !rt().force_fallback) {
+      if (rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput) {
         hipLaunchKernelGGL(k_fri_pow_quad, dim3(grid_for(4 * chunk)), dim3(kBlock), 0, st, (const ChState*)ch->d,
                            (u32)p->proof_of_work_bits, base, chunk, d_wit, p2mt::perm_ctx());
         P2MT_LAUNCH_CHECK();

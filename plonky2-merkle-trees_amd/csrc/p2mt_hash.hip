@@ -228,7 +228,7 @@ int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, 
 }
 int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
   if (n_out == 0) return P2MT_OK;
-  if (n_out <= ((size_t)1 << 12) && rt().mds == 2) {  // small level: one wavefront per node (latency path)
+  if (n_out <= ((size_t)1 << 12) && rt().mds == 2 && !(rt().throughput && n_out > 16)) {  // small level: one wavefront per node (latency path)
     const unsigned per_block = kBlock / 64;
     hipLaunchKernelGGL(k_merkle_level_wave, dim3((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
                        rt().stream, d_in, d_out, n_out, p2mt::perm_ctx());

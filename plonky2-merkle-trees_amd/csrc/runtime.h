@@ -36,6 +36,7 @@ struct Runtime {
   int use_quad = 1;          // four-lanes-per-hash kernels for 2^12 < items <= 2^16 (env P2MT_QUAD=0 disables)
   unsigned subtree_block = 256; // workgroup size of the per-lane subtree kernel (env P2MT_SUBTREE_BLOCK=64|128|256)
   unsigned subtree_levels = 4;  // stage 1 as per-lane subtrees of 2^4 / 2^5 leaves (env P2MT_SUBTREE=4|5); 0 = fused tiles
+  int throughput = 0;        // p2mt_set_throughput_mode: prefer lane-efficient layouts over the latency-optimised ones
   int use_lde12 = 1;         // register-blocked 2^12 LDE kernel (env P2MT_LDE12=0 selects the generic radix-2 one)
   unsigned tile_log = 10;    // fused MMR stage: 2^tile_log inputs per workgroup (env P2MT_TILE_LOG = 9|10|11)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;

@@ -144,6 +144,11 @@ extern "C" int p2mt_thread_stream_create(void) {
   return P2MT_OK;
 }
 
+extern "C" int p2mt_set_throughput_mode(int on) {
+  rt().throughput = on != 0;
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_set_stream(void* hip_stream) {
   rt().stream = static_cast<hipStream_t>(hip_stream);
   return P2MT_OK;

@@ -2,7 +2,7 @@
 """Concurrent-prover throughput of mmr_plonky2_verifier prove on one GPU: T host threads, each with its own stream
 (p2mt_thread_stream_create), circuit handle and witness, proving the same statement in a loop for a few seconds.
 
-usage: prove_threads_probe.py <hipDeviceSchedule flag: -1 keep default (spin), 4 blocking sync> <threads> [seconds]
+usage: prove_threads_probe.py <hipDeviceSchedule flag: -1 keep default (spin), 4 blocking sync> <threads> [seconds] [throughput mode 0/1]
 Prints one JSON line.  Run as its own process (bench.py --workload prove does): the device flag has to be set before the
 HIP context exists, and blocking sync costs a single prover ~0.1 ms of wake-up latency, so the latency leg keeps spinning."""
 import ctypes
@@ -14,6 +14,7 @@ import time
 
 flag, T = int(sys.argv[1]), int(sys.argv[2])
 seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
+throughput_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 if flag >= 0:
     ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(flag)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +28,7 @@ from circuit_cases import assign  # noqa: E402
 pkg = ge.load_package()
 pkg.init(0)
 lib, Nn = pkg.lib(), pkg._native
+Nn.check(lib.p2mt_set_throughput_mode(throughput_mode))
 # a 20-element membership path with one peak (config 3's shape), folded with the product's own hashing
 rng = np.random.default_rng(3)
 P = pkg.GOLDILOCKS_FIELD_ORDER
@@ -77,7 +79,7 @@ stop.set()
 for t in ths:
     t.join()
 dt = time.perf_counter() - t0
-print(json.dumps({"threads": T, "device_schedule_flag": flag, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+print(json.dumps({"threads": T, "device_schedule_flag": flag, "throughput_mode": throughput_mode, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                   "proofs": int(sum(counts)), "seconds": dt, "proofs_per_s": sum(counts) / dt,
                   "amortised_ms_per_proof": dt * 1e3 / max(sum(counts), 1),
                   "host_cpu_cores_busy": (time.process_time() - c0) / dt, "errors": errs[:2]}))
