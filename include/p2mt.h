@@ -56,7 +56,8 @@ int p2mt_thread_stream_create(void);
 /* Process-wide kernel-selection policy.  0 (default) = latency: small batches of hashes run on the 12-lanes-per-permutation
  * layout (one proof as fast as possible; a wavefront then uses 12 of its 64 lanes).  1 = throughput: leaf sponges, Merkle
  * levels and the proof-of-work grind use the 4-lanes / 1-lane-per-hash layouts instead -- a single proof gets slower, but
- * concurrent provers stop competing for SIMD issue slots.  Results are bit-identical in both modes. */
+ * concurrent provers stop competing for SIMD issue slots.  Results are bit-identical in both modes.  (Also: env
+ * P2MT_THROUGHPUT=1 at p2mt_init.) */
 int p2mt_set_throughput_mode(int on);
 int p2mt_sync(void);                    /* hipStreamSynchronize on the library stream */
 const char *p2mt_last_error(void);

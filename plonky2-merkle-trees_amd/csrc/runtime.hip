@@ -122,6 +122,7 @@ extern "C" int p2mt_init(int device) {
     if (v >= 9 && v <= 11) rt().tile_log = (unsigned)v;
   }
   if (const char* e = getenv("P2MT_QUAD")) rt().use_quad = atoi(e) != 0;
+  if (const char* e = getenv("P2MT_THROUGHPUT")) rt().throughput = atoi(e) != 0;
   if (const char* e = getenv("P2MT_LDE12")) rt().use_lde12 = atoi(e) != 0;
   if (const char* e = getenv("P2MT_SUBTREE_BLOCK")) {
     const int v = atoi(e);

@@ -37,6 +37,19 @@ def main():
         leaves_o, dig_o, cap_o = o.polynomial_batch_commit(polys, True)
         assert np.array_equal(pb.merkle_tree.cap, cap_o) and np.array_equal(pb.merkle_tree.leaves, leaves_o)
         assert np.array_equal(pb.merkle_tree.digests, dig_o)
+    # mmr_plonky2_verifier prove + verify against the committed vectors (tests/golden/prove_vectors.json)
+    import hashlib
+    import json
+    from circuit_cases import assign
+    for c in json.load(open(os.path.join(ROOT, "tests", "golden", "prove_vectors.json")))["cases"]:
+        case = (c["leaf"], np.array(c["siblings"], np.uint64).reshape(-1, 4), np.array(c["lefts"], np.uint8),
+                np.array(c["peaks"], np.uint64).reshape(-1, 4), np.array(c["root"], np.uint64))
+        cd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(len(case[1]), len(case[3]))
+        pw = pkg.PartialWitness()
+        assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, case, pw.set_target)
+        proof = cd.prove(pw)
+        assert hashlib.sha256(proof.astype("<u8").tobytes()).hexdigest() == c["proof_sha256"], "proof differs: " + c["name"]
+        assert cd.verify(proof)
     print("knobs ok:", {k: v for k, v in os.environ.items() if k.startswith("P2MT_")})
 
 
