@@ -147,6 +147,35 @@ __global__ __launch_bounds__(kBlock) void k_coset_lde(const u64* __restrict__ co
   for (unsigned q = threadIdx.x; q < n; q += kBlock) o[q] = buf[q];
 }
 
+// from_values for small polynomials (n <= 2^9) in ONE launch: every (poly, coset) workgroup redoes the cheap inverse
+// transform of its polynomial in LDS (8x redundant, negligible at this size), the coset-0 workgroup also writes the
+// coefficients, then the coset's forward transform goes out in leaf order as in k_coset_lde.
+__global__ __launch_bounds__(kBlock) void k_ifft_coset_lde(const u64* __restrict__ vals, unsigned log_n, unsigned rate_bits,
+                                                           const u64* __restrict__ coset_pow, const u64* __restrict__ tw,
+                                                           const u64* __restrict__ tw_inv, u64 n_inv, u64* __restrict__ coeffs,
+                                                           u64* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) u64 buf[];  // 2 n words
+  const unsigned n = 1u << log_n;
+  u64* cf = buf + n;
+  const unsigned poly = blockIdx.x >> rate_bits, j = blockIdx.x & ((1u << rate_bits) - 1);
+  const u64* v = vals + ((size_t)poly << log_n);
+  for (unsigned m = threadIdx.x; m < n; m += kBlock) buf[m] = gl::canon(v[m]);
+  __syncthreads();
+  if (log_n) lds_dif(buf, log_n, 0, tw_inv);
+  for (unsigned q = threadIdx.x; q < n; q += kBlock) cf[brev32(q, log_n)] = cmul(buf[q], n_inv);
+  __syncthreads();
+  const u64* cp = coset_pow + ((size_t)j << log_n);
+  for (unsigned m = threadIdx.x; m < n; m += kBlock) {
+    const u64 c = cf[m];
+    if (j == 0) coeffs[((size_t)poly << log_n) + m] = c;
+    buf[m] = cmul(c, cp[m]);
+  }
+  __syncthreads();
+  if (log_n) lds_dif(buf, log_n, 0, tw);
+  u64* o = out + ((size_t)poly << (log_n + rate_bits)) + ((size_t)brev32(j, rate_bits) << log_n);
+  for (unsigned q = threadIdx.x; q < n; q += kBlock) o[q] = buf[q];
+}
+
 // ---------------------------------------------------------------- register-blocked 2^12 coset LDE
 // The streaming version of k_coset_lde for n = 4096 (the d = 12 circuits of config 4).  Each of the 256 threads
 // keeps 16 points in registers and the transform is three radix-16 passes (4096 = 16 x 16 x 16), so the data
@@ -738,7 +767,24 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   const size_t n = (size_t)1 << log_n, big = (size_t)1 << log_big;
   hipStream_t st = rt().stream;
   const u64* d_coeffs = d_polys;
-  if (is_values && log_n <= kLdsLog) {  // IFFT in one launch
+  bool lde_done = false;
+  u64* lde = d_lde_out;
+  if (!lde) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
+  if (is_values && log_n <= 9 && rate_bits <= 8) {  // IFFT + x2^rate_bits coset LDE in one launch
+    u64* coeffs = d_coeffs_out;
+    if (!coeffs) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8, (void**)&coeffs));
+    const u64 *tw, *twi, *cp;
+    P2MT_TRY(get_twiddles(log_n, 0, &tw));
+    P2MT_TRY(get_twiddles(log_n, 1, &twi));
+    P2MT_TRY(get_coset_pows(log_n, rate_bits, 7, &cp));
+    const int slot = p2mt::prof_begin();
+    hipLaunchKernelGGL(k_ifft_coset_lde, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)16 << log_n, st, d_polys,
+                       log_n, rate_bits, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde);
+    p2mt::prof_end(slot);
+    P2MT_LAUNCH_CHECK();
+    d_coeffs = coeffs;
+    lde_done = true;
+  } else if (is_values && log_n <= kLdsLog) {  // IFFT in one launch
     u64* coeffs = d_coeffs_out;
     if (!coeffs) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8, (void**)&coeffs));
     const u64* twi;
@@ -762,9 +808,7 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
   } else if (d_coeffs_out && d_coeffs_out != d_polys) {
     P2MT_HIP(hipMemcpyAsync(d_coeffs_out, d_polys, n_polys * n * 8, hipMemcpyDeviceToDevice, st));
   }
-  u64* lde = d_lde_out;
-  if (!lde) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, n_polys * big * 8, (void**)&lde));
-  P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
+  if (!lde_done) P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
   const bool wave_sponge = n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad && !rt().throughput;
   if (d_leaves_out && !wave_sponge) {
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
