@@ -446,6 +446,7 @@ class CircuitBuilder {  // CircuitBuilder::<F, 2>::new(CircuitConfig::standard_r
     return h;
   }
   void register_public_inputs(const std::array<Target, 4>& t) { check(p2mt_cb_register_public_inputs(h_, t.data(), 4)); }
+  void register_public_input(Target t) { check(p2mt_cb_register_public_inputs(h_, &t, 1)); }
   CircuitData build() {  // builder.build::<C>() (:89)
     p2mt_circuit_data* c = nullptr;
     check(p2mt_cb_build(h_, &c));
@@ -540,5 +541,42 @@ inline MmrVerifierCircuit verify_mmr_proof_circuit(std::size_t nr_merkle_proof_e
   }
   return MmrVerifierCircuit{builder.build(), leaf_to_prove, std::move(proof_targets), std::move(peak_targets)};
 }
+
+
+// ---------------------------------------------------------------- src/mmr/mmr_plonky2_verifier_1_recursion.rs:20-75 (inner circuit)
+struct InnerMerkleProofCircuit {
+  CircuitData data;
+  Target leaf_to_prove;
+  std::vector<std::pair<HashOutTarget, BoolTarget>> proof_targets;
+};
+inline InnerMerkleProofCircuit verify_inner_merkle_proof_circuit(std::size_t nr_merkle_proof_elms, std::size_t nr_peaks) {
+  std::vector<std::pair<HashOutTarget, BoolTarget>> proof_targets;
+  CircuitBuilder builder;
+  const Target leaf_to_prove = builder.add_virtual_target();
+  HashOutTarget next_hash = builder.hash_or_noop({leaf_to_prove});
+  auto cat = [](const HashOutTarget& a, const HashOutTarget& b) {
+    std::vector<Target> v(a.elements.begin(), a.elements.end());
+    v.insert(v.end(), b.elements.begin(), b.elements.end());
+    return v;
+  };
+  for (std::size_t k = 0; k < nr_merkle_proof_elms; ++k) {
+    const HashOutTarget merkle_proof_elm = builder.add_virtual_hash();
+    const BoolTarget elm_on_left = builder.add_virtual_bool_target_safe();
+    proof_targets.emplace_back(merkle_proof_elm, elm_on_left);
+    const HashOutTarget option1 = builder.hash_or_noop(cat(merkle_proof_elm, next_hash));
+    const HashOutTarget option2 = builder.hash_or_noop(cat(next_hash, merkle_proof_elm));
+    next_hash = pick_hash(builder, option1, option2, elm_on_left);
+  }
+  std::vector<BoolTarget> equals;
+  for (std::size_t k = 0; k < nr_peaks; ++k) {
+    const HashOutTarget peak = builder.add_virtual_hash();
+    for (Target elm : peak.elements) builder.register_public_input(elm);
+    equals.push_back(equal(builder, peak, next_hash));
+  }
+  const BoolTarget hash_in_peaks = or_list(builder, equals);
+  builder.connect(builder.one(), hash_in_peaks.target);
+  return InnerMerkleProofCircuit{builder.build(), leaf_to_prove, std::move(proof_targets)};
+}
+// complete_verification_circuit_with_inner_proof (:84-140) needs plonky2's in-circuit verifier (builder.verify_proof): not built.
 
 }  // namespace p2mt

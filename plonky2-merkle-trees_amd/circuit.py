@@ -103,6 +103,9 @@ class CircuitBuilder:
         ts = _targets(targets)
         N.check(N.lib().p2mt_cb_register_public_inputs(self._h, N.ptr(ts), ts.size))
 
+    def register_public_input(self, target):
+        self.register_public_inputs([target])
+
     def num_gates(self):
         return N.lib().p2mt_cb_num_gates(self._h)
 

@@ -24,7 +24,8 @@ def verify_inner_merkle_proof_circuit(nr_merkle_proof_elms, nr_peaks):
     equals = []
     for _ in range(nr_peaks):
         peak = builder.add_virtual_hash()
-        builder.register_public_inputs(peak)
+        for elm in peak:
+            builder.register_public_input(elm)
         equals.append(equal(builder, peak, next_hash))
     hash_in_peaks = or_list(builder, equals)
     builder.connect(builder.one(), hash_in_peaks)

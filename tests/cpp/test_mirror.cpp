@@ -210,6 +210,26 @@ static void test_mmr_verifier_3leaves() {
   REQUIRE(panicked);
 }
 
+// mmr_plonky2_verifier_1_recursion.rs:152-192 (the inner proof of test_mmr_verifier_1_recursion): peaks are the public inputs
+static void test_inner_merkle_proof_3leaves() {
+  MMR mmr = MMR::from_leaves({1, 2, 3});
+  const MMR_proof pr = mmr.get_proof(get_mmr_index(1));
+  InnerMerkleProofCircuit c = verify_inner_merkle_proof_circuit(pr.merkle_proof.size(), pr.peaks.size());
+  REQUIRE(c.data.prover_only.public_inputs.size() == 4 * pr.peaks.size());
+  PartialWitness pw;
+  pw.set_target(c.leaf_to_prove, 2);
+  for (std::size_t i = 0; i < pr.merkle_proof.size(); ++i) {
+    pw.set_hash_target(c.proof_targets[i].first, pr.merkle_proof[i].first);
+    pw.set_bool_target(c.proof_targets[i].second, pr.merkle_proof[i].second);
+  }
+  for (std::size_t i = 0; i < pr.peaks.size(); ++i)
+    for (int k = 0; k < 4; ++k) pw.set_target(c.data.prover_only.public_inputs[4 * i + k], pr.peaks[i].elements[k]);
+  const ProofWithPublicInputs proof = c.data.prove(pw);
+  c.data.verify(proof);
+  for (std::size_t i = 0; i < pr.peaks.size(); ++i)
+    for (int k = 0; k < 4; ++k) REQUIRE(proof.public_inputs[4 * i + k] == pr.peaks[i].elements[k]);
+}
+
 int main() {
   if (p2mt_device_count() == 0) { std::fprintf(stderr, "no GPU: the product has no CPU fallback\n"); return 77; }
   check(p2mt_init(0));
@@ -223,6 +243,7 @@ int main() {
   test_get_proof();
   test_challenger_and_fri();
   test_mmr_verifier_3leaves();
+  test_inner_merkle_proof_3leaves();
   std::puts("cpp mirror: 8 reference tests + prover pieces passed");
   return 0;
 }
