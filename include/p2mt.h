@@ -53,6 +53,7 @@ int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches of
  * calls enqueue there.  This is how several provers run concurrently on one GPU -- one handle (MMR, circuit data,
  * challenger) per thread; a 64-row prove occupies a few CUs for ~2.6 ms, so independent proofs overlap almost freely. */
 int p2mt_thread_stream_create(void);
+int p2mt_thread_stream_destroy(void); /* before such a thread ends: frees its stream and its scratch buffers */
 /* Process-wide kernel-selection policy.  0 (default) = latency: small batches of hashes run on the 12-lanes-per-permutation
  * layout (one proof as fast as possible; a wavefront then uses 12 of its 64 lanes).  1 = throughput: leaf sponges, Merkle
  * levels and the proof-of-work grind use the 4-lanes / 1-lane-per-hash layouts instead -- a single proof gets slower, but

@@ -1305,9 +1305,15 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
     const char* e = getenv("P2MT_WITNESS_LDS");
     if (need <= 160 * 1024 - 36 * 1024 && !(e && e[0] == '0')) {  // minus the static round-constant, level and generator tables
       c->lds_bytes = (need + 15) & ~(size_t)15;
-      if (c->lds_bytes > 64 * 1024)
+      if (c->lds_bytes > 64 * 1024) {
+        // the limit is a property of the kernel, shared by every circuit (and thread): only ever raise it
+        static std::atomic<size_t> raised{64 * 1024};
+        size_t cur = raised.load();
+        while (c->lds_bytes > cur && !raised.compare_exchange_weak(cur, c->lds_bytes)) {
+        }
         P2MT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_witness_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)c->lds_bytes));
+                                     (int)raised.load()));
+      }
     }
   }
   // ---- device memory
@@ -1738,7 +1744,7 @@ extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_
         first_err.compare_exchange_strong(exp, rc);
       }
     }
-    (void)hipStreamSynchronize(s);
+    p2mt::scratch_release_thread();  // synchronises the stream first
     rt().stream = nullptr;
     (void)hipStreamDestroy(s);
   };

@@ -35,9 +35,14 @@ int fail(int code, const char* msg) {
   return code;
 }
 
+namespace {
+thread_local void* tl_scratch_ptr[kScratchCount] = {};  // per thread: concurrent provers must not share scratch
+thread_local size_t tl_scratch_cap[kScratchCount] = {};
+}  // namespace
+
 int scratch_get(int slot, size_t bytes, void** out) {
-  thread_local void* ptr[kScratchCount] = {};  // per thread: concurrent provers must not share scratch
-  thread_local size_t cap[kScratchCount] = {};
+  void** ptr = tl_scratch_ptr;
+  size_t* cap = tl_scratch_cap;
   if (bytes == 0) bytes = 8;
   if (bytes > cap[slot]) {
     if (ptr[slot]) {
@@ -55,6 +60,16 @@ int scratch_get(int slot, size_t bytes, void** out) {
   }
   *out = ptr[slot];
   return P2MT_OK;
+}
+
+// free the calling thread's scratch buffers (worker threads call it before they exit)
+void scratch_release_thread() {
+  (void)hipStreamSynchronize(rt().stream);
+  for (int k = 0; k < kScratchCount; ++k) {
+    if (tl_scratch_ptr[k]) (void)hipFree(tl_scratch_ptr[k]);
+    tl_scratch_ptr[k] = nullptr;
+    tl_scratch_cap[k] = 0;
+  }
 }
 
 int prof_begin() {
@@ -142,6 +157,17 @@ extern "C" int p2mt_thread_stream_create(void) {
   hipStream_t s = nullptr;
   P2MT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   rt().stream = s;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_thread_stream_destroy(void) {
+  hipStream_t s = rt().stream;
+  p2mt::scratch_release_thread();
+  if (s) {
+    P2MT_HIP(hipStreamSynchronize(s));
+    P2MT_HIP(hipStreamDestroy(s));
+  }
+  rt().stream = nullptr;
   return P2MT_OK;
 }
 

@@ -246,6 +246,8 @@ def test_concurrent_provers_on_threads(pkg, oracle):
             assign(leaf_t, proof_ts, peak_ts, gcd.prover_only.public_inputs, cases[i], pw.set_target)
             for _ in range(5):
                 got[i] = gcd.prove(pw)
+            del gcd, pw
+            pkg._native.check(pkg.lib().p2mt_thread_stream_destroy())
         except Exception as e:  # surfaced below
             errs.append(e)
 
@@ -477,3 +479,15 @@ def test_prove_many(pkg, oracle):
         pkg.prove_many([h[0] for h in handles], pws[:3] + [bad])
     with pytest.raises(pkg.P2mtPanic):
         pkg.prove_many([handles[0][0], handles[0][0]], pws[:2])  # the same handle twice
+
+
+def test_lds_limit_is_only_raised(pkg, oracle):
+    """The dynamic-LDS limit of the witness kernel is a property of the kernel: building a smaller circuit after a larger
+    one must not lower it under the larger one's feet (200 path elements -> ~90 KB table, then 100 -> ~70 KB, then prove both)."""
+    big_case, small_case = synthetic_case(oracle, 200, 5), synthetic_case(oracle, 100, 6)
+    big, bleaf, bproof_ts, bpeak_ts = pkg.verify_mmr_proof_circuit(200, 1)
+    small, sleaf, sproof_ts, speak_ts = pkg.verify_mmr_proof_circuit(100, 1)
+    for cd, leaf_t, proof_ts, peak_ts, case in ((big, bleaf, bproof_ts, bpeak_ts, big_case), (small, sleaf, sproof_ts, speak_ts, small_case)):
+        pw = pkg.PartialWitness()
+        assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, case, pw.set_target)
+        assert cd.verify(cd.prove(pw))

@@ -57,6 +57,8 @@ def worker(i):
         while not stop.is_set():
             Nn.check(lib.p2mt_circuit_prove(cd._h, pw._h, Nn.ptr(proof), proof.size))
             counts[i] += 1
+        del cd, pw
+        Nn.check(lib.p2mt_thread_stream_destroy())
     except Exception as e:
         errs.append(repr(e))
         stop.set()
