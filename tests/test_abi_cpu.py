@@ -92,3 +92,45 @@ def test_product_does_not_touch_oracle():
                     assert not pat.search(text), (dirpath, f, pat.search(text).group(0))
                     scanned += 1
     assert scanned >= 10
+
+
+def _construct(builder, gadgets, n_sib, n_peaks):
+    """verify_mmr_proof_circuit (mmr_plonky2_verifier.rs:13-87) up to, not including, build()."""
+    leaf = builder.add_virtual_target()
+    next_hash = builder.hash_or_noop([leaf])
+    for _ in range(n_sib):
+        elm = builder.add_virtual_hash()
+        on_left = builder.add_virtual_bool_target_safe()
+        option1 = builder.hash_or_noop(list(elm) + list(next_hash))
+        option2 = builder.hash_or_noop(list(next_hash) + list(elm))
+        next_hash = gadgets.pick_hash(builder, option1, option2, on_left)
+    peaks, equals = [], []
+    for _ in range(n_peaks):
+        peak = builder.add_virtual_hash()
+        peaks.append(peak)
+        equals.append(gadgets.equal(builder, peak, next_hash))
+    builder.connect(builder.one(), gadgets.or_list(builder, equals))
+    if n_peaks > 1:
+        builder.register_public_inputs(builder.hash_n_to_hash_no_pad([e for p in peaks for e in p]))
+    else:
+        builder.register_public_inputs(peaks[0])
+
+
+@pytest.mark.parametrize("n_sib,n_peaks", [(0, 1), (3, 2), (20, 1), (31, 5), (63, 3)])
+def test_circuit_builder_host_logic_matches_oracle(pkg, oracle, n_sib, n_peaks):
+    """The builder is host code (constant folding, operation cache, ArithmeticGate slot packing): without a GPU the gate rows
+    it lays out before build() must already equal the oracle builder's; build() itself needs the device (status -3)."""
+    from oracle import circuit as OC
+    from plonky2_merkle_trees_amd import mmr_plonky2_verifier as G
+    b = pkg.CircuitBuilder()
+    _construct(b, G, n_sib, n_peaks)
+    ob = OC.CircuitBuilder(oracle)
+    _construct(ob, OC, n_sib, n_peaks)
+    assert b.num_gates() == len(ob.gate_instances)
+    poseidon_rows = 2 * n_sib + ((4 * n_peaks + 7) // 8 if n_peaks > 1 else 0)  # two hashes per path element + the bagging
+    arithmetic_rows = sum(1 for g in ob.gate_instances if g[0] == OC.ARITHMETIC)
+    assert b.num_gates() == poseidon_rows + arithmetic_rows
+    if pkg.device_count() == 0:
+        with pytest.raises(pkg.P2mtError) as e:
+            b.build()
+        assert e.value.code == -3
