@@ -405,11 +405,28 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
                       "proof_words": int(cd.info.proof_len), "circuit_build_ms": build_ms,
                       "gate_rows": {k: int(v) for k, v in zip(("noop", "constant", "public_input", "arithmetic", "poseidon"),
                                                               cd.info.gate_counts)}},
-           "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                        "note": "a 64-row circuit: ~100 dependent small launches (witness levels, 3 commits, challenger, "
-                                "quotient, FRI); no kernel is bandwidth- or issue-bound at this size; per-kernel split in "
-                                "profiles/"},
            "public_inputs": [int(x) for x in proof[-4:]]}
+    # Roofline of the chain's unit of work: one wave-permutation (k_challenger & co: ~180 of them are chained per proof).
+    # Measured live with HIP events on the library stream: a transcript absorbing 8192 words = 1024 permutations in ONE launch.
+    # Bound: VALU issue of a single wavefront -- 30 rounds x (54 v_mad_u64_u32 at 8 cycles + 59 other VALU at 4 cycles) =
+    # 20 040 cycles at the 2.4 GHz peak engine clock (instruction mix from the ISA).
+    from plonky2_merkle_trees_amd import fri as F
+    ch = F.Challenger()
+    d_words = torch.arange(1, 8193, dtype=torch.int64, device="cuda")
+    Nn.check(lib.p2mt_challenger_observe_dev(ch._h, Nn.ptr(d_words), 8192))
+    torch.cuda.synchronize()
+    Nn.check(lib.p2mt_timer_start())
+    Nn.check(lib.p2mt_challenger_observe_dev(ch._h, Nn.ptr(d_words), 8192))
+    t_ms = C.c_float(0)
+    Nn.check(lib.p2mt_timer_stop(C.byref(t_ms)))
+    perm_us = t_ms.value * 1e3 / 1024
+    peak_perms = 2.4e9 / (30 * (54 * 8 + 59 * 4))
+    out["roofline"] = {"bound": "valu-issue (one wavefront; the chain is latency-bound, no HBM or MFMA roof applies)",
+                       "achieved": 1e6 / perm_us, "peak": peak_perms, "unit": "wave-permutations/s per wavefront",
+                       "frac": (1e6 / perm_us) / peak_perms, "traffic": None, "kernel": "k_challenger (permute_wave)",
+                       "us_per_permutation": perm_us, "permutations_timed": 1024,
+                       "note": "a 64-row proof chains ~180 wave-permutations (transcript 106, witness 21, leaf sponges 22, "
+                               "Merkle levels ~20, FRI ~10) plus ~30 small launches; per-kernel split in profiles/"}
     acc, reason = C.c_int(0), C.c_int(0)
     Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
     assert acc.value == 1, "the product's verifier rejects the product's proof (reason %d)" % reason.value
