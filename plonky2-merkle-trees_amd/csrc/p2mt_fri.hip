@@ -67,7 +67,8 @@ static_assert(sizeof(ChState) == 8 * (12 + 8 + 8) + 8, "layout shared with p2mt_
 
 // Observe obs[0..n_obs), then squeeze n_sq challenges into sq.  One wavefront; lane w < 12 owns sponge word w.
 __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, const u64* __restrict__ obs, u32 n_obs,
-                                                   u64* __restrict__ sq, u32 n_sq, u32 fresh, PermCtx ctx) {
+                                                   u64* __restrict__ sq, u32 n_sq, u32 fresh, ChState* __restrict__ save_to,
+                                                   unsigned long long* __restrict__ init_wit, PermCtx ctx) {
   __shared__ u64 s_in[8], s_out[8];
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
@@ -142,6 +143,20 @@ __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, con
     st->n_in = n_in;
     st->n_out = n_out;
   }
+  // optional extras of the FRI prover, folded in to save two launches: a copy of the updated transcript (rolled back to if
+  // a proof-of-work chunk finds no witness) and the "no witness yet" marker
+  if (save_to) {
+    if (lane < 12) save_to->state[lane] = gl::canon(x);
+    if (lane < 8) {
+      save_to->in[lane] = s_in[lane];
+      save_to->out[lane] = s_out[lane];
+    }
+    if (lane == 0) {
+      save_to->n_in = n_in;
+      save_to->n_out = n_out;
+    }
+  }
+  if (init_wit && lane == 0) *init_wit = ~0ull;
 }
 
 // fri_proof_of_work: candidate = base + gid goes where the next observed element would; the response is the first
@@ -438,10 +453,11 @@ size_t digests_count(size_t rows, unsigned cap_height) {
   return c;
 }
 
-int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, size_t n_sq, bool fresh = false) {
+int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, size_t n_sq, bool fresh = false,
+                      ChState* save_to = nullptr, unsigned long long* init_wit = nullptr) {
   if (n_obs > 0xFFFFFFFFull || n_sq > 0xFFFFFFFFull) return p2mt::fail(P2MT_EINVAL, "challenger: too many elements");
   hipLaunchKernelGGL(k_challenger, dim3(1), dim3(64), 0, rt().stream, st, d_obs, (u32)n_obs, d_sq, (u32)n_sq, fresh ? 1u : 0u,
-                     p2mt::perm_ctx());
+                     save_to, init_wit, p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
@@ -751,7 +767,18 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
       for (size_t j = 0; j < batches[b].n_polys; ++j)
         h_ptrs[k++] = oracles[batches[b].polys[2 * j]].coeffs + (size_t)batches[b].polys[2 * j + 1] * n;
   }
-  P2MT_HIP(hipMemcpyAsync(ws + o_ptrs, h_ptrs.data(), total_cnt * 8, hipMemcpyHostToDevice, st));
+  {  // the table is the same for every proof of a circuit: upload it only when it (or its place in the scratch) changed
+    thread_local std::vector<const u64*> last_ptrs;
+    thread_local const u64* last_dst = nullptr;
+    thread_local uint64_t last_epoch = ~0ull;
+    if (last_dst != ws + o_ptrs || last_epoch != p2mt::scratch_epoch() || last_ptrs != h_ptrs) {
+      P2MT_HIP(hipMemcpyAsync(ws + o_ptrs, h_ptrs.data(), total_cnt * 8, hipMemcpyHostToDevice, st));
+      P2MT_HIP(hipStreamSynchronize(st));  // pageable source; rare
+      last_ptrs = h_ptrs;
+      last_dst = ws + o_ptrs;
+      last_epoch = p2mt::scratch_epoch();
+    }
+  }
   {
     size_t k = 0;
     for (size_t b = 0; b < n_batches; ++b) {
@@ -814,7 +841,9 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
   // final polynomial -> proof words, observe
   hipLaunchKernelGGL(k_fri_pairs, dim3(grid_for(final_len)), dim3(kBlock), 0, st, (const u64*)cur, (u32)final_len, d_proof + off_final);
   P2MT_LAUNCH_CHECK();
-  P2MT_TRY(launch_challenger(ch->d, d_proof + off_final, 2 * final_len, nullptr, 0));
+  // (the same launch keeps a copy of the transcript for the proof-of-work rollback and marks "no witness yet")
+  P2MT_TRY(launch_challenger(ch->d, d_proof + off_final, 2 * final_len, nullptr, 0, false,
+                             reinterpret_cast<ChState*>(ws + o_chsave), reinterpret_cast<unsigned long long*>(d_proof + total - 1)));
 
   // ---- fri_proof_of_work (smallest witness, searched in chunks) + fri_prover_query_rounds.
   // The rest of the proof is enqueued behind each chunk's grind on the assumption that it finds a witness (it does with
@@ -827,8 +856,7 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
     unsigned long long found = ~0ull;
     for (u64 base = 0;; base += chunk) {
       if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
-      P2MT_HIP(hipMemsetAsync(d_wit, 0xFF, 8, st));
-      P2MT_HIP(hipMemcpyAsync(d_saved, ch->d, sizeof(ChState), hipMemcpyDeviceToDevice, st));
+      if (base != 0) P2MT_HIP(hipMemsetAsync(d_wit, 0xFF, 8, st));  // first chunk: marked by the launch above
       if (rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput) {
         hipLaunchKernelGGL(k_fri_pow_quad, dim3(grid_for(4 * chunk)), dim3(kBlock), 0, st, (const ChState*)ch->d,
                            (u32)p->proof_of_work_bits, base, chunk, d_wit, p2mt::perm_ctx());

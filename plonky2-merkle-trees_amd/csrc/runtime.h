@@ -62,6 +62,7 @@ inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ul
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
 enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCircuit, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
+uint64_t scratch_epoch();  // changes whenever this thread's scratch buffers were (re)allocated or freed: content caches key on it
 void scratch_release_thread();  // frees the calling thread's scratch (threads that end must call it)
 
 // RAII: run a scope on another stream, restore the library stream afterwards

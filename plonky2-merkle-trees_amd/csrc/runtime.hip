@@ -38,7 +38,10 @@ int fail(int code, const char* msg) {
 namespace {
 thread_local void* tl_scratch_ptr[kScratchCount] = {};  // per thread: concurrent provers must not share scratch
 thread_local size_t tl_scratch_cap[kScratchCount] = {};
+thread_local uint64_t tl_scratch_epoch = 0;  // bumped whenever a scratch buffer of this thread is (re)allocated or freed
 }  // namespace
+
+uint64_t scratch_epoch() { return tl_scratch_epoch; }
 
 int scratch_get(int slot, size_t bytes, void** out) {
   void** ptr = tl_scratch_ptr;
@@ -52,6 +55,7 @@ int scratch_get(int slot, size_t bytes, void** out) {
       cap[slot] = 0;
     }
     const size_t want = bytes + bytes / 4;
+    ++tl_scratch_epoch;
     if (hipMalloc(&ptr[slot], want) != hipSuccess) {
       (void)hipGetLastError();
       return fail(P2MT_ENOMEM, "hipMalloc(scratch) failed");
@@ -65,6 +69,7 @@ int scratch_get(int slot, size_t bytes, void** out) {
 // free the calling thread's scratch buffers (worker threads call it before they exit)
 void scratch_release_thread() {
   (void)hipStreamSynchronize(rt().stream);
+  ++tl_scratch_epoch;
   for (int k = 0; k < kScratchCount; ++k) {
     if (tl_scratch_ptr[k]) (void)hipFree(tl_scratch_ptr[k]);
     tl_scratch_ptr[k] = nullptr;
