@@ -1554,10 +1554,9 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   P2MT_TRY(p2mt_challenger_observe_dev(c->ch, c->d_open, 2 * n_open));
   hipLaunchKernelGGL(k_opening_set, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs);
   P2MT_LAUNCH_CHECK();
-  P2MT_TRY(p2mt_fri_prove_openings_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri));
-  // the error flags sit right behind the proof words: one copy brings both back
-  P2MT_HIP(hipMemcpyAsync(c->h_pin + 8, d_proof, (c->proof_len + 1) * 8, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipStreamSynchronize(st));
+  // the proof (with the error flags right behind it) rides back on the FRI prover's own final synchronisation
+  P2MT_TRY(p2mt::fri_prove_openings_epilogue_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri, c->h_pin + 8, d_proof,
+                                                 (c->proof_len + 1) * 8));
   std::copy(c->h_pin + 8, c->h_pin + 8 + c->proof_len, proof_out);
   int err[2];
   memcpy(err, c->h_pin + 8 + c->proof_len, sizeof err);

@@ -703,6 +703,14 @@ extern "C" size_t p2mt_fri_proof_len(const p2mt_fri_params* p, size_t n_oracles,
 extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                            size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch,
                                            uint64_t* d_proof) {
+  return p2mt::fri_prove_openings_epilogue_dev(oracles, n_oracles, batches, n_batches, p, ch, d_proof, nullptr, nullptr, 0);
+}
+
+// The same with a device-to-host copy enqueued behind the speculative tail of the proof, in front of the synchronisation
+// that reads the proof-of-work result: the caller's proof comes back with that one wait (dst is valid when this returns 0).
+int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                          size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch, uint64_t* d_proof,
+                                          void* epi_dst, const void* epi_src, size_t epi_bytes) {
   P2MT_TRY(p2mt::ensure_init());
   if (!oracles || !batches || !ch || !d_proof || n_oracles == 0 || n_batches == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
   if (!params_ok(p)) return p2mt::fail(P2MT_EINVAL, "fri: unsupported FriParams (degree_bits <= 12, arity_bits in 1..4, layer trees >= cap)");
@@ -872,6 +880,7 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
         P2MT_LAUNCH_CHECK();
       }
       P2MT_HIP(hipMemcpyAsync(&found, d_wit, 8, hipMemcpyDeviceToHost, st));
+      if (epi_dst && epi_bytes) P2MT_HIP(hipMemcpyAsync(epi_dst, epi_src, epi_bytes, hipMemcpyDeviceToHost, st));
       P2MT_HIP(hipStreamSynchronize(st));
       if (found != ~0ull) break;
       P2MT_HIP(hipMemcpyAsync(ch->d, d_saved, sizeof(ChState), hipMemcpyDeviceToDevice, st));

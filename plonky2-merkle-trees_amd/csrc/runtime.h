@@ -118,6 +118,10 @@ int partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_sigmas
                                const uint64_t* d_betas, const uint64_t* d_gammas, size_t num_challenges, size_t num_routed,
                                unsigned degree_bits, unsigned chunk, uint64_t* d_q_scratch, uint64_t* d_out, int* d_zero_den);
 
+// exported by p2mt_fri.hip: p2mt_fri_prove_openings_dev + one device-to-host copy that rides on its final synchronisation
+int fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                    size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch, uint64_t* d_proof,
+                                    void* epi_dst, const void* epi_src, size_t epi_bytes);
 // exported by p2mt_verify_host.hip: the field arithmetic of CircuitData::verify (the hashing runs on the device)
 struct VerifyDesc {
   uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, n_kinds;
