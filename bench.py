@@ -26,78 +26,112 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import __graft_entry__ as ge  # noqa: E402
 
 ALGO_BYTES_PER_HASH = 72.0   # 8 B leaf in + 2 x 32 B nodes out per two_to_one, N large
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
-# Integer-issue roofline: VALU instructions per two_to_one of the shipped kernel, from
-# SQ_INSTS_VALU / hashes (profiles/r01_final_*.txt), and the measured gfx950 issue rates
-# (profiles/r01_valu_issue_rates_gfx950.txt): ~2.05 wave-instr/CU/ns for v_mad_u64_u32-class ops, ~4.0 for
-# add/sub/xor/mov.  The 85 % / 15 % mix of the kernel predicts ~2.3; the best rate any of our kernels sustains in situ is
-# 2.33 (verify_batch: 24 chained two_to_one per lane, 2.35 G hashes/s), so 2.4 wave-instr/CU/ns is used as the roof.
-VALU_INSTR_PER_HASH = 16190.0
-ISSUE_PEAK_WAVE_INSTR_PER_S = 256 * 2.4e9
-# HBM bytes of ONE stage-1 launch (tile_log 10, 2^24 leaves) from the PMC passes in
-# profiles/r01_final_mmr_build_2p24.txt: FETCH_SIZE 75.0 MB x2 (gfx950 streaming-read correction) + WRITE_SIZE 1346.9 MB.
-# Counters cannot be read live from inside the process, so this is the committed measurement; it is reported only
-# for the configuration it was measured on.
-# k_mmr_subtree: FETCH_SIZE 444.8 MB raw (889.5 MB with the x2 correction, which is calibrated for coalesced streams only;
-# the leaf reads here are lane-strided) + WRITE_SIZE 1288.4 MB.  k_mmr_tile (P2MT_SUBTREE=0): 150.1 + 1346.9 MB.
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = {("subtree4", 24): 889.5e6 + 1288.4e6, ("tile10", 24): 150.1e6 + 1346.9e6}
+# Counter-derived facts about the dominant kernel cannot be read live from inside the process (PMC passes are separate
+# rocprofv3 runs): they come from the committed summary of those passes, keyed by kernel configuration, and are reported only
+# for the configuration they were measured on.  profiles/README.md says how the file is produced.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
+
+
+def pmc_summary(key):
+    try:
+        with open(PMC_SUMMARY) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
 
 
 def splitmix_leaves(n, seed):
-    from conftest import splitmix_leaves as f
-    return f(n, seed)
+    return ge.load_package().synthetic.splitmix_leaves(n, seed)
 
 
-def cpu_baseline_mmr(target_seconds=12.0, max_log=22):
-    """Oracle (C restatement, `for leaf { add_leaf }`, 1 thread) on a bounded sample of the same workload."""
-    from oracle_lib import Oracle
-    o = Oracle()
-    log_n = 16
-    leaves = splitmix_leaves(1 << log_n, 0x5EED0000 + 24)
+def _oracle():
+    """tests/oracle_lib.py is the ctypes binding of oracle/: imported by the cpu_baseline / parity legs only."""
+    tests_dir = os.path.join(ROOT, "tests")
+    if tests_dir not in sys.path:
+        sys.path.insert(0, tests_dir)
+    import oracle_lib
+    return oracle_lib
+
+
+def cpu_baseline_mmr(host_leaves, gpu_elements_sha256, gpu_root, sample_log=20, fast_log=22):
+    """CPU legs on the bench input itself (rank 0's leaves), bounded to ~30 s of CPU work:
+      B1   oracle/mmr.c `for leaf { add_leaf }` on the spec-form port, 1 thread, first 2^sample_log leaves (faithful: the
+           reference is single-threaded; this is `value`), extrapolation to the full size stated;
+      B1'  port_fast: the same loop on the tuned scalar port (oracle/poseidon_fast.c, -O3 -march=native built here), 1 thread,
+           first 2^fast_log leaves;
+      B2   all_cores: level-order OpenMP build of ALL leaves with the tuned port -- also the full-size parity check: its root
+           and the SHA-256 of its node array must equal the GPU's (and the spec-form port's all-core build must agree)."""
+    import hashlib
+    ol = _oracle()
+    o = ol.Oracle()
+    n = host_leaves.size
+    sample_log, fast_log = min(sample_log, n.bit_length() - 1), min(fast_log, n.bit_length() - 1)
     t0 = time.perf_counter()
-    m = o.mmr(leaves)
+    m = o.mmr(host_leaves[:1 << sample_log])
     dt = time.perf_counter() - t0
-    rate = ((1 << log_n) - 1) / dt
-    while log_n < max_log and (2 << log_n) / rate < target_seconds:
-        log_n += 1
-    leaves = splitmix_leaves(1 << log_n, 0x5EED0000 + 24)
+    hashes = (1 << sample_log) - 1
+    b1_root = m.bagging_the_peaks()
+    fast = ol.build_fast_port_native()
     t0 = time.perf_counter()
-    m = o.mmr(leaves)
-    dt = time.perf_counter() - t0
-    hashes = (1 << log_n) - 1
-    # B2 (BASELINE.md): "generous" all-core, level-parallel build of the same array (not the reference's algorithm)
-    # The host may expose far more hardware threads than its CPU quota lets run (observed: 256 visible, ~16 cores'
-    # worth of throughput), so the thread count is calibrated on a small build and the best one is used.
-    el = np.empty((2 * leaves.size - 1, 4), np.uint64)
-    cal = leaves[:1 << 17]
+    el_fast = o.fast_mmr_add_leaf_loop(host_leaves[:1 << fast_log], lib=fast)
+    dt_fast = time.perf_counter() - t0
+    fast_root = el_fast[-1].copy()
+    del el_fast
+    # thread count: the host may expose far more hardware threads than its CPU quota lets run (observed: 256 visible, ~16
+    # cores' worth of throughput), so it is calibrated on a small build
+    el = np.empty((2 * n - 1, 4), np.uint64)
+    cal = host_leaves[:1 << 17]
     best_t, best_rate = 1, 0.0
     for t in sorted({t for t in (8, 16, 32, 64, 128, os.cpu_count() or 1) if t <= (os.cpu_count() or 1)}):
         t0 = time.perf_counter()
-        o.mmr_build_pow2_parallel(cal, t, el[:2 * cal.size - 1])
+        o.fast_mmr_build_pow2(cal, t, el[:2 * cal.size - 1], lib=fast)
         r = cal.size / (time.perf_counter() - t0)
         if r > best_rate:
             best_t, best_rate = t, r
     t0 = time.perf_counter()
-    el, threads = o.mmr_build_pow2_parallel(leaves, best_t, el)
+    el, threads = o.fast_mmr_build_pow2(host_leaves, best_t, el, lib=fast)
     dt2 = time.perf_counter() - t0
-    assert np.array_equal(el[-1], m.bagging_the_peaks())
+    cpu_sha = hashlib.sha256(el.tobytes()).hexdigest()
+    cpu_root = el[-1].copy()
+    t0 = time.perf_counter()
+    el, _ = o.mmr_build_pow2_parallel(host_leaves, best_t, el)  # the pinned spec-form restatement, same array
+    dt_spec = time.perf_counter() - t0
+    spec_sha = hashlib.sha256(el.tobytes()).hexdigest()
+    parity = {"size_log2": n.bit_length() - 1, "root_equal": bool(np.array_equal(cpu_root, gpu_root)),
+              "elements_sha256_gpu": gpu_elements_sha256, "elements_sha256_oracle": spec_sha,
+              "elements_sha256_equal": spec_sha == gpu_elements_sha256 and cpu_sha == gpu_elements_sha256,
+              "oracle": "oracle_mmr_build_pow2_parallel (spec-form port, %d threads, %.1f s) and the tuned port's build" % (threads, dt_spec)}
     return {"value": hashes / dt, "unit": "Poseidon hashes/s", "cores": 1, "kind": "port",
-            "sample": "oracle/mmr.c add_leaf loop (B1, faithful: the reference is single-threaded), first 2^%d "
-                      "leaves of the bench input, %.1f s" % (log_n, dt),
-            "all_cores": {"value": hashes / dt2, "cores": threads, "seconds": dt2,
-                          "what": "B2: level-parallel OpenMP build of the same node array (generous, not the "
-                                  "reference's algorithm)"},
-            "_root": m.bagging_the_peaks(), "_log_n": log_n}
+            "sample": "oracle/mmr.c add_leaf loop (B1, faithful: the reference is single-threaded), first 2^%d leaves of the "
+                      "bench input, %.1f s; at this rate the full 2^%d-leaf build would take %.0f s"
+                      % (sample_log, dt, n.bit_length() - 1, (n - 1) / (hashes / dt)),
+            "port_fast": {"value": ((1 << fast_log) - 1) / dt_fast, "cores": 1, "seconds": dt_fast,
+                          "what": "B1': the same add_leaf loop on the tuned scalar port (oracle/poseidon_fast.c: sparse partial "
+                                  "rounds, lazy reduction, gcc -O3 -march=native on this host), first 2^%d leaves" % fast_log},
+            "all_cores": {"value": (n - 1) / dt2, "cores": threads, "seconds": dt2,
+                          "what": "B2: level-order OpenMP build of ALL 2^%d leaves with the tuned port (generous, not the "
+                                  "reference's algorithm)" % (n.bit_length() - 1)},
+            "full_size_parity": parity,
+            "_roots": (b1_root, fast_root, sample_log, fast_log)}
 
 
 def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
-    n = 1 << args.log_leaves
-    host_leaves = splitmix_leaves(n, 0x5EED0000 + 24 + 1000 * rank)
+    # weak: every rank builds its own 2^log_leaves shard (per-GPU work fixed); strong: 2^log_leaves leaves in total, split
+    # into world leaf ranges (BASELINE.json's "2^24 leaves at 1/2/4/8 GPUs"; config 5 = --scaling strong --log-leaves 26 --gpus 8
+    # or, equivalently, --scaling weak --log-leaves 23 --gpus 8)
+    g = world.bit_length() - 1
+    if world & (world - 1):
+        raise SystemExit("--gpus must be a power of two (perfect subtrees per rank)")
+    local_log = args.log_leaves - g if args.scaling == "strong" else args.log_leaves
+    if local_log < 1:
+        raise SystemExit("--log-leaves too small for %d ranks" % world)
+    n = 1 << local_log
+    host_leaves = pkg.synthetic.bench_leaves(local_log, rank)
     d_leaves = torch.from_numpy(host_leaves.view(np.int64)).cuda()
     shard = pkg.ShardedMMR(pkg, n, rank, world, dist)
 
@@ -138,65 +172,64 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
         return None
     mds, partial = C.c_int(), C.c_int()
     lib.p2mt_get_variant(C.byref(mds), C.byref(partial))
-    tile_log = int(os.environ.get("P2MT_TILE_LOG", "10"))
-    subtree = int(os.environ.get("P2MT_SUBTREE", "4"))
-    # dominant kernel = stage 1: per-lane subtrees (levels 1..4 of every 16-leaf block, default) or, with
-    # P2MT_SUBTREE=0, the fused LDS tile kernel (levels 1 .. tile_log-6 of every 2^tile_log-leaf tile)
-    fused_levels = subtree if subtree in (4, 5) else tile_log - 6
-    stage1 = ("k_mmr_subtree (stage 1: each lane builds levels 1..%d of its own 2^%d leaves)" % (fused_levels, fused_levels)
-              if subtree in (4, 5) else
-              "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (fused_levels, tile_log))
-    # (with the chunked two-stream build there are several stage-1 launches per step; hashes are split evenly)
+    info = pkg.stage1_info()
+    fused_levels = info["levels"]
+    # (hashes are split evenly over the stage-1 launches of a step)
     launches_per_step = max(kern_n.value, 1) / float(args.steps)
     hashes_in_launch = (n - (n >> fused_levels)) / launches_per_step
     launch_ms = kern_ms.value / max(kern_n.value, 1)
     algo_bytes = hashes_in_launch * ALGO_BYTES_PER_HASH
     achieved_gbs = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     in_kernel_rate = hashes_in_launch / (launch_ms * 1e-3) if launch_ms > 0 else 0.0
+    pmc = pmc_summary("%s@2^%d" % (info["key"], local_log)) or {}
+    total_log = local_log + g
     out = {
-        "metric": "Poseidon hashes/s (MMR build, 2^%d leaves per GPU)" % args.log_leaves,
+        "metric": "Poseidon hashes/s (MMR build, 2^%d leaves%s)" % (args.log_leaves, " per GPU" if args.scaling == "weak" else " in total"),
         "value": value, "unit": "Poseidon hashes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64 (Goldilocks, integer VALU)", "data": "synthetic",
-        "config": {"workload": "mmr::merkle_mountain_ranges build, 2^%d leaves per GPU, device-resident leaves"
-                               % args.log_leaves,
-                   "leaves_per_gpu": n, "hashes_per_step": total_hashes,
+        "config": {"workload": "mmr::merkle_mountain_ranges build of one 2^%d-leaf MMR: 2^%d leaves per GPU x %d GPU(s) (%s "
+                               "scaling), device-resident leaves" % (total_log, local_log, world, args.scaling),
+                   "leaves_per_gpu": n, "total_leaves": n * world, "hashes_per_step": total_hashes,
                    "poseidon_variant": {"mds": mds.value, "partial": partial.value},
-                   "stage1": "subtree%d" % subtree if subtree in (4, 5) else "tile%d" % tile_log,
+                   "stage1": info["key"],
                    "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS,
-                     "traffic": (MEASURED_TRAFFIC_BYTES_PER_LAUNCH.get(("subtree%d" % subtree if subtree in (4, 5)
-                                                                        else "tile%d" % tile_log, args.log_leaves)) or 0)
-                     / launches_per_step or None,
-                     "kernel": stage1,
+                     "traffic": pmc.get("hbm_bytes_per_launch"),
+                     "kernel": info["kernel"],
                      "launch_ms": launch_ms, "launches_timed": kern_n.value,
                      "algorithmic_bytes_per_launch": algo_bytes, "hashes_per_launch": hashes_in_launch,
-                     "note": "Poseidon is integer-issue bound (see issue_roofline): ~16k VALU instructions per "
-                             "72 algorithmic bytes, so the HBM fraction is ~1-2 % by construction (SURVEY.md 8d)"},
-        "issue_roofline": {"bound": "valu-issue", "unit": "wave-instr/s",
-                           "achieved": in_kernel_rate * VALU_INSTR_PER_HASH / 64.0,
-                           "peak": ISSUE_PEAK_WAVE_INSTR_PER_S,
-                           "frac": in_kernel_rate * VALU_INSTR_PER_HASH / 64.0 / ISSUE_PEAK_WAVE_INSTR_PER_S,
-                           "valu_instr_per_hash": VALU_INSTR_PER_HASH, "in_kernel_hashes_per_s": in_kernel_rate},
+                     "note": "Poseidon is integer-issue bound (see `valu`): ~15-16k VALU instructions per 72 algorithmic "
+                             "bytes, so the HBM fraction is ~2 % by construction (SURVEY.md 8d)"},
+        # counter evidence for "compute-bound, the right way": share of SIMD issue cycles spent on VALU instructions and VALU
+        # instructions per hash, from the committed PMC passes (null when this configuration was not profiled)
+        "valu": {"valu_busy": pmc.get("valu_busy"), "valu_instr_per_hash": pmc.get("valu_instr_per_hash"),
+                 "source": pmc.get("source"), "in_kernel_hashes_per_s": in_kernel_rate},
         "device_ms_per_step": region_ms.value / args.steps,
         "root": [int(x) for x in root],
     }
     if world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline_mmr()
-        # parity check of the sample: GPU build of the same prefix must give the oracle's root
-        sub = pkg.MMR.from_leaves(host_leaves[:1 << cb["_log_n"]])
-        assert np.array_equal(sub.bagging_the_peaks(), cb["_root"]), "GPU root != oracle root on the CPU sample"
-        cb = {k: v for k, v in cb.items() if not k.startswith("_")}
+        import hashlib
+        gpu_sha = hashlib.sha256(shard.local.elements.tobytes()).hexdigest()
+        cb = cpu_baseline_mmr(host_leaves, gpu_sha, root)
+        assert cb["full_size_parity"]["root_equal"] and cb["full_size_parity"]["elements_sha256_equal"], \
+            "GPU MMR != oracle at the full bench size: %r" % (cb["full_size_parity"],)
+        b1_root, fast_root, sample_log, fast_log = cb.pop("_roots")
+        # the bounded samples are prefixes of the same input: the GPU build of each prefix must give the port's root
+        for r_cpu, lg in ((b1_root, sample_log), (fast_root, fast_log)):
+            sub = pkg.MMR.from_leaves(host_leaves[:1 << lg])
+            assert np.array_equal(sub.bagging_the_peaks(), r_cpu), "GPU root != oracle root on the 2^%d CPU sample" % lg
         cb["gpu_over_cpu"] = value / cb["value"]
+        cb["port_fast"]["gpu_over_cpu"] = value / cb["port_fast"]["value"]
         cb["all_cores"]["gpu_over_cpu"] = value / cb["all_cores"]["value"]
         out["cpu_baseline"] = cb
     if world == 1 and not args.no_prove:
-        # BASELINE.json's second metric (ms/proof mmr_plonky2_verifier), measured after and outside the timed region above
+        # BASELINE.json's second metric (ms/proof), measured after and outside the timed region above
+        import copy
+        pa = copy.copy(args)
+        pa.steps, pa.warmup = 30, 5
         try:
-            import copy
-            pa = copy.copy(args)
-            pa.steps, pa.warmup = 30, 5
             pr = run_prove(pa, torch, pkg, lib, cpu_seconds=3.0)
             out["ms_per_proof_mmr_plonky2_verifier"] = {
                 "value": pr["value"], "unit": "ms", "config": pr["config"]["workload"],
@@ -246,8 +279,7 @@ def run_commit(args, torch, pkg, lib):
         entry = {"ms_per_proof_commit_phase": ms, "lde_kernels_ms": lde_ms,
                  "lde_algorithmic_GBps": lde_bytes / (lde_ms * 1e-3) / 1e9 if lde_ms > 0 else None}
         if not args.no_cpu_baseline:
-            from oracle_lib import Oracle
-            o = Oracle()
+            o = _oracle().Oracle()
             t0 = time.perf_counter()
             caps = [o.polynomial_batch_commit(host, is_values, 3, 4)[2] for _, host, _, is_values in bufs]
             entry["cpu_port_ms_1core"] = (time.perf_counter() - t0) * 1e3
@@ -335,8 +367,7 @@ def run_fri(args, torch, pkg, lib):
         ms = (time.perf_counter() - t0) * 1e3 / args.steps
         entry = {"ms_per_opening_proof": ms, "proof_words": int(total), "pow_witness": int(d_proof[-1].item())}
         if not args.no_cpu_baseline and log_n <= 12:
-            from oracle_lib import Oracle
-            o = Oracle()
+            o = _oracle().Oracle()
             op = o.fri_params_standard(log_n)
             ooracles = [(h, d_l.cpu().numpy().view(np.uint64).reshape(big, w), d_d.cpu().numpy().view(np.uint64).reshape(-1, 4))
                         for h, (_, d_l, d_d, _), w in zip(hosts, dev, widths)]
@@ -380,7 +411,7 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
     cd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(len(pr.siblings), len(pr.peaks))
     build_ms = (time.perf_counter() - t0) * 1e3
     case = (int(leaves[idx]), pr.siblings, pr.lefts, pr.peaks, root)
-    from circuit_cases import assign
+    assign = pkg.synthetic.assign_mmr_proof
     pw = pkg.PartialWitness()
     assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, case, pw.set_target)
     proof = np.zeros(cd.info.proof_len, np.uint64)
@@ -449,9 +480,8 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
         except Exception:
             out["throughput"] = {"error": (r.stdout + r.stderr)[-400:]}
     if not args.no_cpu_baseline:
-        from oracle_lib import Oracle
         from oracle import circuit as OC
-        o = Oracle()
+        o = _oracle().Oracle()
         ocd, oleaf, oproof_ts, opeak_ts = OC.verify_mmr_proof_circuit(o, len(pr.siblings), len(pr.peaks))
         opw = {}
         assign(oleaf, oproof_ts, opeak_ts, ocd.public_inputs, case, opw.__setitem__)
@@ -474,7 +504,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-leaves", type=int, default=24, help="leaves per GPU = 2^this")
+    ap.add_argument("--log-leaves", type=int, default=24,
+                    help="2^this leaves per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", default=os.environ.get("P2MT_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="weak (default): per-GPU work fixed, every rank builds a 2^log_leaves shard of one 2^(log_leaves+log2 N)-leaf "
+                         "MMR; strong: one 2^log_leaves-leaf MMR split over the ranks (BASELINE's 2^24 at 1/2/4/8 GPUs).  "
+                         "Config 5 (2^26 over 8 GPUs): --gpus 8 --log-leaves 23, or --scaling strong --log-leaves 26.")
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
     ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -68,8 +68,15 @@ const char *p2mt_last_error(void);
  * All variants are bit-identical. */
 int p2mt_set_variant(int mds, int partial);
 int p2mt_get_variant(int *mds, int *partial);
+/* Which stage-1 kernel an MMR build uses with the current variant / environment: subtree_levels = 4|5 -> k_mmr_subtree (each lane
+ * builds levels 1..subtree_levels of its own leaves), 0 -> k_mmr_tile over 2^tile_log-leaf tiles.  (bench.py labels its roofline
+ * with it.) */
+int p2mt_get_build_config(int *subtree_levels, int *tile_log, int *subtree_block);
 /* Debug/test knob: make every wave of the mds=2 path take its exact fallback (results must not change). */
 int p2mt_debug_force_fallback(int on);
+/* Test hook: the next `n` device allocations made while growing an MMR handle report P2MT_ENOMEM (fault injection: a failed
+ * flush / extend must leave len(), num_leaves() and every later root or proof consistent, and must be retryable). */
+int p2mt_debug_fail_allocs(int n);
 /* Test hook: run one Goldilocks primitive of the device code on caller-supplied operands (host pointers).
  * op 0: exact reduce of the 128-bit value a[i] + b[i]*2^64;  op 1: exact fold of (b[i] & 0x3FF)*2^64 + a[i];
  * op 2: flag-form reduce (poseidon_fast::reduce128): out = value, flag_out[i] = 1 if the lane raised the sticky flag
@@ -214,6 +221,14 @@ int p2mt_merkle_cap_commit(const uint64_t *leaves, size_t n, size_t width, unsig
                            uint64_t *digests_out, uint64_t *cap_out);
 int p2mt_merkle_cap_commit_dev(const uint64_t *d_leaves, size_t n, size_t width, unsigned cap_height,
                                uint64_t *d_digests_out, uint64_t *d_cap_out);
+/* plonky2's own `MerkleTree.digests` order from the level-major digests the calls above and below return: per cap subtree the
+ * recursive "left subtree || left child || right child || right subtree" order of hash/merkle_tree.rs fill_subtree (SURVEY.md
+ * App. B.4) -- pair q of layer i at pair position (q << (i+1)) + 2^i - 1, which is how MerkleTree::prove indexes it -- so that a
+ * patched PolynomialBatch::from_values / MerkleTree::new can fill MerkleTree { leaves, digests, cap } with one copy and no
+ * re-indexing.  level_major / out: 2 * (n_leaves - 2^cap_height) HashOuts; out must not alias the input. */
+int p2mt_merkle_digests_to_plonky2_layout(const uint64_t *level_major, size_t n_leaves, unsigned cap_height, uint64_t *out);
+int p2mt_merkle_digests_to_plonky2_layout_dev(const uint64_t *d_level_major, size_t n_leaves, unsigned cap_height,
+                                              uint64_t *d_out);
 /* PolynomialBatch::from_values (is_values = 1) / from_coeffs (0).  leaves_out: [2^(log_n+rate_bits)][n_polys],
  * leaf index bit-reversed; digests_out/cap_out as above.  Any output pointer may be NULL except cap_out. */
 int p2mt_polynomial_batch_commit(const uint64_t *polys /*[n_polys][2^log_n]*/, int is_values, size_t n_polys,

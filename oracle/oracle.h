@@ -79,6 +79,11 @@ void oracle_mmr_add_leaves(oracle_mmr *m, const uint64_t *leaves, size_t n); /* 
 /* BASELINE.md B2 ("generous" CPU baseline, NOT the reference's algorithm): the same post-order array for n = 2^k
  * leaves built level by level with every host core (OpenMP).  Returns the number of threads used. */
 int oracle_mmr_build_pow2_parallel(const uint64_t *leaves, size_t n, uint64_t *elements_out, int threads /* 0 = all */);
+/* Tuned scalar port (poseidon_fast.c: sparse partial rounds, lazy reduction; bench.py's cpu_baseline.port_fast).  Same values. */
+void oracle_fast_poseidon_permute(uint64_t state[12]);
+void oracle_fast_two_to_one_batch(const uint64_t *in /*[n][8]*/, uint64_t *out /*[n][4]*/, size_t n);
+void oracle_fast_mmr_add_leaf_loop(const uint64_t *leaves, size_t n, uint64_t *elements_out); /* for leaf { add_leaf }, 1 thread */
+int oracle_fast_mmr_build_pow2(const uint64_t *leaves, size_t n, uint64_t *elements_out, int threads /* 0 = all */);
 size_t oracle_mmr_len(const oracle_mmr *m);
 const uint64_t *oracle_mmr_elements(const oracle_mmr *m);
 /* returns number of peaks, -1 where the reference panics (empty MMR / len >= 2^32) */

@@ -10,7 +10,7 @@ from ._native import P2mtError, P2mtPanic, lib
 from .hashing import (poseidon_gate_witness_batch, hash_no_pad, hash_no_pad_batch, hash_or_noop, hash_or_noop_batch, poseidon_permute_batch,
                       two_to_one, two_to_one_batch)
 from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_batch
-from . import circuit, commit, distributed, fri, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion, plonk
+from . import circuit, commit, distributed, fri, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion, plonk, synthetic
 from .circuit import CircuitBuilder, CircuitData, PartialWitness, prove_many
 from .mmr_plonky2_verifier import verify_mmr_proof_circuit
 from .mmr_plonky2_verifier_1_recursion import verify_inner_merkle_proof_circuit
@@ -33,3 +33,16 @@ def set_variant(mds, partial):
 
 def device_count():
     return lib().p2mt_device_count()
+
+
+def stage1_info():
+    """The dominant launch of an MMR build under the current variant / environment knobs (for bench.py's roofline label)."""
+    import ctypes as C
+    sub, tile, blk = C.c_int(), C.c_int(), C.c_int()
+    _native.check(lib().p2mt_get_build_config(C.byref(sub), C.byref(tile), C.byref(blk)))
+    if sub.value in (4, 5):
+        return {"key": "subtree%d" % sub.value, "levels": sub.value,
+                "kernel": "k_mmr_subtree (stage 1: each lane builds levels 1..%d of its own 2^%d leaves)" % (sub.value, sub.value)}
+    lv = tile.value - 6
+    return {"key": "tile%d" % tile.value, "levels": lv,
+            "kernel": "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (lv, tile.value)}

@@ -34,7 +34,9 @@ SIGNATURES = {
     "p2mt_last_error": (C.c_char_p, []),
     "p2mt_set_variant": (C.c_int, [C.c_int, C.c_int]),
     "p2mt_get_variant": (C.c_int, [intp, intp]),
+    "p2mt_get_build_config": (C.c_int, [intp, intp, intp]),
     "p2mt_debug_force_fallback": (C.c_int, [C.c_int]),
+    "p2mt_debug_fail_allocs": (C.c_int, [C.c_int]),
     "p2mt_debug_field_op": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp, voidp]),
     "p2mt_profile_enable": (C.c_int, [C.c_int]),
     "p2mt_profile_read": (C.c_int, [C.POINTER(C.c_float), intp]),
@@ -90,6 +92,8 @@ SIGNATURES = {
     "p2mt_coset_lde_batch_dev": (C.c_int, [voidp, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t, voidp]),
     "p2mt_merkle_cap_commit": (C.c_int, [voidp, C.c_size_t, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_merkle_cap_commit_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, C.c_uint, voidp, voidp]),
+    "p2mt_merkle_digests_to_plonky2_layout": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp]),
+    "p2mt_merkle_digests_to_plonky2_layout_dev": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp]),
     "p2mt_polynomial_batch_commit": (C.c_int, [voidp, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, voidp,
                                                voidp, voidp]),
     "p2mt_polynomial_batch_commit_dev": (C.c_int, [voidp, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, voidp,

@@ -64,6 +64,15 @@ class MerkleCapTree:
         N.check(N.lib().p2mt_merkle_cap_commit(N.ptr(leaves), n, w, cap_height, N.ptr(digests), N.ptr(cap)))
         return MerkleCapTree(leaves, digests[:nd], cap, cap_height)
 
+    def plonky2_digests(self):
+        """`MerkleTree.digests` in plonky2's own order (hash/merkle_tree.rs fill_subtree: per cap subtree, recursively, left
+        subtree || left child || right child || right subtree), converted on the device from the level-major array."""
+        nd = self.digests.shape[0]
+        out = np.zeros((max(nd, 1), 4), np.uint64)
+        lm = N.as_u64(self.digests) if nd else out
+        N.check(N.lib().p2mt_merkle_digests_to_plonky2_layout(N.ptr(lm), self.leaves.shape[0], self.cap_height, N.ptr(out)))
+        return out[:nd]
+
     def prove(self, leaf_index):
         """Merkle path of a leaf up to (excluding) the cap: sibling digests bottom-up."""
         n = self.leaves.shape[0]

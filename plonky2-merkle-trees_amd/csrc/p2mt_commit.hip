@@ -757,6 +757,68 @@ extern "C" int p2mt_merkle_cap_commit(const uint64_t* leaves, size_t n, size_t w
   return P2MT_OK;
 }
 
+// =================================================================== plonky2's MerkleTree { digests } layout
+// hash/merkle_tree.rs (plonky2 @3b21b87, absent) keeps `digests` per cap subtree in the recursive order its
+// fill_subtree writes -- left recursive output || left child digest || right child digest || right recursive output -- i.e. in
+// units of sibling PAIRS: [layer 0, layer 1, layer 0, layer 2, layer 0, layer 1, layer 0, layer 3, ...]; the pair q of layer i
+// sits at pair position (q << (i + 1)) + 2^i - 1 (the formula MerkleTree::prove indexes with).  This library's kernels write
+// `digests` level-major (level 0 = leaf digests); the map below is what a patched PolynomialBatch::from_values needs to fill
+// MerkleTree { leaves, digests, cap } without re-indexing.  One lane per digest, 32-byte records.
+__global__ __launch_bounds__(kBlock) void k_digests_to_plonky2(const u64* __restrict__ level_major, u64* __restrict__ out,
+                                                               unsigned log_n, unsigned cap_height, size_t total) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= total) return;
+  // level of record t: levels have n, n/2, ... entries
+  size_t off = 0, g = t;
+  unsigned lvl = 0;
+  for (; lvl + cap_height < log_n; ++lvl) {
+    const size_t cnt = (size_t)1 << (log_n - lvl);
+    if (g < cnt) break;
+    g -= cnt;
+    off += cnt;
+  }
+  const unsigned sub_log = log_n - cap_height;                    // log2(leaves per cap subtree)
+  const size_t per_sub = ((size_t)2 << sub_log) - 2;              // digests per cap subtree
+  const size_t in_level_per_sub = (size_t)1 << (sub_log - lvl);   // nodes of this level per subtree
+  const size_t sub = g / in_level_per_sub, j = g % in_level_per_sub;
+  const size_t pair_pos = ((j >> 1) << (lvl + 1)) + (((size_t)1 << lvl) - 1);
+  const size_t dst = sub * per_sub + 2 * pair_pos + (j & 1);
+  const ulonglong4 v = reinterpret_cast<const ulonglong4*>(level_major)[t];
+  reinterpret_cast<ulonglong4*>(out)[dst] = v;
+}
+
+extern "C" int p2mt_merkle_digests_to_plonky2_layout_dev(const uint64_t* d_level_major, size_t n_leaves, unsigned cap_height,
+                                                         uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  const int k = log2_strict(n_leaves);
+  if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree: n must be a power of two >= 2^cap_height");
+  const size_t nd = digests_count(n_leaves, cap_height);
+  if (nd == 0) return P2MT_OK;  // the tree is its cap: plonky2's `digests` is empty
+  if (!d_level_major || !d_out || d_level_major == d_out) return p2mt::fail(P2MT_EINVAL, "null or aliasing pointer");
+  hipLaunchKernelGGL(k_digests_to_plonky2, dim3(grid_for(nd)), dim3(kBlock), 0, rt().stream, d_level_major, d_out, (unsigned)k,
+                     cap_height, nd);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_merkle_digests_to_plonky2_layout(const uint64_t* level_major, size_t n_leaves, unsigned cap_height,
+                                                     uint64_t* out) {
+  P2MT_TRY(p2mt::ensure_init());
+  const int k = log2_strict(n_leaves);
+  if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree: n must be a power of two >= 2^cap_height");
+  const size_t nd = digests_count(n_leaves, cap_height);
+  if (nd == 0) return P2MT_OK;
+  if (!level_major || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  DevBuf bi, bo;
+  P2MT_TRY(bi.alloc(nd * 32));
+  P2MT_TRY(bo.alloc(nd * 32));
+  P2MT_HIP(hipMemcpyAsync(bi.p, level_major, nd * 32, hipMemcpyHostToDevice, rt().stream));
+  P2MT_TRY(p2mt_merkle_digests_to_plonky2_layout_dev(bi.as<u64>(), n_leaves, cap_height, bo.as<u64>()));
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, nd * 32, hipMemcpyDeviceToHost, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
+  return P2MT_OK;
+}
+
 // =================================================================== PolynomialBatch::from_values / from_coeffs
 int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_polys, unsigned log_n, unsigned rate_bits,
                            unsigned cap_height, uint64_t* d_coeffs_out, uint64_t* d_lde_out, uint64_t* d_leaves_out,

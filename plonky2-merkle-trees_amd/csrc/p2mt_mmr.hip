@@ -367,12 +367,21 @@ struct p2mt_mmr {
 };
 
 static constexpr size_t kMaxPendingLeaves = (size_t)1 << 20;
+static int mmr_extend_host(p2mt_mmr* m, const uint64_t* leaves, size_t k);
+// The add_leaf queue is dropped only once its leaves are in `elements`: a failed flush (allocation, copy) leaves the queue
+// intact, so n_leaves + pending -- what len() / num_leaves() report -- stays true and the call can simply be retried.
 static int mmr_flush(const p2mt_mmr* cm) {
   p2mt_mmr* m = const_cast<p2mt_mmr*>(cm);  // the queue is an implementation detail of the logical state
   if (!m || m->pending.empty()) return P2MT_OK;
-  std::vector<u64> batch;
-  batch.swap(m->pending);
-  return p2mt_mmr_extend(m, batch.data(), batch.size());
+  P2MT_TRY(mmr_extend_host(m, m->pending.data(), m->pending.size()));
+  m->pending.clear();
+  return P2MT_OK;
+}
+// test hook (p2mt_debug_fail_allocs): the next `n` device allocations made while growing an MMR report out-of-memory
+static int g_fail_allocs = 0;
+extern "C" int p2mt_debug_fail_allocs(int n) {
+  g_fail_allocs = n < 0 ? 0 : n;
+  return P2MT_OK;
 }
 
 static size_t mmr_len_for(size_t n_leaves) { return 2 * n_leaves - (size_t)__builtin_popcountll((unsigned long long)n_leaves); }
@@ -404,22 +413,27 @@ static int mmr_grow(p2mt_mmr* m, size_t need_nodes) {
   size_t cap = m->cap_nodes ? m->cap_nodes : 1024;
   while (cap < need_nodes) cap *= 2;
   if (m->cap_nodes == 0) cap = need_nodes > 1024 ? need_nodes : 1024;  // first allocation: exact (reserve)
-  u64* fresh = nullptr;
-  hipError_t e = hipMalloc((void**)&fresh, cap * 32);
-  if (e != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc failed while growing the MMR");
+  if (g_fail_allocs > 0) {
+    --g_fail_allocs;
+    return p2mt::fail(P2MT_ENOMEM, "hipMalloc failed while growing the MMR (injected by p2mt_debug_fail_allocs)");
+  }
+  DevBuf fresh;  // released on every error path
+  if (fresh.alloc(cap * 32) != P2MT_OK) return p2mt::fail(P2MT_ENOMEM, "hipMalloc failed while growing the MMR");
   const size_t used = mmr_len_for(m->n_leaves);
-  if (used) P2MT_HIP(hipMemcpyAsync(fresh, m->elements, used * 32, hipMemcpyDeviceToDevice, rt().stream));
+  if (used) P2MT_HIP(hipMemcpyAsync(fresh.p, m->elements, used * 32, hipMemcpyDeviceToDevice, rt().stream));
   if (m->elements) {
     P2MT_HIP(hipStreamSynchronize(rt().stream));
     (void)hipFree(m->elements);
   }
-  m->elements = fresh;
+  m->elements = fresh.as<u64>();
+  fresh.p = nullptr;
   m->cap_nodes = cap;
   return P2MT_OK;
 }
 
 extern "C" int p2mt_mmr_reserve(p2mt_mmr* m, size_t n_leaves) {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  if (n_leaves >> 40) return p2mt::fail(P2MT_ERANGE, "MMR too large");
   return mmr_grow(m, 2 * n_leaves);
 }
 
@@ -555,10 +569,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
   return P2MT_OK;
 }
 
-extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
-  P2MT_TRY(p2mt::ensure_init());
-  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
-  P2MT_TRY(mmr_flush(m));  // queued add_leaf calls come first
+static int mmr_extend_dev_noflush(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
   if (k == 0) return P2MT_OK;
   if (!d_leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
   const size_t n0 = m->n_leaves, n1 = n0 + k;
@@ -572,18 +583,32 @@ extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t
   return P2MT_OK;
 }
 
-extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
-  P2MT_TRY(p2mt::ensure_init());
-  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
-  P2MT_TRY(mmr_flush(m));
+// host leaves -> staging buffer -> extend; m->n_leaves moves only when everything was enqueued and the copy completed
+static int mmr_extend_host(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
   if (k == 0) return P2MT_OK;
   if (!leaves) return p2mt::fail(P2MT_EINVAL, "null pointer");
   DevBuf b;
   P2MT_TRY(b.alloc(k * 8));
   P2MT_HIP(hipMemcpyAsync(b.p, leaves, k * 8, hipMemcpyHostToDevice, rt().stream));
-  P2MT_TRY(p2mt_mmr_extend_dev(m, b.as<u64>(), k));
-  P2MT_HIP(hipStreamSynchronize(rt().stream));  // the staging buffer dies with this call
-  return P2MT_OK;
+  const size_t before = m->n_leaves;
+  int rc = mmr_extend_dev_noflush(m, b.as<u64>(), k);
+  if (rc == P2MT_OK && hipStreamSynchronize(rt().stream) != hipSuccess) rc = p2mt::fail(P2MT_EHIP, "hipStreamSynchronize failed in mmr_extend");
+  if (rc != P2MT_OK) m->n_leaves = before;  // the staging buffer dies with this call: nothing half-built stays visible
+  return rc;
+}
+
+extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));  // queued add_leaf calls come first
+  return mmr_extend_dev_noflush(m, d_leaves, k);
+}
+
+extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+  P2MT_TRY(mmr_flush(m));
+  return mmr_extend_host(m, leaves, k);
 }
 
 // (sizes are known without flushing: the queue only adds leaves)
@@ -623,7 +648,12 @@ extern "C" int p2mt_mmr_save(const p2mt_mmr* m, const char* path) {
   if (!m || !path) return p2mt::fail(P2MT_EINVAL, "null argument");
   P2MT_TRY(mmr_flush(m));
   const size_t len = mmr_len_for(m->n_leaves);
-  std::vector<uint64_t> host(4 * len);
+  std::vector<uint64_t> host;
+  try {
+    host.resize(4 * len);
+  } catch (const std::bad_alloc&) {
+    return p2mt::fail(P2MT_ENOMEM, "mmr_save: out of host memory");
+  }
   if (len) P2MT_TRY(p2mt_mmr_copy_elements(m, 0, len, host.data()));
   CkptHeader h;
   memcpy(h.magic, "P2MTMMR1", 8);
@@ -651,21 +681,44 @@ extern "C" int p2mt_mmr_load(p2mt_mmr* m, const char* path) {
     fclose(f);
     return p2mt::fail(P2MT_EINVAL, "mmr_load: header inconsistent (n_elements != 2N - popcount(N))");
   }
-  std::vector<uint64_t> host(4 * h.n_elements);
+  {  // the payload must be exactly 32 * n_elements bytes: checked against the file BEFORE anything of that size is allocated
+    const long at = ftell(f);
+    if (at < 0 || fseek(f, 0, SEEK_END) != 0) {
+      fclose(f);
+      return p2mt::fail(P2MT_EINVAL, "mmr_load: cannot size the file");
+    }
+    const long end = ftell(f);
+    if (end < at || (uint64_t)(end - at) != 32 * h.n_elements || fseek(f, at, SEEK_SET) != 0) {
+      fclose(f);
+      return p2mt::fail(P2MT_EINVAL, "mmr_load: truncated or oversized payload");
+    }
+  }
+  std::vector<uint64_t> host;
+  try {
+    host.resize(4 * h.n_elements);
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    return p2mt::fail(P2MT_ENOMEM, "mmr_load: out of host memory");
+  }
   const bool ok = host.empty() || fread(host.data(), 8, host.size(), f) == host.size();
-  const bool trailing = fgetc(f) != EOF;
   fclose(f);
-  if (!ok || trailing) return p2mt::fail(P2MT_EINVAL, "mmr_load: truncated or oversized payload");
+  if (!ok) return p2mt::fail(P2MT_EINVAL, "mmr_load: truncated or oversized payload");
   if (fold_checksum(host.data(), host.size()) != h.checksum) return p2mt::fail(P2MT_EINVAL, "mmr_load: checksum mismatch");
   for (size_t i = 0; i < host.size(); ++i)
     if (host[i] >= gl::P) return p2mt::fail(P2MT_EINVAL, "mmr_load: non-canonical field element");
-  m->n_leaves = 0;
-  m->pending.clear();
-  P2MT_TRY(mmr_grow(m, h.n_elements));
+  // the handle changes only once the payload is validated and on the device: upload to a fresh buffer, then swap
+  DevBuf fresh;
+  const size_t cap = h.n_elements > 1024 ? h.n_elements : 1024;
+  if (fresh.alloc(cap * 32) != P2MT_OK) return p2mt::fail(P2MT_ENOMEM, "mmr_load: hipMalloc failed");
   if (h.n_elements) {
-    P2MT_HIP(hipMemcpyAsync(m->elements, host.data(), host.size() * 8, hipMemcpyHostToDevice, rt().stream));
-    P2MT_HIP(hipStreamSynchronize(rt().stream));
+    P2MT_HIP(hipMemcpyAsync(fresh.p, host.data(), host.size() * 8, hipMemcpyHostToDevice, rt().stream));
   }
+  P2MT_HIP(hipStreamSynchronize(rt().stream));  // also: nothing enqueued earlier still reads the old array
+  if (m->elements) (void)hipFree(m->elements);
+  m->elements = fresh.as<u64>();
+  fresh.p = nullptr;
+  m->cap_nodes = cap;
+  m->pending.clear();
   m->n_leaves = h.n_leaves;
   return P2MT_OK;
 }

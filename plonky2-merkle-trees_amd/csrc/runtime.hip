@@ -6,6 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <thread>
+
 namespace p2mt {
 
 Runtime& rt() {
@@ -41,6 +44,24 @@ thread_local size_t tl_scratch_cap[kScratchCount] = {};
 thread_local uint64_t tl_scratch_epoch = 0;  // bumped whenever a scratch buffer of this thread is (re)allocated or freed
 }  // namespace
 
+// A worker thread that ends without p2mt_thread_stream_destroy() still gives its scratch back: the holder's destructor
+// runs at thread exit.  (Not for the thread that loaded the library: at process exit the HIP runtime may already be gone.)
+namespace {
+const std::thread::id g_loader_thread = std::this_thread::get_id();
+struct ScratchHolder {
+  bool armed = false;
+  ~ScratchHolder() {
+    if (!armed || std::this_thread::get_id() == g_loader_thread) return;
+    for (int k = 0; k < kScratchCount; ++k)
+      if (tl_scratch_ptr[k]) {
+        (void)hipFree(tl_scratch_ptr[k]);  // hipFree synchronises the device: nothing still reads the buffer
+        tl_scratch_ptr[k] = nullptr;
+      }
+  }
+};
+thread_local ScratchHolder tl_scratch_holder;
+}  // namespace
+
 uint64_t scratch_epoch() { return tl_scratch_epoch; }
 
 int scratch_get(int slot, size_t bytes, void** out) {
@@ -56,6 +77,7 @@ int scratch_get(int slot, size_t bytes, void** out) {
     }
     const size_t want = bytes + bytes / 4;
     ++tl_scratch_epoch;
+    tl_scratch_holder.armed = true;
     if (hipMalloc(&ptr[slot], want) != hipSuccess) {
       (void)hipGetLastError();
       return fail(P2MT_ENOMEM, "hipMalloc(scratch) failed");
@@ -93,7 +115,7 @@ void prof_end(int slot) {
 }
 
 int ensure_init() {
-  if (rt().initialised) return P2MT_OK;
+  if (rt().initialised) return P2MT_OK;  // (set last, under the lock, by p2mt_init)
   return p2mt_init(rt().device);
 }
 
@@ -110,7 +132,12 @@ extern "C" int p2mt_device_count(void) {
   return n;
 }
 
+// The process-global state is written under one lock; a process drives ONE device (one process per GPU): the twiddle / coset
+// tables cached by the commit step live on the device of the first init, so a later init on another device is refused instead
+// of leaving them pointing at the old one.
+static std::mutex g_init_mutex;
 extern "C" int p2mt_init(int device) {
+  std::lock_guard<std::mutex> lock(g_init_mutex);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) {
@@ -118,8 +145,10 @@ extern "C" int p2mt_init(int device) {
     return p2mt::fail(P2MT_EHIP, "no HIP device available: this library has no CPU fallback");
   }
   if (device < 0 || device >= n) return p2mt::fail(P2MT_EINVAL, "device index out of range");
+  if (rt().initialised && rt().device != device)
+    return p2mt::fail(P2MT_EINVAL, "p2mt_init: already initialised on another device (one process drives one GPU)");
   P2MT_HIP(hipSetDevice(device));
-  if (rt().initialised && rt().device == device) return P2MT_OK;
+  if (rt().initialised) return P2MT_OK;
   rt().device = device;
   if (rt().ev_start) (void)hipEventDestroy(rt().ev_start);
   if (rt().ev_stop) (void)hipEventDestroy(rt().ev_stop);
@@ -209,6 +238,14 @@ extern "C" int p2mt_debug_force_fallback(int on) {
 extern "C" int p2mt_get_variant(int* mds, int* partial) {
   if (mds) *mds = rt().mds;
   if (partial) *partial = rt().partial;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_get_build_config(int* subtree_levels, int* tile_log, int* subtree_block) {
+  P2MT_TRY(p2mt::ensure_init());  // the knobs are read from the environment at init
+  if (subtree_levels) *subtree_levels = rt().mds == 2 ? (int)rt().subtree_levels : 0;
+  if (tile_log) *tile_log = rt().mds == 2 ? (int)rt().tile_log : 11;
+  if (subtree_block) *subtree_block = (int)rt().subtree_block;
   return P2MT_OK;
 }
 

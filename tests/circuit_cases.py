@@ -28,15 +28,6 @@ def synthetic_case(oracle, n_siblings, seed):
 
 
 def assign(leaf_t, proof_ts, peak_ts, public_input_ts, case, set_target):
-    """The witness assignment of mmr_plonky2_verifier.rs:122-146 through set_target(target, value)."""
-    leaf, siblings, lefts, peaks, root = case
-    set_target(leaf_t, int(leaf))
-    for (ht, bt), sib, left in zip(proof_ts, siblings, lefts):
-        for k in range(4):
-            set_target(ht[k], int(sib[k]))
-        set_target(bt, int(left))
-    for pt, pk in zip(peak_ts, peaks):
-        for k in range(4):
-            set_target(pt[k], int(pk[k]))
-    for k, t in enumerate(public_input_ts):
-        set_target(t, int(root[k]))
+    """The witness assignment of mmr_plonky2_verifier.rs:122-146 (lives in the package: synthetic.assign_mmr_proof)."""
+    import __graft_entry__ as ge
+    return ge.load_package().synthetic.assign_mmr_proof(leaf_t, proof_ts, peak_ts, public_input_ts, case, set_target)

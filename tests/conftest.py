@@ -42,24 +42,6 @@ def golden():
 
 
 def splitmix_leaves(n, seed):
-    """n uniform Goldilocks elements: SplitMix64(seed) with rejection of values >= p
-    (mirrors rng.gen_range(0..GOLDILOCKS_FIELD_ORDER), merkle_mountain_ranges.rs:336)."""
-    import numpy as np
-    P = 0xFFFFFFFF00000001
-    out = np.empty(n, dtype=np.uint64)
-    filled = 0
-    state = np.uint64(seed)
-    with np.errstate(over="ignore"):
-        while filled < n:
-            m = max(1024, int((n - filled) * 1.01))
-            idx = np.arange(1, m + 1, dtype=np.uint64)
-            z = state + idx * np.uint64(0x9E3779B97F4A7C15)
-            state = z[-1]
-            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-            z = z ^ (z >> np.uint64(31))
-            z = z[z < np.uint64(P)]
-            take = min(z.size, n - filled)
-            out[filled:filled + take] = z[:take]
-            filled += take
-    return out
+    """The bench's leaf generator (lives in the package: plonky2-merkle-trees_amd/synthetic.py)."""
+    import __graft_entry__ as ge
+    return ge.load_package().synthetic.splitmix_leaves(n, seed)

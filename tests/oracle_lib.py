@@ -24,6 +24,26 @@ def build_oracle(force=False):
     return so
 
 
+def build_fast_port_native():
+    """The tuned scalar port compiled for THIS machine (-O3 -march=native) into a temp dir: bench.py's cpu_baseline.port_fast.
+    (liboracle.so itself is built without -march=native because the built file travels to the GPU box.)"""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="p2mt_fast_port_")
+    so = os.path.join(d, "libfastport.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", so,
+                           os.path.join(ORACLE_DIR, "poseidon_fast.c"), "-I", ORACLE_DIR])
+    lib = C.CDLL(so)
+    _bind_fast(lib)
+    return lib
+
+
+def _bind_fast(lib):
+    lib.oracle_fast_poseidon_permute.argtypes = [_u64p]
+    lib.oracle_fast_two_to_one_batch.argtypes = [_u64p, _u64p, C.c_size_t]
+    lib.oracle_fast_mmr_add_leaf_loop.argtypes = [_u64p, C.c_size_t, _u64p]
+    lib.oracle_fast_mmr_build_pow2.argtypes = [_u64p, C.c_size_t, _u64p, C.c_int]
+
+
 def _ptr(a):
     return a.ctypes.data_as(_u64p)
 
@@ -102,6 +122,7 @@ class Oracle:
         lib.oracle_mmr_add_leaf.argtypes = [C.c_void_p, C.c_uint64]
         lib.oracle_mmr_add_leaves.argtypes = [C.c_void_p, _u64p, C.c_size_t]
         lib.oracle_mmr_build_pow2_parallel.argtypes = [_u64p, C.c_size_t, _u64p, C.c_int]
+        _bind_fast(lib)
         lib.oracle_mmr_len.argtypes = [C.c_void_p]
         lib.oracle_mmr_len.restype = C.c_size_t
         lib.oracle_mmr_elements.argtypes = [C.c_void_p]
@@ -229,6 +250,27 @@ class Oracle:
         el = out if out is not None else np.empty((2 * n - 1, 4), np.uint64)
         threads = self.lib.oracle_mmr_build_pow2_parallel(_ptr(leaves), n, _ptr(el), threads)
         return el, threads
+
+    def fast_mmr_add_leaf_loop(self, leaves, lib=None):
+        """for leaf { add_leaf } on the tuned scalar port, one thread -> elements (2n - popcount n, 4)"""
+        leaves = _arr(leaves)
+        n = leaves.size
+        el = np.empty((2 * n - bin(n).count("1"), 4), np.uint64)
+        (lib or self.lib).oracle_fast_mmr_add_leaf_loop(_ptr(leaves), n, _ptr(el))
+        return el
+
+    def fast_mmr_build_pow2(self, leaves, threads=0, out=None, lib=None):
+        leaves = _arr(leaves)
+        n = leaves.size
+        assert n and n & (n - 1) == 0
+        el = out if out is not None else np.empty((2 * n - 1, 4), np.uint64)
+        threads = (lib or self.lib).oracle_fast_mmr_build_pow2(_ptr(leaves), n, _ptr(el), threads)
+        return el, threads
+
+    def fast_permute(self, state):
+        s = _arr(state).copy()
+        self.lib.oracle_fast_poseidon_permute(_ptr(s))
+        return s
 
     def mmr_proof_verify(self, siblings, lefts, peaks, leaf, root):
         sib = _arr(siblings).reshape(-1, 4)

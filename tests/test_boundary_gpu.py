@@ -1,0 +1,202 @@
+"""GPU tests of the boundary behaviours added in round 2: failure atomicity of the add_leaf queue and of checkpoints, the
+device-side shard-root combine (N > 1 path on one device), the full-size bit-exact check of the headline configuration,
+plonky2's own `MerkleTree.digests` order, and bench.py's multi-rank modes launched as real child processes."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.init(0)
+    return p
+
+
+def test_failed_flush_keeps_queued_leaves(pkg, oracle):
+    """a flush that fails (here: the device allocation while growing) must not drop the queued leaves --
+    len()/num_leaves() already count them -- and the operation must be retryable."""
+    N = pkg._native
+    rng = np.random.default_rng(5)
+    first = rng.integers(0, P, size=700, dtype=np.uint64)
+    queued = rng.integers(0, P, size=900, dtype=np.uint64)
+    m = pkg.MMR.from_leaves(first)          # exact first allocation: 2 * 700 nodes
+    for v in queued:
+        m.add_leaf(int(v))
+    assert m.num_leaves == 1600
+    N.check(N.lib().p2mt_debug_fail_allocs(1))
+    try:
+        with pytest.raises(N.P2mtError) as e:
+            m.bagging_the_peaks()           # observes the MMR -> flush -> grow -> injected ENOMEM
+        assert e.value.code == N.P2MT_ENOMEM
+    finally:
+        N.check(N.lib().p2mt_debug_fail_allocs(0))
+    assert m.num_leaves == 1600 and len(m) == 2 * 1600 - bin(1600).count("1")
+    om = oracle.mmr(np.concatenate([first, queued]))
+    assert np.array_equal(m.bagging_the_peaks(), om.bagging_the_peaks())   # the retry succeeds on the full leaf set
+    assert np.array_equal(m.elements, om.elements)
+    # the same for a bulk extend: a failed call leaves the handle exactly as it was
+    more = rng.integers(0, P, size=5000, dtype=np.uint64)
+    N.check(N.lib().p2mt_debug_fail_allocs(1))
+    try:
+        with pytest.raises(N.P2mtError):
+            m.extend(more)
+    finally:
+        N.check(N.lib().p2mt_debug_fail_allocs(0))
+    assert m.num_leaves == 1600 and np.array_equal(m.bagging_the_peaks(), om.bagging_the_peaks())
+    m.extend(more)
+    om2 = oracle.mmr(np.concatenate([first, queued, more]))
+    assert np.array_equal(m.elements, om2.elements)
+
+
+def test_checkpoint_load_is_validated_before_anything_changes(pkg, oracle, tmp_path):
+    """a truncated / oversized / lying checkpoint is refused with EINVAL before any large allocation, and a
+    failed load leaves the handle untouched."""
+    N = pkg._native
+    leaves = np.arange(1, 1001, dtype=np.uint64)
+    m = pkg.MMR.from_leaves(leaves)
+    good = str(tmp_path / "good.mmr")
+    m.save(good)
+    blob = open(good, "rb").read()
+    keep = pkg.MMR.from_leaves(leaves[:10])
+    before = keep.elements.copy()
+
+    def refused(data):
+        path = str(tmp_path / "bad.mmr")
+        open(path, "wb").write(data)
+        rc = N.lib().p2mt_mmr_load(keep._h, os.fsencode(path))
+        assert rc == N.P2MT_EINVAL, rc
+        assert keep.num_leaves == 10 and np.array_equal(keep.elements, before)
+
+    refused(blob[:-32])                                     # truncated payload
+    refused(blob + b"\0" * 32)                              # trailing bytes
+    # header claiming 2^39 leaves (tens of TiB of nodes) over a tiny payload: rejected by the size check, no allocation
+    n_big = 1 << 39
+    hdr = bytearray(blob[:32])
+    hdr[8:16] = n_big.to_bytes(8, "little")
+    hdr[16:24] = (2 * n_big - 1).to_bytes(8, "little")
+    refused(bytes(hdr) + blob[32:])
+    corrupt = bytearray(blob)
+    corrupt[40] ^= 1                                        # checksum mismatch
+    refused(bytes(corrupt))
+    ok = pkg.MMR.load(good)
+    assert np.array_equal(ok.elements, oracle.mmr(leaves).elements)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_combine_shard_roots_on_one_device(pkg, oracle, world):
+    """The N > 1 device path on ONE GPU: W shards built as separate device-resident MMRs with extend_dev,
+    p2mt_mmr_combine_shard_roots on their roots; shard spans, top nodes and root against the monolithic GPU MMR and the oracle."""
+    import torch
+    k = 14
+    n, n_local = 1 << k, (1 << k) // world
+    leaves = pkg.synthetic.splitmix_leaves(n, 77 + world)
+    d_all = torch.from_numpy(leaves.view(np.int64)).cuda()
+    mono = pkg.MMR()
+    mono.extend_dev(d_all, n)
+    mono_el = mono.elements
+    full = oracle.mmr(leaves)
+    assert np.array_equal(mono_el, full.elements)
+    shards = [pkg.ShardedMMR(pkg, n_local, r, world, None) for r in range(world)]
+    roots = []
+    for r, sh in enumerate(shards):
+        sh.local.reset()
+        sh.local.extend_dev(d_all[r * n_local:(r + 1) * n_local], n_local)
+        roots.append(sh.local.bagging_the_peaks())
+        fp = sh.first_pos()
+        assert np.array_equal(mono_el[fp:fp + 2 * n_local - 1], sh.local.elements), "shard %d span" % r
+    roots = np.array(roots, np.uint64)
+    sh = shards[0]
+    sh.gather_roots = lambda local_root: roots          # the all-gather's result (exchange itself: tests/test_sharded_gloo.py)
+    root = sh.finish(roots[0])
+    assert np.array_equal(root, full.bagging_the_peaks()) and np.array_equal(root, mono.bagging_the_peaks())
+    off = 0
+    for h in range(1, sh.g + 1):
+        for j in range(world >> h):
+            assert np.array_equal(mono_el[sh.top_node_pos(h, j)], sh.top_nodes[off + j]), (h, j)
+        off += world >> h
+    # a cross-shard proof assembled from the last shard's bottom path and the combined top nodes verifies on the GPU
+    last = shards[-1]
+    last.shard_roots, last.top_nodes, last.root = roots, sh.top_nodes, root
+    g = n - 3
+    pr_local = last.local.get_proof_normal_index(g - (world - 1) * n_local)
+    ts, tl = last.top_siblings(world - 1)
+    sib, lefts = np.concatenate([pr_local.siblings, ts]), np.concatenate([pr_local.lefts, tl])
+    ref = full.get_proof_normal_index(g)
+    assert np.array_equal(sib, ref["siblings"]) and np.array_equal(lefts, ref["lefts"])
+    assert pkg.MMR_proof(2 * n - 1, sib, lefts, root[None]).verify(int(leaves[g]), root)
+
+
+def test_full_size_bit_exact_2pow24(pkg, oracle):
+    """The headline configuration (2^24 leaves, the bench's own input) compared with the oracle at the FULL size: root and the
+    SHA-256 of all 33 554 431 nodes, not a prefix."""
+    import torch
+    leaves = pkg.synthetic.bench_leaves(24, 0)
+    d = torch.from_numpy(leaves.view(np.int64)).cuda()
+    m = pkg.MMR()
+    m.reserve(1 << 24)
+    m.extend_dev(d, 1 << 24)
+    gpu_root = m.bagging_the_peaks()
+    gpu_sha = hashlib.sha256(m.elements.tobytes()).hexdigest()
+    del m
+    el, threads = oracle.mmr_build_pow2_parallel(leaves, min(os.cpu_count() or 1, 32))
+    assert np.array_equal(el[-1], gpu_root)
+    assert hashlib.sha256(el.tobytes()).hexdigest() == gpu_sha
+
+
+@pytest.mark.parametrize("n,w,cap", [(64, 3, 2), (512, 135, 4), (16, 5, 4), (32, 20, 0), (4096, 16, 4)])
+def test_plonky2_digest_layout(pkg, oracle, n, w, cap):
+    """p2mt_merkle_digests_to_plonky2_layout == plonky2's own fill_subtree order (oracle/merkle_cap.py), and MerkleTree::prove's
+    index formula finds the same siblings in it as the level-major walk."""
+    from oracle import merkle_cap as MC
+    rng = np.random.default_rng(n + w)
+    leaves = rng.integers(0, P, size=(n, w), dtype=np.uint64)
+    t = pkg.MerkleCapTree.new(leaves, cap)
+    got = t.plonky2_digests()
+    if n <= 512:
+        want, want_cap = MC.merkle_tree_new(oracle, leaves, cap)
+        assert np.array_equal(t.cap, want_cap)
+        assert np.array_equal(got, want)
+    for leaf in (0, 1, n // 2 - 1, n - 1, int(rng.integers(0, n))):
+        assert np.array_equal(MC.prove(got, n, cap, leaf), t.prove(leaf))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("scaling,log_leaves", [("weak", 15), ("strong", 16)])
+def test_bench_two_ranks_on_one_device(pkg, oracle, scaling, log_leaves):
+    """bench.py's N = 2 path as the driver launches it (torch.distributed.run, fresh child processes), both ranks on GPU 0 with
+    the gloo backend for the 32-byte exchange: build_dev -> all-gather -> p2mt_mmr_combine_shard_roots.  The printed root must be
+    the oracle's root of the concatenated shards."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--log-leaves", str(log_leaves), "--scaling", scaling, "--no-prove",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    local_log = log_leaves - 1 if scaling == "strong" else log_leaves
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["leaves_per_gpu"] == 1 << local_log
+    leaves = np.concatenate([pkg.synthetic.bench_leaves(local_log, r) for r in range(2)])
+    assert [int(x) for x in oracle.mmr(leaves).bagging_the_peaks()] == out["root"]
+    assert out["config"]["hashes_per_step"] == 2 * ((1 << local_log) - 1) + 1

@@ -283,3 +283,38 @@ def test_parallel_cpu_baseline_equals_add_leaf_loop(oracle):
     el, threads = oracle.mmr_build_pow2_parallel(leaves)
     assert threads >= 1
     assert np.array_equal(el, oracle.mmr(leaves).elements)
+
+
+def test_fast_port_equals_spec_form(oracle):
+    """oracle/poseidon_fast.c (bench.py's cpu_baseline.port_fast: sparse partial rounds, lazy reduction) is the same function as
+    the spec-form restatement: permutation on edge values and random states, the add_leaf loop and the level-order build."""
+    rng = np.random.default_rng(23)
+    states = [np.zeros(12, np.uint64), np.full(12, P - 1, np.uint64), np.full(12, 2**64 - 1, np.uint64),
+              np.arange(12, dtype=np.uint64)]
+    states += [rng.integers(0, 2**64, size=12, dtype=np.uint64) for _ in range(200)]
+    for s in states:
+        assert np.array_equal(oracle.fast_permute(s), oracle.permute(s))
+    leaves = rng.integers(0, P, size=(1 << 10) + 37, dtype=np.uint64)
+    assert np.array_equal(oracle.fast_mmr_add_leaf_loop(leaves), oracle.mmr(leaves).elements)
+    el, _ = oracle.fast_mmr_build_pow2(leaves[:1 << 10], 3)
+    assert np.array_equal(el, oracle.mmr(leaves[:1 << 10]).elements)
+
+
+def test_plonky2_digest_layout_restatement(oracle):
+    """oracle/merkle_cap.py (plonky2's fill_subtree order + MerkleTree::prove's index formula) agrees with the level-major cap
+    tree of the C oracle: same cap, and every Merkle path read through plonky2's indexing equals the level-major walk."""
+    from oracle import merkle_cap as MC
+    rng = np.random.default_rng(2)
+    for n, w, cap in ((64, 3, 2), (64, 9, 4), (16, 5, 4), (32, 20, 0)):
+        leaves = rng.integers(0, P, size=(n, w), dtype=np.uint64)
+        d, c = MC.merkle_tree_new(oracle, leaves, cap)
+        dig, capo = oracle.merkle_cap_commit(leaves, cap)
+        assert np.array_equal(capo, c) and d.shape[0] == 2 * (n - (1 << cap))
+        k = n.bit_length() - 1
+        for leaf in range(n):
+            off, idx, exp = 0, leaf, []
+            for j in range(k - cap):
+                exp.append(dig[off + (idx ^ 1)])
+                off += n >> j
+                idx >>= 1
+            assert np.array_equal(MC.prove(d, n, cap, leaf), np.array(exp, np.uint64).reshape(-1, 4))
