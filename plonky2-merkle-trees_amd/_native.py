@@ -182,6 +182,14 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 / libhsa-runtime64, and a process that
+        # loads /opt/rocm's copy first (through this library) and torch's afterwards ends up with two runtimes, the second of
+        # which sees no GPU ("No HIP GPUs are available").  Loading torch first makes the dynamic loader resolve this library's
+        # libamdhip64.so.7 to the copy already in the process.  (torch is plumbing here: device tensors, streams, distributed.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(l, name)
