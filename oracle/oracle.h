@@ -80,6 +80,7 @@ void oracle_mmr_add_leaves(oracle_mmr *m, const uint64_t *leaves, size_t n); /* 
  * leaves built level by level with every host core (OpenMP).  Returns the number of threads used. */
 int oracle_mmr_build_pow2_parallel(const uint64_t *leaves, size_t n, uint64_t *elements_out, int threads /* 0 = all */);
 /* Tuned scalar port (poseidon_fast.c: sparse partial rounds, lazy reduction; bench.py's cpu_baseline.port_fast).  Same values. */
+void oracle_poseidon_round_constants(uint64_t out[360]); /* ALL_ROUND_CONSTANTS, round r = [12r, 12r + 12) */
 void oracle_fast_poseidon_permute(uint64_t state[12]);
 void oracle_fast_two_to_one_batch(const uint64_t *in /*[n][8]*/, uint64_t *out /*[n][4]*/, size_t n);
 void oracle_fast_mmr_add_leaf_loop(const uint64_t *leaves, size_t n, uint64_t *elements_out); /* for leaf { add_leaf }, 1 thread */
@@ -168,11 +169,24 @@ int oracle_permutation_partial_products(const uint64_t *wires, const uint64_t *s
  * Circuit shape the verifier circuits of /root/reference/src/mmr/mmr_plonky2_verifier.rs:13-91 build to under
  * CircuitConfig::standard_recursion_config(): the gate types in plonky2's sorted order (degree, id), each with its selector
  * polynomial and selector group (gates/selectors.rs). */
-enum { ORACLE_GATE_NOOP = 0, ORACLE_GATE_CONSTANT = 1, ORACLE_GATE_PUBLIC_INPUT = 2, ORACLE_GATE_ARITHMETIC = 3, ORACLE_GATE_POSEIDON = 4 };
-#define ORACLE_PLONK_NUM_GATE_CONSTRAINTS 123 /* PoseidonGate: 1 + 4 + 36 + 22 + 48 + 12 */
+enum { ORACLE_GATE_NOOP = 0, ORACLE_GATE_CONSTANT = 1, ORACLE_GATE_PUBLIC_INPUT = 2, ORACLE_GATE_ARITHMETIC = 3, ORACLE_GATE_POSEIDON = 4,
+       /* the gates plonky2's in-circuit verifier (builder.verify_proof, mmr_plonky2_verifier_1_recursion.rs:101-104) adds under
+        * standard_recursion_config; parameters fixed by that config (D = 2): */
+       ORACLE_GATE_BASE_SUM = 5,            /* BaseSumGate<2> { num_limbs: 63 } */
+       ORACLE_GATE_ARITHMETIC_EXT = 6,      /* ArithmeticExtensionGate { num_ops: 10 } */
+       ORACLE_GATE_MUL_EXT = 7,             /* MulExtensionGate { num_ops: 13 } */
+       ORACLE_GATE_REDUCING = 8,            /* ReducingGate { num_coeffs: 43 } */
+       ORACLE_GATE_REDUCING_EXT = 9,        /* ReducingExtensionGate { num_coeffs: 32 } */
+       ORACLE_GATE_RANDOM_ACCESS = 10,      /* RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2 } */
+       ORACLE_GATE_COSET_INTERPOLATION = 11,/* CosetInterpolationGate { subgroup_bits: 4, degree: 6 } */
+       ORACLE_GATE_POSEIDON_MDS = 12,       /* PoseidonMdsGate */
+       ORACLE_GATE_KINDS = 13 };
+#define ORACLE_PLONK_NUM_GATE_CONSTRAINTS 123 /* PoseidonGate: 1 + 4 + 36 + 22 + 48 + 12 (the maximum over all gate types) */
+#define ORACLE_PLONK_MAX_GATES 16
 typedef struct oracle_plonk_desc {
   uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, num_gates;
-  uint32_t gate_kind[8], gate_selector[8], group_start[8], group_end[8];
+  uint32_t gate_kind[ORACLE_PLONK_MAX_GATES], gate_selector[ORACLE_PLONK_MAX_GATES], group_start[ORACLE_PLONK_MAX_GATES],
+      group_end[ORACLE_PLONK_MAX_GATES];
 } oracle_plonk_desc;
 /* compute_quotient_polys: cs/wires/zs leaves are the LDE matrices of the three committed batches as
  * oracle_polynomial_batch_commit leaves them ([8n][n_polys], leaf index bit-reversed; cs = selectors | constants | sigmas,
@@ -184,6 +198,10 @@ int oracle_plonk_quotient_polys(const oracle_plonk_desc *d, const uint64_t *k_is
  * vanishing(zeta) == Z_H(zeta) * sum_k t_k(zeta) zeta^(n k) per challenge.  Every opening is an extension element (2 words):
  * constants [num_selectors + num_constants], sigmas [num_routed], wires [num_wires], zs / next_zs [num_challenges],
  * pps [num_challenges * num_prods], quotient [num_challenges * quotient_degree_factor].  Returns 1 accept, 0 reject. */
+/* Unfiltered constraints of ONE gate type on ONE row of base-field wires (tests: every row of a generated witness must satisfy
+ * the constraints of its own gate).  consts: the row's gate constants.  Returns the number of constraints written to out. */
+int oracle_gate_constraints_row(unsigned kind, const uint64_t *wires /*[135]*/, const uint64_t *consts /*[2]*/,
+                                const uint64_t pi_hash[4], uint64_t *out /*[123]*/);
 int oracle_plonk_check_openings(const oracle_plonk_desc *d, const uint64_t *k_is, const uint64_t zeta[2], const uint64_t *constants,
                                 const uint64_t *sigmas, const uint64_t *wires, const uint64_t *zs, const uint64_t *next_zs,
                                 const uint64_t *pps, const uint64_t *quotient, const uint64_t pi_hash[4], const uint64_t *betas,

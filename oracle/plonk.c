@@ -104,6 +104,12 @@ static inline fe2 e_fromc(uint64_t c) { return (fe2){c, 0}; }
 #define FE_FROMC(c) e_fromc(c)
 #include "plonk_eval.inc.h"
 
+int oracle_gate_constraints_row(unsigned kind, const uint64_t *wires, const uint64_t *consts, const uint64_t pi_hash[4],
+                                uint64_t *out) {
+  if (kind >= ORACLE_GATE_KINDS) return -1;
+  return gate_eval_unfiltered_b(kind, 2, 80, consts, wires, pi_hash, out);
+}
+
 static size_t brev(size_t x, unsigned bits) {
   size_t r = 0;
   for (unsigned i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
@@ -111,12 +117,12 @@ static size_t brev(size_t x, unsigned bits) {
 }
 
 static int desc_ok(const oracle_plonk_desc *d) {
-  if (!d || d->num_gates == 0 || d->num_gates > 8 || d->num_challenges == 0 || d->num_challenges > 16) return 0;
+  if (!d || d->num_gates == 0 || d->num_gates > ORACLE_PLONK_MAX_GATES || d->num_challenges == 0 || d->num_challenges > 16) return 0;
   if (d->num_wires != 135 || d->num_routed == 0 || d->num_routed > d->num_wires || d->num_routed % 4) return 0;
   if (d->quotient_degree_factor < 2 || (d->quotient_degree_factor & (d->quotient_degree_factor - 1))) return 0;
   if ((d->num_routed + d->quotient_degree_factor - 1) / d->quotient_degree_factor > 64 || d->num_constants > 4) return 0;
   for (unsigned g = 0; g < d->num_gates; ++g)
-    if (d->gate_kind[g] > ORACLE_GATE_POSEIDON || d->gate_selector[g] >= d->num_selectors || d->group_start[g] > g || d->group_end[g] <= g)
+    if (d->gate_kind[g] >= ORACLE_GATE_KINDS || d->gate_selector[g] >= d->num_selectors || d->group_start[g] > g || d->group_end[g] <= g)
       return 0;
   return 1;
 }

@@ -70,6 +70,211 @@ static void FN(poseidon_gate_eval)(const FE *w, FE *out) {
   for (int i = 0; i < 12; ++i) out[k++] = FE_SUB(s[i], w[12 + i]);
 }
 
+/* ---- the extension algebra FE[X]/(X^2 - 7): what plonky2 calls ExtensionAlgebra when FE is itself the extension field (the
+ * verifier at zeta) and what is simply the quadratic extension when FE is the base field (the prover on the LDE coset).  The
+ * recursion gates' wires hold extension elements as D = 2 consecutive wires. */
+typedef struct { FE a, b; } FN(alg);
+static inline FN(alg) FN(alg_w)(const FE *w, int at) { return (FN(alg)){w[at], w[at + 1]}; }
+static inline FN(alg) FN(alg_add)(FN(alg) x, FN(alg) y) { return (FN(alg)){FE_ADD(x.a, y.a), FE_ADD(x.b, y.b)}; }
+static inline FN(alg) FN(alg_sub)(FN(alg) x, FN(alg) y) { return (FN(alg)){FE_SUB(x.a, y.a), FE_SUB(x.b, y.b)}; }
+static inline FN(alg) FN(alg_mul)(FN(alg) x, FN(alg) y) {
+  return (FN(alg)){FE_ADD(FE_MUL(x.a, y.a), FE_MULC(FE_MUL(x.b, y.b), 7)), FE_ADD(FE_MUL(x.a, y.b), FE_MUL(x.b, y.a))};
+}
+static inline FN(alg) FN(alg_scale)(FN(alg) x, FE s) { return (FN(alg)){FE_MUL(x.a, s), FE_MUL(x.b, s)}; }
+static inline FN(alg) FN(alg_scalec)(FN(alg) x, uint64_t c) { return (FN(alg)){FE_MULC(x.a, c), FE_MULC(x.b, c)}; }
+static inline FN(alg) FN(alg_subc)(FN(alg) x, uint64_t c) { return (FN(alg)){FE_SUBC(x.a, c), x.b}; }
+
+/* ArithmeticExtensionGate { num_ops: 10 }: per op, wires m0 | m1 | addend | output (2 each); output - (c0 m0 m1 + c1 addend) */
+static int FN(arithmetic_ext_gate_eval)(const FE *w, const FE *gc, FE *out) {
+  int k = 0;
+  for (int i = 0; i < 10; ++i) {
+    const FN(alg) m0 = FN(alg_w)(w, 8 * i), m1 = FN(alg_w)(w, 8 * i + 2), ad = FN(alg_w)(w, 8 * i + 4), o = FN(alg_w)(w, 8 * i + 6);
+    const FN(alg) c = FN(alg_sub)(o, FN(alg_add)(FN(alg_scale)(FN(alg_mul)(m0, m1), gc[0]), FN(alg_scale)(ad, gc[1])));
+    out[k++] = c.a;
+    out[k++] = c.b;
+  }
+  return k;
+}
+
+/* MulExtensionGate { num_ops: 13 }: per op, wires m0 | m1 | output; output - c0 m0 m1 */
+static int FN(mul_ext_gate_eval)(const FE *w, const FE *gc, FE *out) {
+  int k = 0;
+  for (int i = 0; i < 13; ++i) {
+    const FN(alg) m0 = FN(alg_w)(w, 6 * i), m1 = FN(alg_w)(w, 6 * i + 2), o = FN(alg_w)(w, 6 * i + 4);
+    const FN(alg) c = FN(alg_sub)(o, FN(alg_scale)(FN(alg_mul)(m0, m1), gc[0]));
+    out[k++] = c.a;
+    out[k++] = c.b;
+  }
+  return k;
+}
+
+/* BaseSumGate<2> { num_limbs: 63 }: wire 0 = sum, wires 1..63 = limbs; sum constraint, then limb (limb - 1) per limb */
+static int FN(base_sum_gate_eval)(const FE *w, FE *out) {
+  int k = 0;
+  FE acc = FE_FROMC(0);
+  for (int i = 63; i-- > 0;) acc = FE_ADD(FE_MULC(acc, 2), w[1 + i]); /* reduce_with_powers(limbs, 2) */
+  out[k++] = FE_SUB(acc, w[0]);
+  for (int i = 0; i < 63; ++i) out[k++] = FE_MUL(w[1 + i], FE_SUBC(w[1 + i], 1));
+  return k;
+}
+
+/* ReducingGate { num_coeffs: 43 }: output 0-1, alpha 2-3, old_acc 4-5, coeffs 6..48 (base field), accs 49.. (the last acc is
+ * the output); acc_i = acc_{i-1} alpha + coeff_i */
+static int FN(reducing_gate_eval)(const FE *w, FE *out) {
+  int k = 0;
+  const FN(alg) alpha = FN(alg_w)(w, 2);
+  FN(alg) acc = FN(alg_w)(w, 4);
+  for (int i = 0; i < 43; ++i) {
+    const FN(alg) next = i == 42 ? FN(alg_w)(w, 0) : FN(alg_w)(w, 49 + 2 * i);
+    FN(alg) c = FN(alg_mul)(acc, alpha);
+    c.a = FE_ADD(c.a, w[6 + i]);
+    c = FN(alg_sub)(next, c);
+    out[k++] = c.a;
+    out[k++] = c.b;
+    acc = next;
+  }
+  return k;
+}
+
+/* ReducingExtensionGate { num_coeffs: 32 }: output 0-1, alpha 2-3, old_acc 4-5, coeffs 6..69 (2 each), accs 70.. */
+static int FN(reducing_ext_gate_eval)(const FE *w, FE *out) {
+  int k = 0;
+  const FN(alg) alpha = FN(alg_w)(w, 2);
+  FN(alg) acc = FN(alg_w)(w, 4);
+  for (int i = 0; i < 32; ++i) {
+    const FN(alg) next = i == 31 ? FN(alg_w)(w, 0) : FN(alg_w)(w, 70 + 2 * i);
+    const FN(alg) c = FN(alg_sub)(next, FN(alg_add)(FN(alg_mul)(acc, alpha), FN(alg_w)(w, 6 + 2 * i)));
+    out[k++] = c.a;
+    out[k++] = c.b;
+    acc = next;
+  }
+  return k;
+}
+
+/* RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2 }: copy c: access_index 18c, claimed 18c+1, list 18c+2..18c+17;
+ * extra constants on wires 72, 73; bits of copy c on wires 74+4c.. */
+static int FN(random_access_gate_eval)(const FE *w, const FE *gc, FE *out) {
+  int k = 0;
+  for (int c = 0; c < 4; ++c) {
+    const FE *bits = w + 74 + 4 * c;
+    for (int i = 0; i < 4; ++i) out[k++] = FE_MUL(bits[i], FE_SUBC(bits[i], 1));
+    FE idx = FE_FROMC(0);
+    for (int i = 4; i-- > 0;) idx = FE_ADD(FE_ADD(idx, idx), bits[i]);
+    out[k++] = FE_SUB(idx, w[18 * c]);
+    FE list[16];
+    for (int i = 0; i < 16; ++i) list[i] = w[18 * c + 2 + i];
+    for (int b = 0, len = 16; b < 4; ++b, len >>= 1)
+      for (int j = 0; j < len / 2; ++j) list[j] = FE_ADD(list[2 * j], FE_MUL(bits[b], FE_SUB(list[2 * j + 1], list[2 * j])));
+    out[k++] = FE_SUB(list[0], w[18 * c + 1]);
+  }
+  for (int i = 0; i < 2; ++i) out[k++] = FE_SUB(gc[i], w[72 + i]);
+  return k;
+}
+
+/* CosetInterpolationGate { subgroup_bits: 4, degree: 6 } (2 intermediates): shift 0, values 1..32, evaluation point 33-34,
+ * evaluation value 35-36, intermediate evals 37..40, intermediate products 41..44, shifted evaluation point 45-46.
+ * Barycentric interpolation on the subgroup <g_16>, chunked so that no constraint exceeds degree 6. */
+#ifndef ORACLE_COSET_INTERP_TABLES
+#define ORACLE_COSET_INTERP_TABLES
+static uint64_t coset_interp_domain[16], coset_interp_weights[16];
+static void coset_interp_tables(void) {
+  if (coset_interp_domain[0]) return;
+  uint64_t d[16];
+  const uint64_t g = gl_primitive_root_of_unity(4);
+  d[0] = 1;
+  for (int i = 1; i < 16; ++i) d[i] = gl_mul(d[i - 1], g);
+  for (int i = 0; i < 16; ++i) { /* w_i = 1 / prod_{j != i} (x_i - x_j) */
+    uint64_t p = 1;
+    for (int j = 0; j < 16; ++j)
+      if (j != i) p = gl_mul(p, gl_sub(d[i], d[j]));
+    coset_interp_weights[i] = gl_inv(p);
+  }
+  for (int i = 15; i >= 0; --i) coset_interp_domain[i] = d[i]; /* [0] last: it is the "initialised" marker */
+}
+#endif
+static void FN(partial_interpolate)(const FE *w, int from, int to, FN(alg) x, FN(alg) *eval, FN(alg) *prod) {
+  for (int i = from; i < to; ++i) {
+    const FN(alg) term = FN(alg_subc)(x, coset_interp_domain[i]);
+    const FN(alg) weighted = FN(alg_scalec)(FN(alg_w)(w, 1 + 2 * i), coset_interp_weights[i]);
+    *eval = FN(alg_add)(FN(alg_mul)(*eval, term), FN(alg_mul)(weighted, *prod));
+    *prod = FN(alg_mul)(*prod, term);
+  }
+}
+static int FN(coset_interpolation_gate_eval)(const FE *w, FE *out) {
+  coset_interp_tables();
+  int k = 0;
+  const FN(alg) point = FN(alg_w)(w, 33), shifted = FN(alg_w)(w, 45);
+  FN(alg) c = FN(alg_sub)(point, FN(alg_scale)(shifted, w[0]));
+  out[k++] = c.a;
+  out[k++] = c.b;
+  FN(alg) eval = {FE_FROMC(0), FE_FROMC(0)}, prod = {FE_FROMC(1), FE_FROMC(0)};
+  FN(partial_interpolate)(w, 0, 6, shifted, &eval, &prod);
+  for (int i = 0; i < 2; ++i) {
+    const FN(alg) ie = FN(alg_w)(w, 37 + 2 * i), ip = FN(alg_w)(w, 41 + 2 * i);
+    c = FN(alg_sub)(ie, eval);
+    out[k++] = c.a;
+    out[k++] = c.b;
+    c = FN(alg_sub)(ip, prod);
+    out[k++] = c.a;
+    out[k++] = c.b;
+    eval = ie;
+    prod = ip;
+    const int start = 1 + 5 * (i + 1), end = start + 5 < 16 ? start + 5 : 16;
+    FN(partial_interpolate)(w, start, end, shifted, &eval, &prod);
+  }
+  c = FN(alg_sub)(FN(alg_w)(w, 35), eval);
+  out[k++] = c.a;
+  out[k++] = c.b;
+  return k;
+}
+
+/* PoseidonMdsGate: inputs 0..23 (2 each), outputs 24..47; output = MDS * input over the algebra */
+static int FN(poseidon_mds_gate_eval)(const FE *w, FE *out) {
+  int k = 0;
+  for (int r = 0; r < 12; ++r) {
+    FN(alg) acc = FN(alg_scalec)(FN(alg_w)(w, 2 * r), POSEIDON_MDS_DIAG[r]);
+    for (int i = 0; i < 12; ++i) acc = FN(alg_add)(acc, FN(alg_scalec)(FN(alg_w)(w, 2 * ((i + r) % 12)), POSEIDON_MDS_CIRC[i]));
+    const FN(alg) c = FN(alg_sub)(acc, FN(alg_w)(w, 24 + 2 * r));
+    out[k++] = c.a;
+    out[k++] = c.b;
+  }
+  return k;
+}
+
+/* eval_unfiltered of one gate type: gc = the gate's own constants (after the selectors).  Returns the constraint count. */
+static int FN(gate_eval_unfiltered)(unsigned kind, unsigned num_constants, unsigned num_routed, const FE *gc, const FE *w,
+                                    const uint64_t pi_hash[4], FE *c) {
+  int nc = 0;
+  switch (kind) {
+    case ORACLE_GATE_NOOP: break;
+    case ORACLE_GATE_CONSTANT: /* local_constants[i] - wires[i] */
+      for (unsigned i = 0; i < num_constants; ++i) c[nc++] = FE_SUB(gc[i], w[i]);
+      break;
+    case ORACLE_GATE_PUBLIC_INPUT: /* wires[i] - public_inputs_hash[i] */
+      for (int i = 0; i < 4; ++i) c[nc++] = FE_SUBC(w[i], pi_hash[i]);
+      break;
+    case ORACLE_GATE_ARITHMETIC: /* output - (m0 m1 c0 + addend c1), num_routed / 4 operations per row */
+      for (unsigned i = 0; i < num_routed / 4; ++i) {
+        const FE prod = FE_MUL(FE_MUL(w[4 * i], w[4 * i + 1]), gc[0]);
+        c[nc++] = FE_SUB(w[4 * i + 3], FE_ADD(prod, FE_MUL(w[4 * i + 2], gc[1])));
+      }
+      break;
+    case ORACLE_GATE_POSEIDON:
+      FN(poseidon_gate_eval)(w, c);
+      nc = 123;
+      break;
+    case ORACLE_GATE_BASE_SUM: nc = FN(base_sum_gate_eval)(w, c); break;
+    case ORACLE_GATE_ARITHMETIC_EXT: nc = FN(arithmetic_ext_gate_eval)(w, gc, c); break;
+    case ORACLE_GATE_MUL_EXT: nc = FN(mul_ext_gate_eval)(w, gc, c); break;
+    case ORACLE_GATE_REDUCING: nc = FN(reducing_gate_eval)(w, c); break;
+    case ORACLE_GATE_REDUCING_EXT: nc = FN(reducing_ext_gate_eval)(w, c); break;
+    case ORACLE_GATE_RANDOM_ACCESS: nc = FN(random_access_gate_eval)(w, gc, c); break;
+    case ORACLE_GATE_COSET_INTERPOLATION: nc = FN(coset_interpolation_gate_eval)(w, c); break;
+    case ORACLE_GATE_POSEIDON_MDS: nc = FN(poseidon_mds_gate_eval)(w, c); break;
+  }
+  return nc;
+}
+
 /* compute_filter: prod_{i in group, i != row} (i - s) * (UNUSED_SELECTOR - s if there are several groups) */
 static FE FN(gate_filter)(const oracle_plonk_desc *d, unsigned g, FE s) {
   FE f = FE_FROMC(1);
@@ -87,26 +292,7 @@ static void FN(gate_constraints)(const oracle_plonk_desc *d, const FE *consts, c
   for (int j = 0; j < ORACLE_PLONK_NUM_GATE_CONSTRAINTS; ++j) terms[j] = FE_FROMC(0);
   for (unsigned g = 0; g < d->num_gates; ++g) {
     FE c[ORACLE_PLONK_NUM_GATE_CONSTRAINTS];
-    int nc = 0;
-    switch (d->gate_kind[g]) {
-      case ORACLE_GATE_NOOP: break;
-      case ORACLE_GATE_CONSTANT: /* local_constants[i] - wires[i] */
-        for (unsigned i = 0; i < d->num_constants; ++i) c[nc++] = FE_SUB(gc[i], w[i]);
-        break;
-      case ORACLE_GATE_PUBLIC_INPUT: /* wires[i] - public_inputs_hash[i] */
-        for (int i = 0; i < 4; ++i) c[nc++] = FE_SUBC(w[i], pi_hash[i]);
-        break;
-      case ORACLE_GATE_ARITHMETIC: /* output - (m0 m1 c0 + addend c1), num_routed / 4 operations per row */
-        for (unsigned i = 0; i < d->num_routed / 4; ++i) {
-          const FE prod = FE_MUL(FE_MUL(w[4 * i], w[4 * i + 1]), gc[0]);
-          c[nc++] = FE_SUB(w[4 * i + 3], FE_ADD(prod, FE_MUL(w[4 * i + 2], gc[1])));
-        }
-        break;
-      case ORACLE_GATE_POSEIDON:
-        FN(poseidon_gate_eval)(w, c);
-        nc = 123;
-        break;
-    }
+    const int nc = FN(gate_eval_unfiltered)(d->gate_kind[g], d->num_constants, d->num_routed, gc, w, pi_hash, c);
     const FE f = FN(gate_filter)(d, g, consts[d->gate_selector[g]]);
     for (int j = 0; j < nc; ++j) terms[j] = FE_ADD(terms[j], FE_MUL(f, c[j]));
   }

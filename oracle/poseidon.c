@@ -105,6 +105,8 @@ void oracle_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]) {
   }
 }
 
+void oracle_poseidon_round_constants(uint64_t out[360]) { memcpy(out, POSEIDON_RC, sizeof(POSEIDON_RC)); }
+
 uint64_t oracle_gl_add(uint64_t a, uint64_t b) { return gl_add(gl_canon(a), gl_canon(b)); }
 uint64_t oracle_gl_sub(uint64_t a, uint64_t b) { return gl_sub(gl_canon(a), gl_canon(b)); }
 uint64_t oracle_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a, b); }

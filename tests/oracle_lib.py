@@ -73,7 +73,7 @@ class FriBatch(C.Structure):
 class PlonkDesc(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("degree_bits", "num_wires", "num_routed", "num_constants", "num_selectors",
                                           "num_challenges", "quotient_degree_factor", "num_gates")] + \
-               [(k, C.c_uint32 * 8) for k in ("gate_kind", "gate_selector", "group_start", "group_end")]
+               [(k, C.c_uint32 * 16) for k in ("gate_kind", "gate_selector", "group_start", "group_end")]
 
 
 class ChallengerState(C.Structure):
@@ -123,6 +123,7 @@ class Oracle:
         lib.oracle_mmr_add_leaves.argtypes = [C.c_void_p, _u64p, C.c_size_t]
         lib.oracle_mmr_build_pow2_parallel.argtypes = [_u64p, C.c_size_t, _u64p, C.c_int]
         _bind_fast(lib)
+        lib.oracle_poseidon_round_constants.argtypes = [_u64p]
         lib.oracle_mmr_len.argtypes = [C.c_void_p]
         lib.oracle_mmr_len.restype = C.c_size_t
         lib.oracle_mmr_elements.argtypes = [C.c_void_p]
@@ -143,6 +144,7 @@ class Oracle:
                                                             C.c_uint, C.c_uint, _u64p]
         lib.oracle_plonk_quotient_polys.argtypes = [C.POINTER(PlonkDesc)] + [_u64p] * 9
         lib.oracle_plonk_check_openings.argtypes = [C.POINTER(PlonkDesc)] + [_u64p] * 13
+        lib.oracle_gate_constraints_row.argtypes = [C.c_uint, _u64p, _u64p, _u64p, _u64p]
         lib.oracle_challenger_init.argtypes = [C.POINTER(ChallengerState)]
         lib.oracle_challenger_observe.argtypes = [C.POINTER(ChallengerState), _u64p, C.c_size_t]
         lib.oracle_challenger_get.argtypes = [C.POINTER(ChallengerState)]
@@ -267,6 +269,11 @@ class Oracle:
         threads = (lib or self.lib).oracle_fast_mmr_build_pow2(_ptr(leaves), n, _ptr(el), threads)
         return el, threads
 
+    def poseidon_round_constants(self):
+        out = np.zeros(360, np.uint64)
+        self.lib.oracle_poseidon_round_constants(_ptr(out))
+        return out
+
     def fast_permute(self, state):
         s = _arr(state).copy()
         self.lib.oracle_fast_poseidon_permute(_ptr(s))
@@ -354,6 +361,13 @@ class Oracle:
         for i, (k, s, (gs, ge)) in enumerate(zip(gate_kinds, gate_selectors, gate_groups)):
             d.gate_kind[i], d.gate_selector[i], d.group_start[i], d.group_end[i] = k, s, gs, ge
         return d
+
+    def gate_constraints_row(self, kind, wires_row, consts, pi_hash):
+        """unfiltered constraints of gate `kind` on one row of wires -> array of constraint values (all zero on a valid row)"""
+        w, c, ph, out = _arr(wires_row), _arr(consts), _arr(pi_hash), np.zeros(123, np.uint64)
+        n = self.lib.oracle_gate_constraints_row(kind, _ptr(w), _ptr(c), _ptr(ph), _ptr(out))
+        assert n >= 0
+        return out[:n]
 
     def plonk_quotient_polys(self, desc, k_is, cs_leaves, wires_leaves, zs_leaves, pi_hash, betas, gammas, alphas):
         """compute_quotient_polys -> (num_challenges, quotient_degree_factor << degree_bits) coefficients"""
