@@ -382,8 +382,11 @@ int p2mt_cb_build(p2mt_circuit_builder *b, p2mt_circuit_data **out);
 int p2mt_circuit_destroy(p2mt_circuit_data *c);
 typedef struct p2mt_circuit_info {
   uint32_t degree_bits, num_gate_types, num_selectors, num_constants_sigmas, num_public_inputs, num_partial_products;
-  uint32_t gate_counts[5];  /* rows per gate type: Noop, Constant, PublicInput, Arithmetic, Poseidon */
-  uint32_t gate_kinds[5], gate_selector[5], group_start[5], group_end[5]; /* sorted gate types and their selector groups */
+  /* rows per gate type, indexed by gate kind: 0 Noop, 1 Constant, 2 PublicInput, 3 Arithmetic, 4 Poseidon, and the gate types of
+   * the in-circuit verifier: 5 BaseSum, 6 ArithmeticExtension, 7 MulExtension, 8 Reducing, 9 ReducingExtension, 10 RandomAccess,
+   * 11 CosetInterpolation, 12 PoseidonMds */
+  uint32_t gate_counts[16];
+  uint32_t gate_kinds[16], gate_selector[16], group_start[16], group_end[16]; /* sorted gate types and their selector groups */
   uint64_t proof_len, fri_proof_len; /* words */
 } p2mt_circuit_info;
 int p2mt_circuit_get_info(const p2mt_circuit_data *c, p2mt_circuit_info *info);
@@ -417,6 +420,26 @@ int p2mt_circuit_prove_many(p2mt_circuit_data *const *circuits, size_t n_handles
  * be NULL): 0 ok, 10 malformed (length / non-canonical word), 11 vanishing polynomial != Z_H * quotient at zeta, 1 proof of
  * work, 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 inconsistent layer value, 5 final polynomial. */
 int p2mt_circuit_verify(p2mt_circuit_data *c, const uint64_t *proof, size_t proof_len, int *accepted, int *reason);
+/* ---- the outer circuit of the recursion (mmr_plonky2_verifier_1_recursion.rs:84-140): plonky2's in-circuit verifier.
+ * `inner` stands for `inner_circuit_data.common` (and `.verifier_only` for the witness): the built inner circuit.
+ * A ProofWithPublicInputsTarget is a flat array of proof_len targets (the inner circuit's p2mt_circuit_info), one per word of the proof
+ * p2mt_circuit_prove writes (same order); a VerifierCircuitTarget is 68 targets: constants_sigmas_cap [16][4], circuit_digest [4].
+ *   builder.add_virtual_proof_with_pis(&common) (:95), builder.add_virtual_verifier_data(cap_height) (:98),
+ *   builder.verify_proof::<PoseidonGoldilocksConfig>(&proof, &verifier_data, &common) (:101-104): public-input hash, the whole
+ *   transcript (RecursiveChallenger), the vanishing polynomial at zeta (the inner gates' constraints evaluated with extension
+ *   arithmetic gates and one PoseidonMdsGate per round), quotient recombination, FRI: proof-of-work range check, 28 query rounds
+ *   of Merkle paths (PoseidonGate with swap + RandomAccessGate cap lookup), reduced openings (ReducingGates), coset interpolation.
+ * The inner circuit may contain the gate types Noop / Constant / PublicInput / Arithmetic / Poseidon (what the reference's inner
+ * circuits use); P2MT_EINVAL otherwise.  public_inputs of the proof target = its last num_public_inputs targets. */
+int p2mt_cb_add_virtual_proof_with_pis(p2mt_circuit_builder *b, const p2mt_circuit_data *inner, p2mt_target *out, size_t out_len);
+int p2mt_cb_add_virtual_verifier_data(p2mt_circuit_builder *b, unsigned cap_height, p2mt_target *out /*[68]*/);
+int p2mt_cb_verify_proof(p2mt_circuit_builder *b, const p2mt_target *proof_with_pis, size_t proof_len,
+                         const p2mt_target *verifier_data /*[68]*/, const p2mt_circuit_data *inner);
+/* pw.set_proof_with_pis_target(&target, &proof) (:201) and pw.set_verifier_data_target(&target, &inner.verifier_only) (:202) */
+int p2mt_pw_set_proof_with_pis_target(p2mt_partial_witness *pw, const p2mt_target *proof_target, const uint64_t *proof_words,
+                                      size_t proof_len);
+int p2mt_pw_set_verifier_data_target(p2mt_partial_witness *pw, const p2mt_target *verifier_data_target,
+                                     const p2mt_circuit_data *inner);
 /* intermediates of the last prove (parity tests): 0 wires [135][n], 1 Z | partial products [20][n] (values), 2 quotient chunks
  * [16][n] (coefficients), 3 challenges {betas[2], gammas[2], alphas[2], zeta[2]}, 4 public_inputs_hash [4] */
 int p2mt_circuit_prove_trace(const p2mt_circuit_data *c, int what, uint64_t *out);

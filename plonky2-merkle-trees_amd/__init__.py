@@ -13,7 +13,7 @@ from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_ba
 from . import circuit, commit, distributed, fri, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion, plonk, synthetic
 from .circuit import CircuitBuilder, CircuitData, PartialWitness, prove_many
 from .mmr_plonky2_verifier import verify_mmr_proof_circuit
-from .mmr_plonky2_verifier_1_recursion import verify_inner_merkle_proof_circuit
+from .mmr_plonky2_verifier_1_recursion import complete_verification_circuit_with_inner_proof, verify_inner_merkle_proof_circuit
 from .commit import MerkleCapTree, PolynomialBatch, coset_lde, fft, ifft
 from .distributed import ShardedMMR
 from .fri import Challenger, FriParams, eval_polys_ext, prove_openings

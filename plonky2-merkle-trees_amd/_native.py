@@ -151,6 +151,11 @@ SIGNATURES = {
     "p2mt_pw_destroy": (C.c_int, [voidp]),
     "p2mt_pw_clear": (C.c_int, [voidp]),
     "p2mt_pw_set_target": (C.c_int, [voidp, C.c_uint64, C.c_uint64]),
+    "p2mt_cb_add_virtual_proof_with_pis": (C.c_int, [voidp, voidp, voidp, C.c_size_t]),
+    "p2mt_cb_add_virtual_verifier_data": (C.c_int, [voidp, C.c_uint, voidp]),
+    "p2mt_cb_verify_proof": (C.c_int, [voidp, voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_pw_set_proof_with_pis_target": (C.c_int, [voidp, voidp, voidp, C.c_size_t]),
+    "p2mt_pw_set_verifier_data_target": (C.c_int, [voidp, voidp, voidp]),
     "p2mt_circuit_generate_witness": (C.c_int, [voidp, voidp, voidp]),
     "p2mt_circuit_prove": (C.c_int, [voidp, voidp, voidp, C.c_size_t]),
     "p2mt_circuit_prove_trace": (C.c_int, [voidp, C.c_int, voidp]),

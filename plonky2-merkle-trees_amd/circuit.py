@@ -11,8 +11,8 @@ from . import _native as N
 class CircuitInfo(C.Structure):
     _fields_ = [("degree_bits", C.c_uint32), ("num_gate_types", C.c_uint32), ("num_selectors", C.c_uint32),
                 ("num_constants_sigmas", C.c_uint32), ("num_public_inputs", C.c_uint32),
-                ("num_partial_products", C.c_uint32), ("gate_counts", C.c_uint32 * 5), ("gate_kinds", C.c_uint32 * 5),
-                ("gate_selector", C.c_uint32 * 5), ("group_start", C.c_uint32 * 5), ("group_end", C.c_uint32 * 5),
+                ("num_partial_products", C.c_uint32), ("gate_counts", C.c_uint32 * 16), ("gate_kinds", C.c_uint32 * 16),
+                ("gate_selector", C.c_uint32 * 16), ("group_start", C.c_uint32 * 16), ("group_end", C.c_uint32 * 16),
                 ("proof_len", C.c_uint64), ("fri_proof_len", C.c_uint64)]
 
 
@@ -109,11 +109,47 @@ class CircuitBuilder:
     def num_gates(self):
         return N.lib().p2mt_cb_num_gates(self._h)
 
+    # ---- recursion (mmr_plonky2_verifier_1_recursion.rs:95-104): plonky2's in-circuit verifier
+    def add_virtual_proof_with_pis(self, inner_circuit_data):
+        """builder.add_virtual_proof_with_pis(&inner.common) -> ProofWithPublicInputsTarget"""
+        n = inner_circuit_data.info.proof_len
+        out = np.zeros(n, np.uint64)
+        N.check(N.lib().p2mt_cb_add_virtual_proof_with_pis(self._h, inner_circuit_data._h, N.ptr(out), n))
+        return ProofWithPublicInputsTarget([int(t) for t in out], inner_circuit_data.info.num_public_inputs)
+
+    def add_virtual_verifier_data(self, cap_height):
+        """builder.add_virtual_verifier_data(cap_height) -> VerifierCircuitTarget"""
+        out = np.zeros(68, np.uint64)
+        N.check(N.lib().p2mt_cb_add_virtual_verifier_data(self._h, cap_height, N.ptr(out)))
+        return VerifierCircuitTarget([int(t) for t in out])
+
+    def verify_proof(self, proof_with_pis, inner_verifier_data, inner_circuit_data):
+        """builder.verify_proof::<PoseidonGoldilocksConfig>(&proof_with_pis, &inner_verifier_data, &inner.common)"""
+        pt, vd = _targets(proof_with_pis.targets), _targets(inner_verifier_data.targets)
+        N.check(N.lib().p2mt_cb_verify_proof(self._h, N.ptr(pt), pt.size, N.ptr(vd), inner_circuit_data._h))
+
     def build(self):
         """builder.build::<PoseidonGoldilocksConfig>()"""
         h = C.c_void_p()
         N.check(N.lib().p2mt_cb_build(self._h, C.byref(h)))
         return CircuitData(h)
+
+
+class ProofWithPublicInputsTarget:
+    """One target per word of a proof of the inner circuit (the order CircuitData.prove writes); public_inputs = the last ones."""
+
+    def __init__(self, targets, num_public_inputs):
+        self.targets = targets
+        self.public_inputs = targets[len(targets) - num_public_inputs:]
+
+
+class VerifierCircuitTarget:
+    """constants_sigmas_cap (16 HashOutTargets) and circuit_digest (1 HashOutTarget), flat"""
+
+    def __init__(self, targets):
+        self.targets = targets
+        self.constants_sigmas_cap = [targets[4 * i:4 * i + 4] for i in range(16)]
+        self.circuit_digest = targets[64:68]
 
 
 class PartialWitness:
@@ -136,6 +172,17 @@ class PartialWitness:
         for t, v in zip(targets, value):
             self.set_target(t, v)
 
+    def set_proof_with_pis_target(self, proof_target, proof):
+        """pw.set_proof_with_pis_target(&target, &proof) (mmr_plonky2_verifier_1_recursion.rs:201)"""
+        pt, words = _targets(proof_target.targets), N.as_u64(proof).reshape(-1)
+        assert pt.size == words.size, "proof does not match its target"
+        N.check(N.lib().p2mt_pw_set_proof_with_pis_target(self._h, N.ptr(pt), N.ptr(words), words.size))
+
+    def set_verifier_data_target(self, verifier_data_target, inner_circuit_data):
+        """pw.set_verifier_data_target(&target, &inner.verifier_only) (:202)"""
+        vd = _targets(verifier_data_target.targets)
+        N.check(N.lib().p2mt_pw_set_verifier_data_target(self._h, N.ptr(vd), inner_circuit_data._h))
+
 
 class _ProverOnly:
     def __init__(self, public_inputs):
@@ -153,6 +200,8 @@ class CircuitData:
         N.check(N.lib().p2mt_circuit_public_inputs(self._h, N.ptr(pis)))
         self.prover_only = _ProverOnly([int(t) for t in pis[:self.info.num_public_inputs]])
         self.degree_bits = self.info.degree_bits
+        self.common = self          # `inner_circuit_data.common` / `.verifier_only`: the handle itself carries both
+        self.verifier_only = self
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

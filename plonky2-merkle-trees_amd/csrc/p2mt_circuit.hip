@@ -15,6 +15,8 @@
 //          verify: transcript and Merkle paths (k_verify_merkle) here, the field arithmetic in p2mt_verify_host.hip.
 // Nothing here is GEMM-shaped: 64-bit modular arithmetic on the integer VALU, latency-bound at these sizes (64..4096 rows).
 #include "tree_common.hip.h"
+#include "circuit_types.h"
+#include "gates_recursion.hip.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -29,53 +31,15 @@
 #include <vector>
 
 using namespace p2mt_dev;
+using namespace p2mt_cb;
 using p2mt::rt;
 
 namespace {
 
-// CircuitConfig::standard_recursion_config() (mmr_plonky2_verifier.rs:30)
-constexpr u32 kNumWires = 135, kNumRouted = 80, kNumConsts = 2, kNumCh = 2, kQF = 8, kRateBits = 3, kCapHeight = 4;
-constexpr u32 kNumChunks = (kNumRouted + kQF - 1) / kQF, kNumProds = kNumChunks - 1, kNumOps = kNumRouted / 4;
-constexpr u32 kNumZs = kNumCh * (1 + kNumProds), kNumQuot = kNumCh * kQF, kNumGateConstraints = 123;
-enum { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_POSEIDON, G_KINDS };
-// plonky2 sorts the gate types by (degree, id): Noop(0) < Constant(1) < PublicInput(1) < Arithmetic(3) < Poseidon(7), which
-// is the enum order
-constexpr u32 kGateDegree[G_KINDS] = {0, 1, 1, 3, 7};
-constexpr u64 kWireFlag = 1ull << 63, kUnusedSelector = 0xFFFFFFFFull;
-constexpr u32 kNoSlot = 0xFFFFFFFFu;  // a wire nothing reads: no entry in the value table
-
-inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
-inline u64 h_add(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % gl::P); }
-inline u64 h_pow(u64 a, u64 e) {
-  u64 r = 1;
-  for (; e; e >>= 1, a = h_mul(a, a))
-    if (e & 1) r = h_mul(r, a);
-  return r;
-}
-inline u64 h_root_of_unity(unsigned log_n) {
-  u64 g = h_pow(7, (gl::P - 1) >> 32);
-  for (unsigned i = log_n; i < 32; ++i) g = h_mul(g, g);
-  return g;
-}
-
-inline u64 wire_t(u32 row, u32 col) { return kWireFlag | ((u64)row << 8) | col; }
-inline bool is_wire(u64 t) { return (t & kWireFlag) != 0; }
-inline u32 wire_row(u64 t) { return (u32)((t & ~kWireFlag) >> 8); }
-inline u32 wire_col(u64 t) { return (u32)(t & 0xFF); }
-
-struct GateInst {
-  int kind;
-  u64 c[2];
-};
-enum { GEN_POSEIDON = 0, GEN_ARITH = 1, GEN_EQUALITY = 2, GEN_CONST = 3 };
-struct Gen {
-  int kind;
-  u32 row, i;
-  u64 c0, c1;
-  u64 x, y, eq, inv;  // EqualityGenerator targets
-};
-
-// one generator as the device interpreter sees it (slots index the value table)
+// one generator as the device interpreter sees it.  GEN_POSEIDON / GEN_ARITH / GEN_EQUALITY: a, b, c, out, out2 are value slots
+// (GEN_POSEIDON: a = row, b = index into pslots).  The generators of the recursion gates are tied to one gate row: a = row,
+// b = operation / copy index, slots come from the dense wire -> slot table; GEN_QUOTIENT_EXT / GEN_WIRE_SPLIT: a = offset of
+// their slot list in the argument array, b = its length.
 struct WOp {
   u32 kind, a, b, c, out, out2;
   u64 c0, c1;
@@ -83,26 +47,14 @@ struct WOp {
 
 }  // namespace
 
-struct p2mt_circuit_builder {
-  u64 n_virtual = 0;
-  std::vector<GateInst> gates;
-  std::vector<std::pair<u64, u64>> copies;
-  std::vector<Gen> gens;
-  std::map<u64, u64> const_to_target;  // iterated in increasing canonical order at build()
-  std::unordered_map<u64, u64> target_to_const;
-  std::map<std::tuple<u64, u64, u64, u64, u64>, u64> arith_results;
-  std::map<std::pair<u64, u64>, std::pair<u32, u32>> slots;  // (c0, c1) -> (row, next free operation)
-  std::vector<u64> public_inputs;
-  bool built = false;  // build() consumes the builder, as plonky2's does
-};
-
 struct p2mt_partial_witness {
   std::vector<std::pair<u64, u64>> sets;  // (target, canonical value), in call order
 };
 
 struct p2mt_circuit_data {
   u32 degree_bits = 0, n = 0, num_selectors = 0, n_kinds = 0, n_cs = 0, n_slots = 0, n_pi = 0, n_act = 0;
-  u32 kind[G_KINDS] = {}, sel[G_KINDS] = {}, gs[G_KINDS] = {}, ge[G_KINDS] = {}, counts[G_KINDS] = {};
+  u32 kind[kMaxGateTypes] = {}, sel[kMaxGateTypes] = {}, gs[kMaxGateTypes] = {}, ge[kMaxGateTypes] = {}, counts[kMaxGateTypes] = {};
+  bool has_recursion_gates = false;  // any gate type beyond Noop / Constant / PublicInput / Arithmetic / Poseidon
   u64 n_virtual = 0;
   std::vector<Gen> gens;
   std::vector<u64> public_inputs;
@@ -123,10 +75,12 @@ struct p2mt_circuit_data {
   u64 *d_z_vals = nullptr, *d_z_coeffs = nullptr, *d_z_lde = nullptr, *d_z_leaves = nullptr, *d_z_dig = nullptr, *d_pp_q = nullptr;
   u64 *d_q_vals = nullptr, *d_q_coeffs = nullptr, *d_q_lde = nullptr, *d_q_leaves = nullptr, *d_q_dig = nullptr;
   u64 *d_head = nullptr, *d_open = nullptr, *d_chal = nullptr, *d_kis = nullptr, *d_vals = nullptr, *d_init = nullptr;
+  u64* d_q_extra = nullptr;  // [kNumCh][8n]: the recursion gates' share of the vanishing polynomial (k_quotient_extra)
   u32 *d_set = nullptr, *d_wire_slot = nullptr, *d_pi_slot = nullptr, *d_lvl = nullptr, *d_pslots = nullptr, *d_prows = nullptr;
+  u32 *d_slot_tab = nullptr, *d_args = nullptr, *d_sync = nullptr;  // dense wire -> slot table; slot lists of free-standing generators; grid barrier
   WOp* d_ops = nullptr;
   int* d_err = nullptr;  // [0] witness conflict (op index + 1, or -1 unset public input), [1] zero denominator
-  size_t init_cap = 0, ops_cap = 0, lds_bytes = 0;  // lds_bytes != 0: the value table fits LDS (k_witness_lds)
+  size_t init_cap = 0, ops_cap = 0, args_cap = 0, lds_bytes = 0;  // lds_bytes != 0: the value table fits LDS (k_witness_lds)
   p2mt_challenger* ch = nullptr;
   // verifier scratch (allocated on the first p2mt_circuit_verify)
   u64* d_verify = nullptr;
@@ -137,9 +91,9 @@ struct p2mt_circuit_data {
   u64 k_is[kNumRouted] = {};
 };
 
-namespace {
-
 // ------------------------------------------------------------------------------------------------ builder (host)
+namespace p2mt_cb {
+
 int cb_check(const p2mt_circuit_builder* b, u64 t, bool routable) {
   if (is_wire(t)) {
     if (wire_row(t) >= b->gates.size() || wire_col(t) >= kNumWires || (t & ~kWireFlag) >> 40) return p2mt::fail(P2MT_EINVAL, "circuit: bad wire target");
@@ -165,9 +119,46 @@ int cb_connect(p2mt_circuit_builder* b, u64 x, u64 y) {
   b->copies.emplace_back(x, y);
   return P2MT_OK;
 }
-u32 cb_add_gate(p2mt_circuit_builder* b, int kind, u64 c0 = 0, u64 c1 = 0) {
+u32 cb_add_gate(p2mt_circuit_builder* b, int kind, u64 c0, u64 c1) {
   b->gates.push_back(GateInst{kind, {c0, c1}});
-  return (u32)b->gates.size() - 1;
+  const u32 row = (u32)b->gates.size() - 1;
+  // Gate::extra_constant_wires: routed wires that can carry a constant; build() hands them out before adding ConstantGates
+  if (kind == G_RANDOM_ACCESS)
+    for (u32 k = 0; k < kRaExtra; ++k) b->constant_generators.push_back({row, k, 72 + k});
+  else if (kind == G_CONSTANT)
+    for (u32 k = 0; k < kNumConsts; ++k) b->constant_generators.push_back({row, k, k});
+  // Gate::generators of the gates whose generator covers the whole row (per-operation generators are added where the slot is
+  // taken: build() drops the generators of unused slots, circuit_builder.rs "Remove unused generators, if any")
+  int gk = -1;
+  switch (kind) {
+    case G_BASE_SUM: gk = GEN_BASE_SPLIT; break;
+    case G_REDUCING: gk = GEN_REDUCING; break;
+    case G_REDUCING_EXT: gk = GEN_REDUCING_EXT; break;
+    case G_COSET_INTERPOLATION: gk = GEN_INTERPOLATION; break;
+    case G_POSEIDON_MDS: gk = GEN_POSEIDON_MDS; break;
+    default: break;
+  }
+  if (gk >= 0) {
+    Gen g{};
+    g.kind = gk;
+    g.row = row;
+    b->gens.push_back(g);
+  }
+  return row;
+}
+// circuit_builder.rs find_slot: the next free operation of a multi-operation gate with these parameters
+void cb_find_slot(p2mt_circuit_builder* b, int kind, u64 p0, u64 p1, u32 num_ops, u32* row, u32* i) {
+  const auto key = std::make_tuple(kind, p0, p1);
+  auto sl = b->slots.find(key);
+  if (sl != b->slots.end()) {
+    *row = sl->second.first;
+    *i = sl->second.second;
+  } else {
+    *row = cb_add_gate(b, kind, p0, p1);
+    *i = 0;
+  }
+  if (*i == num_ops - 1) b->slots.erase(key);
+  else b->slots[key] = std::make_pair(*row, *i + 1);
 }
 // gadgets/arithmetic.rs arithmetic(): const_0 * m0 * m1 + const_1 * addend
 int cb_arithmetic(p2mt_circuit_builder* b, u64 c0, u64 c1, u64 m0, u64 m1, u64 ad, u64* out) {
@@ -214,18 +205,8 @@ int cb_arithmetic(p2mt_circuit_builder* b, u64 c0, u64 c1, u64 m0, u64 m1, u64 a
     *out = hit->second;
     return P2MT_OK;
   }
-  const auto key = std::make_pair(c0, c1);
   u32 row, i;
-  auto sl = b->slots.find(key);
-  if (sl != b->slots.end()) {
-    row = sl->second.first;
-    i = sl->second.second;
-  } else {
-    row = cb_add_gate(b, G_ARITHMETIC, c0, c1);
-    i = 0;
-  }
-  if (i == kNumOps - 1) b->slots.erase(key);
-  else b->slots[key] = std::make_pair(row, i + 1);
+  cb_find_slot(b, G_ARITHMETIC, c0, c1, kNumOps, &row, &i);
   b->copies.emplace_back(m0, wire_t(row, 4 * i));
   b->copies.emplace_back(m1, wire_t(row, 4 * i + 1));
   b->copies.emplace_back(ad, wire_t(row, 4 * i + 2));
@@ -240,10 +221,10 @@ int cb_arithmetic(p2mt_circuit_builder* b, u64 c0, u64 c1, u64 m0, u64 m1, u64 a
   b->arith_results[op] = *out;
   return P2MT_OK;
 }
-// hash/poseidon.rs permute_swapped with swap = _false(): one PoseidonGate row
-int cb_permute(p2mt_circuit_builder* b, u64 (&state)[12]) {
+// hash/poseidon.rs permute_swapped: one PoseidonGate row
+int cb_permute_swapped(p2mt_circuit_builder* b, u64 (&state)[12], u64 swap) {
   const u32 row = cb_add_gate(b, G_POSEIDON);
-  b->copies.emplace_back(cb_constant(b, 0), wire_t(row, 24));
+  b->copies.emplace_back(swap, wire_t(row, 24));
   for (u32 i = 0; i < 12; ++i) b->copies.emplace_back(state[i], wire_t(row, i));
   Gen g{};
   g.kind = GEN_POSEIDON;
@@ -259,11 +240,38 @@ int cb_hash_no_pad(p2mt_circuit_builder* b, const u64* in, size_t n, u64* out) {
   for (auto& s : state) s = zero;
   for (size_t off = 0; off < n; off += 8) {
     for (size_t k = 0; k < 8 && off + k < n; ++k) state[k] = in[off + k];
-    P2MT_TRY(cb_permute(b, state));
+    P2MT_TRY(cb_permute_swapped(b, state, zero));  // swap = _false()
   }
   for (int k = 0; k < 4; ++k) out[k] = state[k];
   return P2MT_OK;
 }
+int cb_is_equal(p2mt_circuit_builder* b, u64 x, u64 y, u64* out) {
+  P2MT_TRY(cb_check(b, x, true));
+  P2MT_TRY(cb_check(b, y, true));
+  const u64 zero = cb_constant(b, 0), one = cb_constant(b, 1);
+  const u64 equal = cb_virtual(b);
+  u64 not_equal, diff, not_equal_check, diff_normalized;
+  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, one, one, equal, &not_equal));
+  const u64 inv = cb_virtual(b);
+  Gen g{};
+  g.kind = GEN_EQUALITY;
+  g.x = x;
+  g.y = y;
+  g.eq = equal;
+  g.inv = inv;
+  b->gens.push_back(g);
+  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, x, one, y, &diff));
+  P2MT_TRY(cb_arithmetic(b, 1, 0, diff, inv, diff, &not_equal_check));
+  P2MT_TRY(cb_arithmetic(b, 1, 0, diff, equal, diff, &diff_normalized));
+  P2MT_TRY(cb_connect(b, diff_normalized, zero));
+  P2MT_TRY(cb_connect(b, not_equal, not_equal_check));
+  *out = equal;
+  return P2MT_OK;
+}
+
+}  // namespace p2mt_cb
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------ witness fill (device)
 GL_DEV u64 ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -288,6 +296,22 @@ GL_DEV u64 gl_inv(u64 x) {
   const u64 t31 = gl::mul(gl::sqr(t30), x);
   const u64 t32 = gl::mul(gl::sqr(t31), x);
   return gl::mul(sqn(t31, 33), t32);
+}
+
+// quadratic extension F[X]/(X^2 - 7) on loose u64 pairs
+struct DE {
+  u64 a, b;
+};
+GL_DEV DE de_add(DE x, DE y) { return DE{gl::add(x.a, y.a), gl::add(x.b, y.b)}; }
+GL_DEV DE de_sub(DE x, DE y) { return DE{fsub(x.a, y.a), fsub(x.b, y.b)}; }
+GL_DEV DE de_mul(DE x, DE y) {
+  return DE{gl::mul_add(gl::mul(x.b, y.b), 7, gl::mul(x.a, y.a)), gl::mul_add(x.a, y.b, gl::mul(x.b, y.a))};
+}
+GL_DEV DE de_scale(DE x, u64 c) { return DE{gl::mul(x.a, c), gl::mul(x.b, c)}; }
+GL_DEV DE de_inv(DE x) {  // (a - bX) / (a^2 - 7 b^2)
+  const u64 n = gl::canon(fsub(gl::sqr(x.a), gl::mul(gl::sqr(x.b), 7)));
+  const u64 ni = gl_inv(n);
+  return DE{gl::mul(x.a, ni), gl::mul(fsub(0, x.b), ni)};
 }
 
 // Where the value table lives while the generators run: global memory (any circuit size; agent-scope accesses so that
@@ -338,6 +362,162 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
   set[slot] = 1;
 }
 
+// The generators of the recursion gates (one lane each).  tab: dense wire -> slot table [row * 135 + col]; args: the slot lists of
+// the generators that are not tied to a gate row.  What each computes is the gate's own generator in plonky2:
+// ArithmeticExtensionGenerator, MulExtensionGenerator, QuotientGeneratorExtension, ReducingGenerator (both gates),
+// WireSplitGenerator, BaseSplitGenerator<2>, RandomAccessGenerator, InterpolationGenerator, PoseidonMdsGenerator.
+template <typename Mem>
+GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
+                                    int* err) {
+  const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
+  auto G = [&](u32 col) { return m.get(S[col]); };
+  auto GE = [&](u32 col) { return DE{m.get(S[col]), m.get(S[col + 1])}; };
+  auto PE = [&](u32 col, DE v) {
+    put(m, S[col], v.a, err, o);
+    put(m, S[col + 1], v.b, err, o);
+  };
+  switch (op.kind) {
+    case GEN_ARITH_EXT: {
+      const u32 at = 8 * op.b;
+      PE(at + 6, de_add(de_scale(de_mul(GE(at), GE(at + 2)), op.c0), de_scale(GE(at + 4), op.c1)));
+      break;
+    }
+    case GEN_MUL_EXT: {
+      const u32 at = 6 * op.b;
+      PE(at + 4, de_scale(de_mul(GE(at), GE(at + 2)), op.c0));
+      break;
+    }
+    case GEN_QUOTIENT_EXT: {
+      const u32* A = args + op.a;
+      const DE num{m.get(A[0]), m.get(A[1])}, den{m.get(A[2]), m.get(A[3])};
+      const DE q = de_mul(num, de_inv(den));
+      put(m, A[4], q.a, err, o);
+      put(m, A[5], q.b, err, o);
+      break;
+    }
+    case GEN_REDUCING: {
+      const DE alpha = GE(2);
+      DE acc = GE(4);
+#pragma unroll 1
+      for (u32 i = 0; i < kReducingCoeffs; ++i) {
+        acc = de_mul(acc, alpha);
+        acc.a = gl::add(acc.a, G(6 + i));
+        acc.a = gl::canon(acc.a), acc.b = gl::canon(acc.b);
+        PE(i == kReducingCoeffs - 1 ? 0 : 6 + kReducingCoeffs + 2 * i, acc);
+      }
+      break;
+    }
+    case GEN_REDUCING_EXT: {
+      const DE alpha = GE(2);
+      DE acc = GE(4);
+#pragma unroll 1
+      for (u32 i = 0; i < kReducingExtCoeffs; ++i) {
+        acc = de_add(de_mul(acc, alpha), GE(6 + 2 * i));
+        acc.a = gl::canon(acc.a), acc.b = gl::canon(acc.b);
+        PE(i == kReducingExtCoeffs - 1 ? 0 : 6 + 2 * kReducingExtCoeffs + 2 * i, acc);
+      }
+      break;
+    }
+    case GEN_WIRE_SPLIT: {  // args: integer, then the sum wires of the BaseSumGates, low limbs first
+      const u32* A = args + op.a;
+      u64 v = gl::canon(m.get(A[0]));
+      for (u32 k = 1; k < op.b; ++k) {
+        put(m, A[k], v & ((1ull << kBaseSumLimbs) - 1), err, o);
+        v >>= kBaseSumLimbs;
+      }
+      if (v) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in the BaseSumGates"
+      break;
+    }
+    case GEN_BASE_SPLIT: {
+      const u64 v = gl::canon(G(0));
+      if (v >> kBaseSumLimbs) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in given number of limbs"
+#pragma unroll 1
+      for (u32 j = 0; j < kBaseSumLimbs; ++j) put(m, S[1 + j], (v >> j) & 1, err, o);
+      break;
+    }
+    case GEN_RANDOM_ACCESS: {
+      const u32 at = 18 * op.b;
+      const u64 idx = gl::canon(G(at));
+      if (idx >= 16) {
+        atomicCAS(err, 0, (int)o + 1);  // "Access index is larger than the vector size"
+        break;
+      }
+      put(m, S[at + 1], G(at + 2 + (u32)idx), err, o);
+      for (u32 j = 0; j < kRaBits; ++j) put(m, S[74 + kRaBits * op.b + j], (idx >> j) & 1, err, o);
+      break;
+    }
+    case GEN_INTERPOLATION: {
+      const DE point = GE(33);
+      const DE x = de_scale(point, gl_inv(gl::canon(G(0))));  // shifted_evaluation_point = evaluation_point / shift
+      PE(45, x);
+      DE ev{0, 0}, pr{1, 0};
+      auto partial = [&](int from, int to) {
+#pragma unroll 1
+        for (int i = from; i < to; ++i) {
+          const DE term{gl::sub_c(x.a, gates_rec::kCosetDomainDev[i]), x.b};
+          const DE weighted = de_scale(GE(1 + 2 * i), gates_rec::kCosetWeightsDev[i]);
+          ev = de_add(de_mul(ev, term), de_mul(weighted, pr));
+          pr = de_mul(pr, term);
+        }
+      };
+      partial(0, 6);
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) {
+        ev.a = gl::canon(ev.a), ev.b = gl::canon(ev.b), pr.a = gl::canon(pr.a), pr.b = gl::canon(pr.b);
+        PE(37 + 2 * i, ev);
+        PE(41 + 2 * i, pr);
+        const int start = 1 + 5 * (i + 1);
+        partial(start, start + 5 < 16 ? start + 5 : 16);
+      }
+      PE(35, ev);
+      break;
+    }
+    case GEN_POSEIDON_MDS: {
+#pragma unroll 1
+      for (u32 r = 0; r < 12; ++r) {
+        DE acc = r == 0 ? de_scale(GE(0), 8) : DE{0, 0};
+#pragma unroll 1
+        for (u32 i = 0; i < 12; ++i) {
+          const u32 src = i + r >= 12 ? i + r - 12 : i + r;
+          acc = de_add(acc, de_scale(GE(2 * src), gates_rec::mds_circ((int)i)));
+        }
+        PE(24 + 2 * r, acc);
+      }
+      break;
+    }
+    default: break;
+  }
+}
+
+// ArithmeticBaseGenerator / EqualityGenerator (slots in the record itself) or one of the generators above
+template <typename Mem>
+GL_DEV void run_lane_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args, int* err) {
+  if (op.kind == GEN_ARITH) {
+    const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
+    put(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
+  } else if (op.kind == GEN_EQUALITY) {
+    const u64 x = m.get(op.a), y = m.get(op.b);
+    put(m, op.out, x == y ? 1 : 0, err, o);
+    put(m, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
+  } else {
+    run_recursion_generator(m, op, o, tab, args, err);
+  }
+}
+
+// PoseidonGenerator on one wavefront (lane w < 12 owns state word w): reads the 12 inputs and the swap bit, writes the 12 outputs.
+// ps: this lane's slot among the row's wires 0..24 (lane < 25).
+template <typename Mem>
+GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, int* err, const PermCtx& ctx) {
+  const u32 swap_slot = __shfl(ps, 24), out_slot = __shfl(ps, (lane + 12) & 31);
+  u64 x = lane < 12 ? m.get(ps) : 0;
+  const u64 swap = m.get(swap_slot);
+  const u64 partner = __shfl_xor((unsigned long long)x, 4);
+  if (lane < 4) x = gl::add(x, gl::mul(swap, fsub(partner, x)));       // the permutation runs on the swapped state
+  else if (lane < 8) x = fsub(x, gl::mul(swap, fsub(x, partner)));
+  x = permute_wave(x, ctx);  // outputs only: the row's delta / S-box wires are filled afterwards (k_poseidon_rows)
+  if (lane < 12) put(m, out_slot, x, err, o);
+}
+
 // One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
 // and puts the PoseidonGate rows first).  PoseidonGenerator: one wavefront per row, lane w < 12 owns state word w.
 // The PoseidonGate's non-routed wires (delta and S-box inputs: 110 of the row's 135) are never read by a generator nor
@@ -346,7 +526,8 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
 // the recording hook, once the wire matrix holds the rows' inputs.
 template <typename Mem>
 GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                       const u32* __restrict__ pslots, u64* __restrict__ wires, u32 log_n, int* err, const PermCtx& ctx) {
+                       const u32* __restrict__ pslots, const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
+                       const PermCtx& ctx) {
   // A level should cost its LDS reads, its arithmetic and a barrier, not a chain of global-memory round trips: the level
   // bounds sit in LDS (when they fit), the generator records are staged into LDS a chunk of whole levels at a time (one
   // exposed load latency per <= 512 generators instead of one per level), and each wavefront's PoseidonGate row for level
@@ -376,58 +557,37 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
     ch_begin = s;
     ch_end = end;
   };
-  auto lookup = [&](u32 l, u32& row, u32& ps) {  // this wavefront's first PoseidonGate row of level l
+  auto lookup = [&](u32 l, u32& ps) {  // this wavefront's first PoseidonGate row of level l
     const u32 s = L[2 * l], np = L[2 * l + 1];
     if (wave < np) {
       const WOp po = OP(s + wave);
-      row = po.a;
       ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;
     }
   };
-  u32 cur_row = 0, cur_ps = 0, nxt_row = 0, nxt_ps = 0;
+  u32 cur_ps = 0, nxt_ps = 0;
   if (n_levels) {
     stage(0);
-    lookup(0, cur_row, cur_ps);
+    lookup(0, cur_ps);
   }
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 s = L[2 * l], np = L[2 * l + 1], e = L[2 * l + 2];
-    if (l + 1 < n_levels && L[2 * (l + 1) + 2] <= ch_end) lookup(l + 1, nxt_row, nxt_ps);  // else: after the next staging
+    if (l + 1 < n_levels && L[2 * (l + 1) + 2] <= ch_end) lookup(l + 1, nxt_ps);  // else: after the next staging
     for (u32 o = s + wave; o < s + np; o += n_waves) {  // wave-uniform
-      u32 row = cur_row, ps = cur_ps;
+      u32 ps = cur_ps;
       if (o != s + wave) {  // more PoseidonGate rows in this level than wavefronts
         const WOp po = OP(o);
-        row = po.a;
         ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;
       }
-      const u32 swap_slot = __shfl(ps, 24), out_slot = __shfl(ps, (lane + 12) & 31);
-      (void)row;
-      u64 x = lane < 12 ? m.get(ps) : 0;
-      const u64 swap = m.get(swap_slot);
-      const u64 partner = __shfl_xor((unsigned long long)x, 4);
-      if (lane < 4) x = gl::add(x, gl::mul(swap, fsub(partner, x)));       // the permutation runs on the swapped state
-      else if (lane < 8) x = fsub(x, gl::mul(swap, fsub(x, partner)));
-      x = permute_wave(x, ctx);  // outputs only: the row's delta / S-box wires are filled afterwards (k_poseidon_rows)
-      if (lane < 12) put(m, out_slot, x, err, o);
+      run_poseidon_generator(m, ps, lane, o, err, ctx);
     }
-    for (u32 o = s + np + tid; o < e; o += kBlock) {
-      const WOp op = OP(o);
-      if (op.kind == GEN_ARITH) {
-        const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
-        put(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
-      } else {  // EqualityGenerator
-        const u64 x = m.get(op.a), y = m.get(op.b);
-        put(m, op.out, x == y ? 1 : 0, err, o);
-        put(m, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
-      }
-    }
+    for (u32 o = s + np + tid; o < e; o += kBlock) run_lane_generator(m, OP(o), o, tab, args, err);
     m.sync();
     if (l + 1 < n_levels) {
       if (L[2 * (l + 1) + 2] <= ch_end) {
-        cur_row = nxt_row;
         cur_ps = nxt_ps;
       } else {
         stage(l + 1);
-        lookup(l + 1, cur_row, cur_ps);
+        lookup(l + 1, cur_ps);
       }
     }
   }
@@ -435,10 +595,60 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
 
 __global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
                                                         u64* vals, u32* set, const u32* __restrict__ pslots,
-                                                        u64* __restrict__ wires, u32 log_n, int* err, PermCtx ctx) {
+                                                        const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
+                                                        PermCtx ctx) {
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
-  run_levels(GMem{vals, set}, ops, lvl, n_levels, pslots, wires, log_n, err, ctx);
+  run_levels(GMem{vals, set}, ops, lvl, n_levels, pslots, tab, args, err, ctx);
+}
+
+// The same interpreter spread over the whole grid, for circuits with wide levels (the recursion's outer circuit: 28 FRI query
+// rounds side by side, each a chain of PoseidonGate rows).  Every level: the PoseidonGate rows go one per wavefront over ALL
+// wavefronts of the grid, the other generators one per lane over all lanes; then a grid-wide barrier.  The barrier is a counter
+// in global memory: one lane per workgroup adds 1 and waits until every workgroup of this level has (counter >= (level + 1) *
+// gridDim.x).  Every workgroup must be resident for this to terminate, so the launch uses at most kGridBlocks workgroups
+// (far below what the device holds); as a last resort a wait that exceeds its spin budget raises err[2] and every workgroup
+// leaves its loop -- a hung launch is never left behind.
+constexpr u32 kGridBlocks = 64, kGridSpinBudget = 1u << 24;
+__global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                                                         u64* vals, u32* set, const u32* __restrict__ pslots,
+                                                         const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
+                                                         u32* sync, PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  __shared__ int abort_flag;
+  ctx = stage_round_constants(rc_lds, ctx);
+  const GMem m{vals, set};
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = kBlock / 64;
+  const u32 gwave = blockIdx.x * waves_per_block + wave, n_gwaves = gridDim.x * waves_per_block;
+  const u32 gtid = blockIdx.x * kBlock + tid, n_gthreads = gridDim.x * kBlock;
+  if (tid == 0) abort_flag = 0;
+  __syncthreads();
+  for (u32 l = 0; l < n_levels; ++l) {
+    const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
+    for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
+      const u32 ps = lane < 25 ? pslots[(size_t)ops[o].b * 32 + lane] : 0;
+      run_poseidon_generator(m, ps, lane, o, err, ctx);
+    }
+    for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
+    // grid-wide barrier
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const u32 target = (l + 1) * gridDim.x;
+      atomicAdd(sync, 1u);
+      u32 spins = 0;
+      while (ld32(sync) < target) {
+        if (ld32(reinterpret_cast<const u32*>(err) + 2) != 0 || ++spins > kGridSpinBudget) {
+          atomicExch(err + 2, 1);
+          abort_flag = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (abort_flag) return;  // block-uniform
+  }
 }
 
 // The whole witness fill in one launch with the value table in LDS: initial assignments, generator levels, and
@@ -448,6 +658,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
                                                         const u32* __restrict__ pslots, const u32* __restrict__ wire_slot, u32 n_act,
                                                         u32 log_n, u64* __restrict__ wires,
                                                         const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
+                                                        const u32* __restrict__ tab, const u32* __restrict__ args,
                                                         int* err, PermCtx ctx) {
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
@@ -455,11 +666,11 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
   const LMem m{sh, reinterpret_cast<uint8_t*>(sh + n_slots)};
   for (u32 k = threadIdx.x; k < n_slots; k += kBlock) m.set[k] = 0;
   for (u32 t = threadIdx.x; t < (kNumWires << log_n); t += kBlock) wires[t] = 0;  // wires nothing sets are zero
-  if (threadIdx.x < 2) err[threadIdx.x] = 0;
+  if (threadIdx.x < 3) err[threadIdx.x] = 0;
   __syncthreads();
   for (u32 k = threadIdx.x; k < n_pairs; k += kBlock) m.store((u32)pairs[2 * k], pairs[2 * k + 1]);
   __syncthreads();
-  run_levels(m, ops, lvl, n_levels, pslots, wires, log_n, err, ctx);
+  run_levels(m, ops, lvl, n_levels, pslots, tab, args, err, ctx);
   // full_witness: only the wires that own a slot (list of (wire index, slot) pairs); everything else was zero-filled before
   // the launch or written by the PoseidonGate rows above
   for (u32 k = threadIdx.x; k < n_act; k += kBlock) {
@@ -524,7 +735,7 @@ __global__ __launch_bounds__(kBlock) void k_poseidon_rows(const u32* __restrict_
 // ------------------------------------------------------------------------------------------------ quotient (device)
 struct QDesc {
   u32 log_n, n_kinds, num_selectors, n_cs;
-  u32 kind[G_KINDS], sel[G_KINDS], gs[G_KINDS], ge[G_KINDS];
+  u32 kind[kMaxGateTypes], sel[kMaxGateTypes], gs[kMaxGateTypes], ge[kMaxGateTypes];
   u64 zh[kQF], zh_inv[kQF];  // Z_H(x_i) = 7^n w_8^(i mod 8) - 1 and its inverse
   u64 n_inv, w_big;
 };
@@ -543,7 +754,8 @@ constexpr u32 kNumTerms = kNumCh + kNumCh * kNumChunks + kNumGateConstraints;
 __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
                                                   const u64* __restrict__ zl, const u64* __restrict__ pi_hash,
                                                   const u64* __restrict__ chal, const u64* __restrict__ k_is,
-                                                  const u64* __restrict__ rc, u64* __restrict__ qvals) {
+                                                  const u64* __restrict__ rc, const u64* __restrict__ extra,
+                                                  u64* __restrict__ qvals) {
   __shared__ u64 apow[kNumCh][kNumTerms];
   __shared__ u64 part[4][64][kNumCh];
   const u32 log_big = d.log_n + 3, big = 1u << log_big;
@@ -585,10 +797,15 @@ __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __re
       gacc[c] = 0;
     }
   };
-  int g_of[G_KINDS];  // position of each gate type in the circuit's sorted list, -1 if absent
-#pragma unroll
-  for (u32 k = 0; k < G_KINDS; ++k) g_of[k] = -1;
-  for (u32 g = 0; g < d.n_kinds; ++g) g_of[d.kind[g]] = (int)g;
+  // position of each gate type this kernel evaluates in the circuit's sorted list, -1 if absent (recursion gates: k_quotient_extra)
+  int gp = -1, g_arith = -1, g_const = -1, g_pi = -1;
+  for (u32 g = 0; g < d.n_kinds; ++g) {
+    const u32 k = d.kind[g];
+    if (k == G_POSEIDON) gp = (int)g;
+    else if (k == G_ARITHMETIC) g_arith = (int)g;
+    else if (k == G_CONSTANT) g_const = (int)g;
+    else if (k == G_PUBLIC_INPUT) g_pi = (int)g;
+  }
   const u32 sig0 = d.num_selectors + kNumConsts;
   // partial-product check `idx` = challenge * 10 + chunk (term kNumCh + idx)
   auto pp_check = [&](u32 idx) {
@@ -623,7 +840,6 @@ __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __re
 #pragma unroll
     for (u32 k = 0; k < 12; ++k) s[k] = W(base + k);
   };
-  const int gp = g_of[G_POSEIDON];
   if (role == 0) {
     if (gp >= 0) {
       u64 s[12];
@@ -685,22 +901,22 @@ __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __re
       full_step(s, nullptr, 12, 111);
       close_gate((u32)gp);
     }
-    if (g_of[G_ARITHMETIC] >= 0) {
+    if (g_arith >= 0) {
       const u64 c0 = CS(d.num_selectors), c1 = CS(d.num_selectors + 1);
 #pragma unroll 1
       for (u32 o = 0; o < kNumOps; ++o) {
         const u64 prod = gl::mul(gl::mul(W(4 * o), W(4 * o + 1)), c0);
         G(o, fsub(W(4 * o + 3), gl::mul_add(W(4 * o + 2), c1, prod)));
       }
-      close_gate((u32)g_of[G_ARITHMETIC]);
+      close_gate((u32)g_arith);
     }
-    if (g_of[G_CONSTANT] >= 0) {
+    if (g_const >= 0) {
       for (u32 j = 0; j < kNumConsts; ++j) G(j, gl::sub_c(CS(d.num_selectors + j), W(j)));
-      close_gate((u32)g_of[G_CONSTANT]);
+      close_gate((u32)g_const);
     }
-    if (g_of[G_PUBLIC_INPUT] >= 0) {
+    if (g_pi >= 0) {
       for (u32 j = 0; j < 4; ++j) G(j, gl::sub_c(W(j), pi_hash[j]));
-      close_gate((u32)g_of[G_PUBLIC_INPUT]);
+      close_gate((u32)g_pi);
     }
     {  // L_0(x) (Z_c(x) - 1), L_0(x) = (x^n - 1) / (n (x - 1))
       const u64 x = gl::mul(7, gl::pow(d.w_big, i));
@@ -720,10 +936,75 @@ __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __re
     const u64 zh_inv = d.zh_inv[i & (kQF - 1)];
 #pragma unroll
     for (u32 c = 0; c < kNumCh; ++c) {
-      const u64 sum = gl::add(gl::add(part[0][lane][c], part[1][lane][c]), gl::add(part[2][lane][c], part[3][lane][c]));
+      u64 sum = gl::add(gl::add(part[0][lane][c], part[1][lane][c]), gl::add(part[2][lane][c], part[3][lane][c]));
+      if (extra) sum = gl::add(sum, extra[(size_t)c * big + i]);  // the recursion gates' filtered constraints (k_quotient_extra)
       qvals[(size_t)c * big + i] = gl::canon(gl::mul(sum, zh_inv));
     }
   }
+}
+
+// The gate types of the in-circuit verifier (gates_recursion.hip.h) on the LDE coset: one lane per point evaluates every such gate
+// type present in the circuit, weights constraint j with alpha_c^(22 + j) (the gate constraints follow the 2 + 20 permutation terms),
+// multiplies by the gate's selector filter and leaves the per-challenge sums in extra[c][i] (natural order) for k_quotient to add
+// before the division by Z_H.  ~2 k field multiplications per point -- two orders of magnitude below the PoseidonGate's share.
+struct FBaseDev {
+  typedef u64 T;
+  GL_DEV static T add(T a, T b) { return gl::add(a, b); }
+  GL_DEV static T sub(T a, T b) { return fsub(a, b); }
+  GL_DEV static T mul(T a, T b) { return gl::mul(a, b); }
+  GL_DEV static T mulc(T a, u64 c) { return gl::mul(a, c); }
+  GL_DEV static T addc(T a, u64 c) { return gl::add_c(a, c); }
+  GL_DEV static T subc(T a, u64 c) { return gl::sub_c(a, c); }
+  GL_DEV static T fromc(u64 c) { return c; }
+};
+__global__ __launch_bounds__(kBlock) void k_quotient_extra(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
+                                                           const u64* __restrict__ chal, u64* __restrict__ extra) {
+  __shared__ u64 apow[kNumCh][kNumGateConstraints];
+  const u32 log_big = d.log_n + 3, big = 1u << log_big;
+  for (u32 k = threadIdx.x; k < kNumCh * kNumGateConstraints; k += kBlock) {
+    const u32 c = k / kNumGateConstraints, e = k % kNumGateConstraints;
+    apow[c][e] = gl::canon(gl::pow(chal[2 * kNumCh + c], kNumCh + kNumCh * kNumChunks + e));
+  }
+  __syncthreads();
+  const u32 r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= big) return;
+  const u32 i = __brev(r) >> (32 - log_big);
+  auto CS = [&](u32 j) { return cs[(size_t)j * big + r]; };
+  auto W = [&](int j) { return wl[(size_t)j * big + r]; };
+  u64 acc[kNumCh], gacc[kNumCh];
+#pragma unroll
+  for (u32 c = 0; c < kNumCh; ++c) acc[c] = gacc[c] = 0;
+  auto G = [&](int j, u64 t) {
+#pragma unroll
+    for (u32 c = 0; c < kNumCh; ++c) gacc[c] = gl::mul_add(apow[c][j], t, gacc[c]);
+  };
+  const u64 c0 = CS(d.num_selectors), c1 = CS(d.num_selectors + 1);
+#pragma unroll 1
+  for (u32 g = 0; g < d.n_kinds; ++g) {
+    switch (d.kind[g]) {
+      case G_BASE_SUM: gates_rec::base_sum_gate<FBaseDev>(W, G); break;
+      case G_ARITHMETIC_EXT: gates_rec::arithmetic_ext_gate<FBaseDev>(W, c0, c1, G); break;
+      case G_MUL_EXT: gates_rec::mul_ext_gate<FBaseDev>(W, c0, G); break;
+      case G_REDUCING: gates_rec::reducing_gate<FBaseDev>(W, G); break;
+      case G_REDUCING_EXT: gates_rec::reducing_ext_gate<FBaseDev>(W, G); break;
+      case G_RANDOM_ACCESS: gates_rec::random_access_gate<FBaseDev>(W, c0, c1, G); break;
+      case G_COSET_INTERPOLATION: gates_rec::coset_interpolation_gate<FBaseDev>(W, G); break;
+      case G_POSEIDON_MDS: gates_rec::poseidon_mds_gate<FBaseDev>(W, G); break;
+      default: continue;  // the five gate types k_quotient evaluates itself
+    }
+    const u64 sv = CS(d.sel[g]);  // compute_filter
+    u64 f = 1;
+    for (u32 k = d.gs[g]; k < d.ge[g]; ++k)
+      if (k != g) f = gl::mul(f, fsub((u64)k, sv));
+    if (d.num_selectors > 1) f = gl::mul(f, fsub(kUnusedSelector, sv));
+#pragma unroll
+    for (u32 c = 0; c < kNumCh; ++c) {
+      acc[c] = gl::mul_add(f, gacc[c], acc[c]);
+      gacc[c] = 0;
+    }
+  }
+#pragma unroll
+  for (u32 c = 0; c < kNumCh; ++c) extra[(size_t)c * big + i] = gl::canon(acc[c]);
 }
 
 // OpeningSet order (constants | sigmas | wires | zs | zs_next | partial products | quotient) from the FriOpenings order the
@@ -805,6 +1086,76 @@ int valid_target(const p2mt_circuit_data* c, u64 t) {
   return t < c->n_virtual;
 }
 
+// Targets a generator watches (ins) and sets (outs), as wire / virtual targets.  These are the dependencies() of plonky2's
+// generators; build() gives every one of them a value slot.
+void gen_targets(const Gen& g, std::vector<u64>& ins, std::vector<u64>& outs) {
+  ins.clear();
+  outs.clear();
+  auto W = [&](u32 col) { return wire_t(g.row, col); };
+  switch (g.kind) {
+    case GEN_POSEIDON:
+      for (u32 k = 0; k < 12; ++k) ins.push_back(W(k));
+      ins.push_back(W(24));
+      for (u32 k = 12; k < 24; ++k) outs.push_back(W(k));
+      break;
+    case GEN_ARITH:
+      for (u32 k = 0; k < 3; ++k) ins.push_back(W(4 * g.i + k));
+      outs.push_back(W(4 * g.i + 3));
+      break;
+    case GEN_EQUALITY:
+      ins = {g.x, g.y};
+      outs = {g.eq, g.inv};
+      break;
+    case GEN_CONST: outs.push_back(W(g.i)); break;
+    case GEN_ARITH_EXT:
+      for (u32 k = 0; k < 6; ++k) ins.push_back(W(8 * g.i + k));
+      outs = {W(8 * g.i + 6), W(8 * g.i + 7)};
+      break;
+    case GEN_MUL_EXT:
+      for (u32 k = 0; k < 4; ++k) ins.push_back(W(6 * g.i + k));
+      outs = {W(6 * g.i + 4), W(6 * g.i + 5)};
+      break;
+    case GEN_QUOTIENT_EXT:
+      ins.assign(g.t.begin(), g.t.begin() + 4);
+      outs.assign(g.t.begin() + 4, g.t.begin() + 6);
+      break;
+    case GEN_REDUCING:
+      for (u32 k = 2; k < 6 + kReducingCoeffs; ++k) ins.push_back(W(k));
+      outs = {W(0), W(1)};
+      for (u32 k = 0; k + 1 < kReducingCoeffs; ++k) outs.push_back(W(6 + kReducingCoeffs + 2 * k)), outs.push_back(W(7 + kReducingCoeffs + 2 * k));
+      break;
+    case GEN_REDUCING_EXT:
+      for (u32 k = 2; k < 6 + 2 * kReducingExtCoeffs; ++k) ins.push_back(W(k));
+      outs = {W(0), W(1)};
+      for (u32 k = 0; k + 1 < kReducingExtCoeffs; ++k)
+        outs.push_back(W(6 + 2 * kReducingExtCoeffs + 2 * k)), outs.push_back(W(7 + 2 * kReducingExtCoeffs + 2 * k));
+      break;
+    case GEN_WIRE_SPLIT:
+      ins.push_back(g.t[0]);
+      outs.assign(g.t.begin() + 1, g.t.end());
+      break;
+    case GEN_BASE_SPLIT:
+      ins.push_back(W(0));
+      for (u32 k = 0; k < kBaseSumLimbs; ++k) outs.push_back(W(1 + k));
+      break;
+    case GEN_RANDOM_ACCESS:
+      ins.push_back(W(18 * g.i));
+      for (u32 k = 0; k < 16; ++k) ins.push_back(W(18 * g.i + 2 + k));
+      outs.push_back(W(18 * g.i + 1));
+      for (u32 k = 0; k < kRaBits; ++k) outs.push_back(W(74 + kRaBits * g.i + k));
+      break;
+    case GEN_INTERPOLATION:
+      for (u32 k = 0; k < 35; ++k) ins.push_back(W(k));
+      for (u32 k = 35; k < 47; ++k) outs.push_back(W(k));
+      break;
+    case GEN_POSEIDON_MDS:
+      for (u32 k = 0; k < 24; ++k) ins.push_back(W(k));
+      for (u32 k = 24; k < 48; ++k) outs.push_back(W(k));
+      break;
+    default: break;
+  }
+}
+
 // Order the generators into levels for the given set of externally set slots (generate_partial_witness's watch lists,
 // resolved ahead of time: readiness does not depend on values).  Returns P2MT_EINVAL if some generator can never run.
 int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
@@ -814,71 +1165,93 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
   for (const auto& ci : c->const_inits) set_level[ci.first] = 0;
   for (u32 s : input_slots) set_level[s] = 0;
   auto slot_w = [&](u32 row, u32 col) { return c->slot_of[row * kNumWires + col]; };
+  // slots of every generator's inputs / outputs, once
+  const size_t n_gens = c->gens.size();
+  std::vector<u32> io;            // concatenated slot lists
+  std::vector<u32> io_off(n_gens + 1, 0), n_ins(n_gens, 0);
+  {
+    std::vector<u64> ins, outs;
+    for (size_t gi = 0; gi < n_gens; ++gi) {
+      gen_targets(c->gens[gi], ins, outs);
+      n_ins[gi] = (u32)ins.size();
+      for (u64 t : ins) io.push_back(c->slot_of[target_index(c, t)]);
+      for (u64 t : outs) io.push_back(c->slot_of[target_index(c, t)]);
+      io_off[gi + 1] = (u32)io.size();
+    }
+  }
+  // worklist: a generator becomes ready when its last unset input slot gets a level
+  std::vector<u32> missing(n_gens, 0);
+  std::vector<std::vector<u32>> watchers(c->n_slots);
+  std::vector<u32> ready;
+  for (size_t gi = 0; gi < n_gens; ++gi) {
+    const u32* in = io.data() + io_off[gi];
+    for (u32 k = 0; k < n_ins[gi]; ++k) {
+      if (in[k] == kNoSlot) return p2mt::fail(P2MT_EINVAL, "internal: a generator input has no value slot");
+      bool dup = false;
+      for (u32 j = 0; j < k; ++j) dup |= in[j] == in[k];
+      if (!dup && set_level[in[k]] < 0) {
+        ++missing[gi];
+        watchers[in[k]].push_back((u32)gi);
+      }
+    }
+    if (!missing[gi]) ready.push_back((u32)gi);
+  }
   struct Item {
     int level;
     WOp op;
   };
   std::vector<Item> items;
+  items.reserve(n_gens);
   std::vector<u32> pslots;  // per PoseidonGate row: the value slots of wires 0..24 (inputs, outputs, swap), padded to 32
+  std::vector<u32> args;    // slot lists of the generators that are not tied to a gate row
   u32 n_poseidon = 0;
-  std::vector<char> done(c->gens.size(), 0);
-  size_t remaining = c->gens.size();
-  while (remaining) {
-    size_t progressed = 0;
-    for (size_t gi = 0; gi < c->gens.size(); ++gi) {
-      if (done[gi]) continue;
-      const Gen& g = c->gens[gi];
-      u32 ins[13], outs[12];
-      u32 n_in = 0, n_out = 0;
-      WOp op{};
-      op.kind = (u32)g.kind;
-      if (g.kind == GEN_ARITH) {
-        for (u32 k = 0; k < 3; ++k) ins[n_in++] = slot_w(g.row, 4 * g.i + k);
-        outs[n_out++] = slot_w(g.row, 4 * g.i + 3);
-        op.a = ins[0];
-        op.b = ins[1];
-        op.c = ins[2];
-        op.out = outs[0];
-        op.c0 = g.c0;
-        op.c1 = g.c1;
-      } else if (g.kind == GEN_EQUALITY) {
-        ins[n_in++] = c->slot_of[target_index(c, g.x)];
-        ins[n_in++] = c->slot_of[target_index(c, g.y)];
-        outs[n_out++] = c->slot_of[target_index(c, g.eq)];
-        outs[n_out++] = c->slot_of[target_index(c, g.inv)];
-        op.a = ins[0];
-        op.b = ins[1];
-        op.out = outs[0];
-        op.out2 = outs[1];
-      } else {  // PoseidonGenerator
-        for (u32 k = 0; k < 12; ++k) ins[n_in++] = slot_w(g.row, k);
-        ins[n_in++] = slot_w(g.row, 24);
-        for (u32 k = 12; k < 24; ++k) outs[n_out++] = slot_w(g.row, k);
+  size_t head = 0;
+  while (head < ready.size()) {
+    const u32 gi = ready[head++];
+    const Gen& g = c->gens[gi];
+    const u32 *in = io.data() + io_off[gi], *out = in + n_ins[gi];
+    const u32 n_out = io_off[gi + 1] - io_off[gi] - n_ins[gi];
+    int level = 0;
+    for (u32 k = 0; k < n_ins[gi]; ++k) level = std::max(level, set_level[in[k]]);
+    for (u32 k = 0; k < n_out; ++k) {
+      if (out[k] == kNoSlot) return p2mt::fail(P2MT_EINVAL, "internal: a generator output has no value slot");
+      level = std::max(level, set_level[out[k]]);  // a check waits for the value it checks
+    }
+    ++level;
+    for (u32 k = 0; k < n_out; ++k)
+      if (set_level[out[k]] < 0) {
+        set_level[out[k]] = level;
+        for (u32 w : watchers[out[k]])
+          if (--missing[w] == 0) ready.push_back(w);
+        watchers[out[k]].clear();
+      }
+    WOp op{};
+    op.kind = (u32)g.kind;
+    op.c0 = g.c0;
+    op.c1 = g.c1;
+    switch (g.kind) {
+      case GEN_ARITH: op.a = in[0], op.b = in[1], op.c = in[2], op.out = out[0]; break;
+      case GEN_EQUALITY: op.a = in[0], op.b = in[1], op.out = out[0], op.out2 = out[1]; break;
+      case GEN_POSEIDON:
         op.a = g.row;
-      }
-      int level = 0;
-      bool ready = true;
-      for (u32 k = 0; k < n_in; ++k) {
-        if (set_level[ins[k]] < 0) ready = false;
-        else level = std::max(level, set_level[ins[k]]);
-      }
-      if (!ready) continue;
-      for (u32 k = 0; k < n_out; ++k) level = std::max(level, set_level[outs[k]]);  // a check waits for the value it checks
-      ++level;
-      for (u32 k = 0; k < n_out; ++k)
-        if (set_level[outs[k]] < 0) set_level[outs[k]] = level;
-      if (g.kind == GEN_POSEIDON) {  // only now: a generator that is not ready yet is visited again in a later pass
         op.b = n_poseidon++;
         pslots.resize((size_t)n_poseidon * 32, 0);
         for (u32 k = 0; k < 25; ++k) pslots[(size_t)op.b * 32 + k] = slot_w(g.row, k);
-      }
-      items.push_back(Item{level, op});
-      done[gi] = 1;
-      ++progressed;
+        break;
+      case GEN_QUOTIENT_EXT:
+      case GEN_WIRE_SPLIT:
+        op.a = (u32)args.size();
+        op.b = io_off[gi + 1] - io_off[gi];
+        args.insert(args.end(), in, in + op.b);
+        break;
+      default:  // tied to a gate row: slots through the dense table
+        op.a = g.row;
+        op.b = g.i;
+        break;
     }
-    if (!progressed) return p2mt::fail(P2MT_EINVAL, "prove: some generators weren't run (a target they depend on was never set)");
-    remaining -= progressed;
+    items.push_back(Item{level, op});
   }
+  if (items.size() != n_gens) return p2mt::fail(P2MT_EINVAL, "prove: some generators weren't run (a target they depend on was never set)");
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
     return a.level != b.level ? a.level < b.level : (a.op.kind == GEN_POSEIDON) > (b.op.kind == GEN_POSEIDON);
   });
@@ -896,11 +1269,13 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
   }
   lvl.push_back((u32)items.size());
   c->n_levels = (u32)(lvl.size() / 2);
+  if (args.size() > c->args_cap) return p2mt::fail(P2MT_EINVAL, "internal: generator argument table overflow");
   hipStream_t st = rt().stream;
   P2MT_HIP(hipStreamSynchronize(st));  // the previous schedule may still be in use
   if (!ops.empty()) P2MT_HIP(hipMemcpy(c->d_ops, ops.data(), ops.size() * sizeof(WOp), hipMemcpyHostToDevice));
   P2MT_HIP(hipMemcpy(c->d_lvl, lvl.data(), lvl.size() * 4, hipMemcpyHostToDevice));
   if (!pslots.empty()) P2MT_HIP(hipMemcpy(c->d_pslots, pslots.data(), pslots.size() * 4, hipMemcpyHostToDevice));
+  if (!args.empty()) P2MT_HIP(hipMemcpy(c->d_args, args.data(), args.size() * 4, hipMemcpyHostToDevice));
   c->sched_inputs = input_slots;
   c->sched_valid = true;
   return P2MT_OK;
@@ -950,14 +1325,15 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   P2MT_HIP(hipMemcpyAsync(c->d_init, c->h_pin + c->pin_pairs_off, pairs.size() * 8, hipMemcpyHostToDevice, st));
   u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
   if (!c->lds_bytes) {
-    P2MT_HIP(hipMemsetAsync(c->d_err, 0, 2 * sizeof(int), st));
+    P2MT_HIP(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), st));
     P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
   }
   if (c->lds_bytes) {
     hipLaunchKernelGGL(k_witness_lds, dim3(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
                        (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_pslots, (const u32*)c->d_wire_slot,
                        c->n_act, c->degree_bits,
-                       c->d_w_vals, (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, c->d_err, p2mt::perm_ctx());
+                       c->d_w_vals, (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, (const u32*)c->d_slot_tab, (const u32*)c->d_args,
+                       c->d_err, p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return fill_poseidon_rows(c);
   }
@@ -965,8 +1341,21 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   hipLaunchKernelGGL(k_witness_init, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
                      c->d_set);
   P2MT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
-                     c->d_set, (const u32*)c->d_pslots, c->d_w_vals, c->degree_bits, c->d_err, p2mt::perm_ctx());
+  // Wide circuits (more generators than one workgroup can usefully hold per level) run the level interpreter over the whole grid;
+  // env P2MT_WITNESS_GRID=0 forces the single-workgroup interpreter (A/B and fallback).
+  static const bool grid_ok = [] {
+    const char* e = getenv("P2MT_WITNESS_GRID");
+    return !(e && e[0] == '0');
+  }();
+  if (grid_ok && c->gens.size() >= 4096) {
+    P2MT_HIP(hipMemsetAsync(c->d_sync, 0, 8, st));
+    hipLaunchKernelGGL(k_witness_grid, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
+                       c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
+                       c->d_sync, p2mt::perm_ctx());
+  } else {
+    hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
+                       c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err, p2mt::perm_ctx());
+  }
   P2MT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for(std::max<size_t>(c->n_act, c->n_pi))), dim3(kBlock), 0, st,
                      (const u64*)c->d_vals, (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->n_act, c->d_w_vals,
@@ -980,6 +1369,7 @@ int witness_status(p2mt_circuit_data* c, const int* err) {
   if (err[0] == -1) return p2mt::fail(P2MT_EINVAL, "prove: a public input target was never set");
   if (err[0] != 0) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
   if (err[1] != 0) return p2mt::fail(P2MT_EINVAL, "prove: zero denominator in the permutation argument (plonky2 panics on this division)");
+  if (err[2] != 0) return p2mt::fail(P2MT_EHIP, "prove: the grid-wide witness interpreter gave up waiting at a level barrier");
   return P2MT_OK;
 }
 
@@ -1060,27 +1450,7 @@ extern "C" int p2mt_cb_add_virtual_bool_target_safe(p2mt_circuit_builder* b, p2m
 }
 extern "C" int p2mt_cb_is_equal(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
   CB_ARGS(b, out);
-  P2MT_TRY(cb_check(b, x, true));
-  P2MT_TRY(cb_check(b, y, true));
-  const u64 zero = cb_constant(b, 0), one = cb_constant(b, 1);
-  const u64 equal = cb_virtual(b);
-  u64 not_equal, diff, not_equal_check, diff_normalized;
-  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, one, one, equal, &not_equal));
-  const u64 inv = cb_virtual(b);
-  Gen g{};
-  g.kind = GEN_EQUALITY;
-  g.x = x;
-  g.y = y;
-  g.eq = equal;
-  g.inv = inv;
-  b->gens.push_back(g);
-  P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, x, one, y, &diff));
-  P2MT_TRY(cb_arithmetic(b, 1, 0, diff, inv, diff, &not_equal_check));
-  P2MT_TRY(cb_arithmetic(b, 1, 0, diff, equal, diff, &diff_normalized));
-  P2MT_TRY(cb_connect(b, diff_normalized, zero));
-  P2MT_TRY(cb_connect(b, not_equal, not_equal_check));
-  *out = equal;
-  return P2MT_OK;
+  return cb_is_equal(b, x, y, out);
 }
 extern "C" int p2mt_cb_hash_n_to_hash_no_pad(p2mt_circuit_builder* b, const p2mt_target* inputs, size_t n, p2mt_target* out) {
   CB_ARGS(b, out);
@@ -1131,22 +1501,19 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   P2MT_TRY(cb_hash_no_pad(b, b->public_inputs.data(), b->public_inputs.size(), pi_hash_t));
   const u32 pi_gate = cb_add_gate(b, G_PUBLIC_INPUT);
   for (u32 k = 0; k < 4; ++k) b->copies.emplace_back(pi_hash_t[k], wire_t(pi_gate, k));
-  // one ConstantGate slot per distinct constant, in increasing canonical order
+  // one constant generator per distinct constant, in increasing canonical order: the spare constant wires of the gates that have
+  // them (RandomAccessGate) first, in row order, then ConstantGates added as needed
+  while (b->const_to_target.size() > b->constant_generators.size()) cb_add_gate(b, G_CONSTANT);
   {
-    std::vector<std::pair<u32, u32>> free_slots;
+    size_t k = 0;
     for (const auto& ct : b->const_to_target) {
-      if (free_slots.empty()) {
-        const u32 row = cb_add_gate(b, G_CONSTANT);
-        for (u32 k = kNumConsts; k-- > 0;) free_slots.emplace_back(row, k);
-      }
-      const auto sl = free_slots.back();
-      free_slots.pop_back();
-      b->gates[sl.first].c[sl.second] = ct.first;
-      b->copies.emplace_back(wire_t(sl.first, sl.second), ct.second);
+      const auto cg = b->constant_generators[k++];
+      b->gates[cg[0]].c[cg[1]] = ct.first;
+      b->copies.emplace_back(wire_t(cg[0], cg[2]), ct.second);
       Gen g{};
       g.kind = GEN_CONST;
-      g.row = sl.first;
-      g.i = sl.second;
+      g.row = cg[0];
+      g.i = cg[2];
       g.c0 = ct.first;
       b->gens.push_back(g);
     }
@@ -1171,13 +1538,16 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   for (const auto& g : b->gates) ++c->counts[g.kind];
   // gate types present, sorted by (degree, id); selector groups (gates/selectors.rs selector_polynomials)
   u32 index_of[G_KINDS] = {};
-  for (u32 k = 0; k < G_KINDS; ++k)
-    if (c->counts[k]) {
-      index_of[k] = c->n_kinds;
-      c->kind[c->n_kinds++] = k;
+  for (u32 k = 0; k < G_KINDS; ++k) {
+    const u32 kind = (u32)kSortedKinds[k];
+    if (c->counts[kind]) {
+      index_of[kind] = c->n_kinds;
+      c->kind[c->n_kinds++] = kind;
+      if (kind > G_POSEIDON) c->has_recursion_gates = true;
     }
+  }
   const u32 max_degree = kQF + 1;
-  u32 group_of[G_KINDS] = {};
+  u32 group_of[kMaxGateTypes] = {};
   if (kGateDegree[c->kind[c->n_kinds - 1]] + c->n_kinds - 1 <= max_degree) {
     c->num_selectors = 1;
     for (u32 g = 0; g < c->n_kinds; ++g) {
@@ -1244,15 +1614,12 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
       mark(cp.first);
       mark(cp.second);
     }
-    for (const auto& g : b->gens) {
-      if (g.kind == GEN_ARITH) {
-        for (u32 k = 0; k < 4; ++k) mark(wire_t(g.row, 4 * g.i + k));
-      } else if (g.kind == GEN_EQUALITY) {
-        mark(g.x), mark(g.y), mark(g.eq), mark(g.inv);
-      } else if (g.kind == GEN_POSEIDON) {
-        for (u32 k = 0; k < 25; ++k) mark(wire_t(g.row, k));
-      } else {
-        mark(wire_t(g.row, g.i));
+    {
+      std::vector<u64> ins, outs;
+      for (const auto& g : b->gens) {
+        gen_targets(g, ins, outs);
+        for (u64 t : ins) mark(t);
+        for (u64 t : outs) mark(t);
       }
     }
     for (u64 t : b->public_inputs) mark(t);
@@ -1331,7 +1698,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   auto carve_batch = [&](size_t polys) { return Batch{carve(polys * n), carve(polys * n), carve(polys * big), carve(polys * big), carve(4 * (nd ? nd : 1))}; };
   const Batch bc = carve_batch(n_cs), bw = carve_batch(kNumWires), bz = carve_batch(kNumZs), bq = carve_batch(kNumQuot);
   const size_t o_qvals = carve(kNumCh * big), o_ppq = carve((size_t)kNumCh * kNumChunks * n);
-  const size_t o_head = carve(8 + c->proof_len + 1), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
+  const size_t o_head = carve(8 + c->proof_len + 2), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
   const size_t o_vals = carve(c->n_slots), o_set = carve((c->n_slots + 1) / 2);
   c->init_cap = c->const_inits.size() + n_targets;
   const size_t o_init = carve(2 * c->init_cap);
@@ -1339,8 +1706,13 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   c->ops_cap = c->gens.size();
   const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2);
   const size_t o_pslots = carve((size_t)c->counts[G_POSEIDON] * 16 + 16), o_prows = carve(c->counts[G_POSEIDON] / 2 + 1);
+  c->args_cap = 0;
+  for (const auto& g : c->gens)
+    if (g.kind == GEN_QUOTIENT_EXT || g.kind == GEN_WIRE_SPLIT) c->args_cap += g.t.size();
+  const size_t o_slot_tab = carve((n * kNumWires + 1) / 2 + 1), o_args = carve(c->args_cap / 2 + 1), o_sync = carve(4);
+  const size_t o_q_extra = c->has_recursion_gates ? carve(kNumCh * big) : 0;
   if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");
-  c->pin_pairs_off = 8 + c->proof_len + 1;
+  c->pin_pairs_off = 8 + c->proof_len + 2;
   if (hipHostMalloc((void**)&c->h_pin, (c->pin_pairs_off + 2 * c->init_cap) * 8, hipHostMallocDefault) != hipSuccess)
     return p2mt::fail(P2MT_ENOMEM, "hipHostMalloc(circuit staging) failed");
   u64* base = c->d_base;
@@ -1355,10 +1727,14 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   c->d_ops = (WOp*)(base + o_ops), c->d_lvl = (u32*)(base + o_lvl), c->d_err = (int*)(base + o_head + 8 + c->proof_len);
   c->d_pslots = (u32*)(base + o_pslots);
   c->d_prows = (u32*)(base + o_prows);
+  c->d_slot_tab = (u32*)(base + o_slot_tab), c->d_args = (u32*)(base + o_args), c->d_sync = (u32*)(base + o_sync);
+  c->d_q_extra = c->has_recursion_gates ? base + o_q_extra : nullptr;
   hipStream_t st = rt().stream;
   P2MT_HIP(hipMemsetAsync(c->d_base, 0, words * 8, st));
   std::vector<u32> pi_slot(c->n_pi);
   for (u32 k = 0; k < c->n_pi; ++k) pi_slot[k] = c->slot_of[target_index(c, c->public_inputs[k])];
+  // dense wire -> slot table (the generators of the recursion gates find their operands through it); slot_of's wire part IS it
+  P2MT_HIP(hipMemcpyAsync(c->d_slot_tab, c->slot_of.data(), n * kNumWires * 4, hipMemcpyHostToDevice, st));
   P2MT_HIP(hipMemcpyAsync(c->d_cs_vals, c->h_cs.data(), c->h_cs.size() * 8, hipMemcpyHostToDevice, st));
   std::copy(k_is, k_is + kNumRouted, c->k_is);
   P2MT_HIP(hipMemcpyAsync(c->d_kis, k_is, sizeof k_is, hipMemcpyHostToDevice, st));
@@ -1412,8 +1788,8 @@ extern "C" int p2mt_circuit_get_info(const p2mt_circuit_data* c, p2mt_circuit_in
   info->num_partial_products = kNumProds;
   info->proof_len = c->proof_len;
   info->fri_proof_len = c->fri_len;
-  for (u32 k = 0; k < G_KINDS; ++k) info->gate_counts[k] = c->counts[k];
-  for (u32 g = 0; g < G_KINDS; ++g) {
+  for (u32 k = 0; k < kMaxGateTypes; ++k) info->gate_counts[k] = c->counts[k];
+  for (u32 g = 0; g < kMaxGateTypes; ++g) {
     info->gate_kinds[g] = g < c->n_kinds ? c->kind[g] : 0;
     info->gate_selector[g] = g < c->n_kinds ? c->sel[g] : 0;
     info->group_start[g] = g < c->n_kinds ? c->gs[g] : 0;
@@ -1421,6 +1797,19 @@ extern "C" int p2mt_circuit_get_info(const p2mt_circuit_data* c, p2mt_circuit_in
   }
   return P2MT_OK;
 }
+int p2mt_circuit_common_data(const p2mt_circuit_data* c, p2mt_common_data* out) {
+  if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  *out = p2mt_common_data{};
+  out->degree_bits = c->degree_bits, out->num_selectors = c->num_selectors, out->n_kinds = c->n_kinds, out->num_public_inputs = c->n_pi;
+  for (u32 g = 0; g < kMaxGateTypes; ++g) out->kind[g] = c->kind[g], out->sel[g] = c->sel[g], out->gs[g] = c->gs[g], out->ge[g] = c->ge[g];
+  std::copy(c->k_is, c->k_is + kNumRouted, out->k_is);
+  out->fri = c->fri;
+  out->proof_len = c->proof_len;
+  std::copy(c->cs_cap, c->cs_cap + 64, out->cs_cap);
+  std::copy(c->digest, c->digest + 4, out->digest);
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_circuit_public_inputs(const p2mt_circuit_data* c, p2mt_target* out) {
   if (!c || (c->n_pi && !out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (u32 k = 0; k < c->n_pi; ++k) out[k] = c->public_inputs[k];
@@ -1461,7 +1850,7 @@ extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_pa
   if (!c || !pw || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_TRY(fill_witness(c, pw));
   hipStream_t st = rt().stream;
-  int err[2] = {0, 0};
+  int err[4] = {0, 0, 0, 0};
   P2MT_HIP(hipMemcpyAsync(wires_out, c->d_w_vals, (size_t)kNumWires * c->n * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
@@ -1502,7 +1891,7 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   qd.n_kinds = c->n_kinds;
   qd.num_selectors = c->num_selectors;
   qd.n_cs = n_cs;
-  for (u32 g = 0; g < G_KINDS; ++g) qd.kind[g] = c->kind[g], qd.sel[g] = c->sel[g], qd.gs[g] = c->gs[g], qd.ge[g] = c->ge[g];
+  for (u32 g = 0; g < kMaxGateTypes; ++g) qd.kind[g] = c->kind[g], qd.sel[g] = c->sel[g], qd.gs[g] = c->gs[g], qd.ge[g] = c->ge[g];
   {
     const u64 shift_n = h_pow(7, n), w_q = h_root_of_unity(3);
     for (u32 k = 0; k < kQF; ++k) {
@@ -1512,9 +1901,14 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
     qd.n_inv = h_pow(n, gl::P - 2);
     qd.w_big = h_root_of_unity(log_big);
   }
+  if (c->has_recursion_gates) {
+    hipLaunchKernelGGL(k_quotient_extra, dim3(grid_for(big)), dim3(kBlock), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
+                       (const u64*)c->d_chal, c->d_q_extra);
+    P2MT_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_quotient, dim3((big + 63) / 64), dim3(256), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
                      (const u64*)c->d_z_lde, (const u64*)d_pi_hash, (const u64*)c->d_chal, (const u64*)c->d_kis,
-                     (const u64*)rt().d_rc, c->d_q_vals);
+                     (const u64*)rt().d_rc, (const u64*)c->d_q_extra, c->d_q_vals);
   P2MT_LAUNCH_CHECK();
   P2MT_TRY(p2mt::coset_ifft_dev(c->d_q_vals, log_big, kNumCh, 7, c->d_q_coeffs));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_q_coeffs, 0, kNumQuot, log_n, kRateBits, kCapHeight, nullptr, c->d_q_lde, c->d_q_leaves,
@@ -1556,9 +1950,9 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   P2MT_LAUNCH_CHECK();
   // the proof (with the error flags right behind it) rides back on the FRI prover's own final synchronisation
   P2MT_TRY(p2mt::fri_prove_openings_epilogue_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri, c->h_pin + 8, d_proof,
-                                                 (c->proof_len + 1) * 8));
+                                                 (c->proof_len + 2) * 8));
   std::copy(c->h_pin + 8, c->h_pin + 8 + c->proof_len, proof_out);
-  int err[2];
+  int err[4];
   memcpy(err, c->h_pin + 8 + c->proof_len, sizeof err);
   return witness_status(c, err);
 }
@@ -1642,7 +2036,7 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
   p2mt::VerifyDesc vd{};
   vd.degree_bits = log_n, vd.num_wires = kNumWires, vd.num_routed = kNumRouted, vd.num_constants = kNumConsts;
   vd.num_selectors = c->num_selectors, vd.num_challenges = kNumCh, vd.quotient_degree_factor = kQF, vd.n_kinds = c->n_kinds;
-  for (u32 g = 0; g < G_KINDS; ++g) vd.kind[g] = c->kind[g], vd.sel[g] = c->sel[g], vd.gs[g] = c->gs[g], vd.ge[g] = c->ge[g];
+  for (u32 g = 0; g < kMaxGateTypes; ++g) vd.kind[g] = c->kind[g], vd.sel[g] = c->sel[g], vd.gs[g] = c->gs[g], vd.ge[g] = c->ge[g];
   *reason = 11;
   if (!p2mt::verify_openings_host(vd, c->k_is, zeta, proof + off_open, pi_hash.data(), betas, gammas, alphas)) return P2MT_OK;
   *reason = 1;

@@ -9,7 +9,9 @@
 // extension-field multiplications per proof: host work, as in the reference.
 #include "runtime.h"
 #include "poseidon_constants.h"  // host copy of the round constants / MDS (P2MT_QUAL defaults to static const)
+#include "gates_recursion.hip.h"  // the in-circuit verifier's gate types, one source for base field (device) and extension (here)
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -105,6 +107,18 @@ void poseidon_gate_eval(const E* w, std::vector<E>& out) {
   for (int i = 0; i < 12; ++i) out.push_back(s[i] - w[12 + i]);
 }
 
+// the evaluation field of the verifier: the quadratic extension (gates_recursion.hip.h's F)
+struct FExtHost {
+  typedef E T;
+  static T add(T a, T b) { return a + b; }
+  static T sub(T a, T b) { return a - b; }
+  static T mul(T a, T b) { return a * b; }
+  static T mulc(T a, u64 c) { return e_scale(a, c); }
+  static T addc(T a, u64 c) { return a + e_of(c); }
+  static T subc(T a, u64 c) { return a - e_of(c); }
+  static T fromc(u64 c) { return e_of(c); }
+};
+
 }  // namespace
 
 // openings: the OpeningSet of the proof (constants | sigmas | wires | zs | zs_next | partial products | quotient), 2 words each
@@ -164,7 +178,30 @@ int p2mt::verify_openings_host(const VerifyDesc& d, const uint64_t* k_is, const 
       case 4:  // PoseidonGate
         poseidon_gate_eval(w.data(), cs);
         break;
-      default: break;  // NoopGate
+      case 0: break;  // NoopGate
+      default: {      // the gate types of the in-circuit verifier (5..12)
+        cs.assign(123, e_of(0));
+        size_t used = 0;
+        auto W = [&](int j) { return w[j]; };
+        auto emit = [&](int j, E v) {
+          cs[j] = v;
+          used = std::max(used, (size_t)j + 1);
+        };
+        const E c0 = e_at(gc, 0), c1 = e_at(gc, 1);
+        switch (d.kind[g]) {
+          case 5: gates_rec::base_sum_gate<FExtHost>(W, emit); break;
+          case 6: gates_rec::arithmetic_ext_gate<FExtHost>(W, c0, c1, emit); break;
+          case 7: gates_rec::mul_ext_gate<FExtHost>(W, c0, emit); break;
+          case 8: gates_rec::reducing_gate<FExtHost>(W, emit); break;
+          case 9: gates_rec::reducing_ext_gate<FExtHost>(W, emit); break;
+          case 10: gates_rec::random_access_gate<FExtHost>(W, c0, c1, emit); break;
+          case 11: gates_rec::coset_interpolation_gate<FExtHost>(W, emit); break;
+          case 12: gates_rec::poseidon_mds_gate<FExtHost>(W, emit); break;
+          default: return 0;  // unknown gate type
+        }
+        cs.resize(used);
+        break;
+      }
     }
     const E s = e_at(consts, d.sel[g]);
     E f = e_of(1);

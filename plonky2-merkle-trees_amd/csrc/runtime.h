@@ -125,7 +125,7 @@ int fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_ora
 // exported by p2mt_verify_host.hip: the field arithmetic of CircuitData::verify (the hashing runs on the device)
 struct VerifyDesc {
   uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, n_kinds;
-  uint32_t kind[5], sel[5], gs[5], ge[5];
+  uint32_t kind[16], sel[16], gs[16], ge[16];
 };
 int verify_openings_host(const VerifyDesc& d, const uint64_t* k_is, const uint64_t zeta[2], const uint64_t* openings,
                          const uint64_t pi_hash[4], const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas);

@@ -2,8 +2,8 @@
 written against circuit.CircuitBuilder as the reference writes it against plonky2's.
 
 The OUTER circuit (complete_verification_circuit_with_inner_proof, :84-140) calls plonky2's in-circuit verifier
-(builder.verify_proof: CosetInterpolation / RandomAccess / Reducing / ArithmeticExtension / BaseSum / Exponentiation /
-PoseidonMds gates and their generators), which this library does not build yet; calling it raises."""
+(builder.verify_proof), which the library builds (csrc/p2mt_recursion.hip: CosetInterpolation / RandomAccess / Reducing /
+ReducingExtension / ArithmeticExtension / MulExtension / BaseSum / PoseidonMds gates and their generators)."""
 from .circuit import CircuitBuilder
 from .mmr_plonky2_verifier import equal, or_list, pick_hash
 
@@ -34,7 +34,27 @@ def verify_inner_merkle_proof_circuit(nr_merkle_proof_elms, nr_peaks):
 
 
 def complete_verification_circuit_with_inner_proof(inner_proof_circuit_data_common, nr_peaks):
-    """:84-140 -- needs plonky2's recursive verifier gadget (builder.verify_proof); not built."""
-    raise NotImplementedError("outer recursion circuit: builder.verify_proof (in-circuit plonky2 verifier) is not built; "
-                              "its commit and opening-proof stages at the d = 12 shape are covered by bench.py "
-                              "--workload commit / fri")
+    """:84-140 -> (circuit_data, ProofWithPublicInputsTarget, VerifierCircuitTarget, [peak HashOutTargets]).
+    Outer circuit: verifies the inner proof in-circuit (plonky2's recursive verifier, built by the library), checks that the
+    inner proof's first four public inputs -- its FIRST peak, quirk Q4 of SURVEY.md App. C -- appear among the given peaks, and
+    exposes the bagged root as its public input."""
+    inner = inner_proof_circuit_data_common
+    builder = CircuitBuilder()
+    prev_proof_target = builder.add_virtual_proof_with_pis(inner)
+    prev_proof_verifier_data = builder.add_virtual_verifier_data(4)   # inner.config.fri_config.cap_height
+    builder.verify_proof(prev_proof_target, prev_proof_verifier_data, inner)
+    targets, peaks, equals = [], [], []
+    prev_hash = prev_proof_target.public_inputs[0:4]
+    for _ in range(nr_peaks):
+        peak = builder.add_virtual_hash()
+        peaks.append(peak)
+        targets.append(peak)
+        equals.append(equal(builder, peak, prev_hash))
+    hash_in_peaks = or_list(builder, equals)
+    builder.connect(builder.one(), hash_in_peaks)
+    if len(peaks) > 1:
+        root = builder.hash_n_to_hash_no_pad([e for p in peaks for e in p])
+        builder.register_public_inputs(root)
+    else:
+        builder.register_public_inputs(peaks[0])
+    return builder.build(), prev_proof_target, prev_proof_verifier_data, targets

@@ -1,0 +1,138 @@
+"""mmr_plonky2_verifier_1_recursion on the GPU (BASELINE config 4): inner circuit -> inner proof -> outer circuit
+(plonky2's in-circuit verifier built by the library) -> outer witness on the device -> outer proof -> verify.
+Everything is compared stage by stage with the oracle's restatement (oracle/recursion.py): circuit (gate rows, selector groups,
+constants_sigmas values, cap, digest), witness matrix, challenges, Z / partial products, quotient chunks, proof words.
+The reference's five recursion tests (/root/reference/src/mmr/mmr_plonky2_verifier_1_recursion.rs:223-257) are re-expressed below.
+[parity unpinned: plonky2 is absent; both sides restate it from its published algorithm]"""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from circuit_cases import mmr_case, synthetic_case
+from oracle import circuit as OC, recursion as R
+from test_circuit_gpu import check_build, check_prove
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.init(0)
+    return p
+
+
+def inner_both(pkg, oracle, case):
+    """verify_inner_merkle_proof_circuit + witness (:168-190) on both sides -> (gpu circuit, gpu witness, oracle circuit, oracle witness)"""
+    leaf, sib, lefts, peaks, root = case
+    gcd, gleaf, gproof_ts = pkg.verify_inner_merkle_proof_circuit(len(sib), len(peaks))
+    ocd, oleaf, oproof_ts = OC.verify_inner_merkle_proof_circuit(oracle, len(sib), len(peaks))
+    pw, opw = pkg.PartialWitness(), {}
+    for set_target, leaf_t, proof_ts, pis in ((pw.set_target, gleaf, gproof_ts, gcd.prover_only.public_inputs),
+                                              (opw.__setitem__, oleaf, oproof_ts, ocd.public_inputs)):
+        set_target(leaf_t, leaf)
+        for (ht, bt), s, l in zip(proof_ts, sib, lefts):
+            for k in range(4):
+                set_target(ht[k], int(s[k]))
+            set_target(bt, int(l))
+        for i, pk in enumerate(peaks):
+            for k in range(4):
+                set_target(pis[4 * i + k], int(pk[k]))
+    return gcd, pw, ocd, opw
+
+
+def outer_both(pkg, oracle, case, gcd_inner, ocd_inner, inner_proof):
+    """complete_verification_circuit_with_inner_proof + witness (:195-216) on both sides"""
+    leaf, sib, lefts, peaks, root = case
+    gcd, gpt, gvd, gpeak_ts = pkg.complete_verification_circuit_with_inner_proof(gcd_inner.common, len(peaks))
+    pw = pkg.PartialWitness()
+    pw.set_proof_with_pis_target(gpt, inner_proof)
+    pw.set_verifier_data_target(gvd, gcd_inner.verifier_only)
+    for pt, pk in zip(gpeak_ts, peaks):
+        pw.set_hash_target(pt, [int(x) for x in pk])
+    for k, t in enumerate(gcd.prover_only.public_inputs):
+        pw.set_target(t, int(root[k]))
+    ocd, opt, ovd, opeak_ts = R.complete_verification_circuit_with_inner_proof(oracle, R.CommonData(ocd_inner), len(peaks))
+    opw = {}
+    R.set_proof_with_pis_target(opw.__setitem__, opt, inner_proof)
+    R.set_verifier_data_target(opw.__setitem__, ovd, ocd_inner)
+    for pt, pk in zip(opeak_ts, peaks):
+        for k in range(4):
+            opw[pt[k]] = int(pk[k])
+    for k in range(4):
+        opw[ocd.public_inputs[k]] = int(root[k])
+    return gcd, pw, ocd, opw
+
+
+def run_recursion(pkg, oracle, case, full=True):
+    gi, pwi, oi, opwi = inner_both(pkg, oracle, case)
+    check_build(gi, oi)
+    inner_proof = check_prove(gi, pwi, oi, opwi) if full else gi.prove(pwi)
+    assert gi.verify(inner_proof)
+    go, pwo, oo, opwo = outer_both(pkg, oracle, case, gi, oi, inner_proof)
+    check_build(go, oo)
+    if full:
+        final_proof = check_prove(go, pwo, oo, opwo)          # witness, challenges, Z, quotient, proof words == oracle; oracle verifies
+    else:
+        assert np.array_equal(go.generate_witness(pwo), oo.generate_witness(opwo)[0])
+        final_proof = go.prove(pwo)
+        assert oo.verify(final_proof) == (True, 0)
+    assert go.verify(final_proof)                              # main_circuit_data.verify(final_proof) (:220)
+    assert np.array_equal(final_proof[-4:], case[4])           # the public input is the MMR root
+    return go, final_proof
+
+
+def test_mmr_verifier_2leaves(pkg, oracle):
+    """:223-227"""
+    run_recursion(pkg, oracle, mmr_case(oracle, 2, 0))
+
+
+@pytest.mark.parametrize("leaf", [0, 3, 5, 6])
+def test_mmr_verifier_7leaves_multiple(pkg, oracle, leaf):
+    """:229-236 (3 peaks; leaves 4..6 sit outside the first mountain: quirk Q4 makes the outer peak check pass regardless)"""
+    run_recursion(pkg, oracle, mmr_case(oracle, 7, leaf), full=(leaf == 5))
+
+
+@pytest.mark.parametrize("leaf", [0, 7])
+def test_mmr_verifier_8leaves_multiple(pkg, oracle, leaf):
+    """:238-245"""
+    run_recursion(pkg, oracle, mmr_case(oracle, 8, leaf), full=False)
+
+
+def test_mmr_verifier_31leaves(pkg, oracle):
+    """:247-251"""
+    run_recursion(pkg, oracle, mmr_case(oracle, 31, 8), full=False)
+
+
+def test_mmr_verifier_1031leaves(pkg, oracle):
+    """:253-257: 4 peaks, 10 path elements -> the inner circuit has a FRI reduction layer, the outer one CosetInterpolationGates"""
+    go, _ = run_recursion(pkg, oracle, mmr_case(oracle, 1031, 100))
+    assert go.info.gate_counts[11] == 28 and go.degree_bits == 12
+
+
+def test_config4_leaf_of_a_2pow20_mmr(pkg, oracle):
+    """BASELINE config 4: inner + outer prove for a leaf of a 2^20-leaf MMR (20 path elements, 1 peak; the MMR and its membership
+    proof come from the device-resident MMR of config 2)"""
+    leaves = pkg.synthetic.splitmix_leaves(1 << 20, 0x5EED0000 + 3)
+    mmr = pkg.MMR.from_leaves(leaves)
+    root = mmr.bagging_the_peaks()
+    pr = mmr.get_proof_normal_index(777777)
+    case = (int(leaves[777777]), pr.siblings, pr.lefts, pr.peaks, root)
+    go, final_proof = run_recursion(pkg, oracle, case)
+    assert go.degree_bits == 12
+    bad = final_proof.copy()
+    bad[300] = (int(bad[300]) + 1) % P
+    assert go.verify(bad, with_reason=True)[0] is False
+
+
+def test_outer_witness_rejects_a_tampered_inner_proof(pkg, oracle):
+    """plonky2 panics in generate_partial_witness ("set twice with different values") when the inner proof does not verify"""
+    case = mmr_case(oracle, 8, 3)
+    gi, pwi, oi, opwi = inner_both(pkg, oracle, case)
+    inner_proof = gi.prove(pwi)
+    bad = inner_proof.copy()
+    bad[250] = (int(bad[250]) + 1) % P
+    go, pwo, oo, opwo = outer_both(pkg, oracle, case, gi, oi, bad)
+    with pytest.raises(pkg.P2mtPanic):
+        go.prove(pwo)
