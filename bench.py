@@ -11,6 +11,7 @@ N - popcount(N) of them.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (weak scaling: every rank builds its own 2^LOG shard)
   python bench.py --workload prove                        (BASELINE's second metric: ms/proof mmr_plonky2_verifier)
+  python bench.py --workload recursion                    (config 4: ms/proof mmr_plonky2_verifier_1_recursion, inner + outer)
   python bench.py --workload commit | fri                 (parts of a prove at the d = 12 shape: commit phase, opening proof)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
@@ -237,6 +238,14 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                 "how": "python bench.py --workload prove"}
         except Exception as e:  # the headline line must survive a failure of the secondary leg
             out["ms_per_proof_mmr_plonky2_verifier"] = {"error": repr(e)}
+        try:
+            pa.steps, pa.warmup = 10, 2
+            rr = run_recursion(pa, torch, pkg, lib, cpu_baseline=not args.no_cpu_baseline)
+            out["ms_per_proof_mmr_plonky2_verifier_1_recursion"] = {
+                "value": rr["value"], "unit": "ms", "config": rr["config"], "verify_outer_ms": rr["verify_outer_ms"],
+                "cpu_baseline": rr.get("cpu_baseline"), "how": "python bench.py --workload recursion"}
+        except Exception as e:
+            out["ms_per_proof_mmr_plonky2_verifier_1_recursion"] = {"error": repr(e)}
     return out
 
 
@@ -499,6 +508,122 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
     return out
 
 
+def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
+    """BASELINE.json config 4 / the second half of its metric: ms/proof of mmr_plonky2_verifier_1_recursion -- inner prove + outer
+    prove (/root/reference/src/mmr/mmr_plonky2_verifier_1_recursion.rs:191-192 and :217-218) for one leaf of a 2^20-leaf MMR.
+    One step = inner_circuit_data.prove(pw1) -> pw2.set_proof_with_pis_target(inner proof) -> main_circuit_data.prove(pw2), host
+    PartialWitness in, host proof words out.  Both circuits are built once (as in the reference's driver the build is not part of
+    `prove`); the outer circuit is plonky2's in-circuit verifier: 2^12 rows, 13 gate types."""
+    Nn = pkg._native
+    leaves = splitmix_leaves(1 << 20, 0x5EED0000 + 3)
+    mmr = pkg.MMR.from_leaves(leaves)
+    root = mmr.bagging_the_peaks()
+    idx = 777777
+    pr = mmr.get_proof_normal_index(idx)
+    t0 = time.perf_counter()
+    inner, leaf_t, proof_ts = pkg.verify_inner_merkle_proof_circuit(len(pr.siblings), len(pr.peaks))
+    inner_build_ms = (time.perf_counter() - t0) * 1e3
+    pw1 = pkg.PartialWitness()
+    pw1.set_target(leaf_t, int(leaves[idx]))
+    for (ht, bt), sib, left in zip(proof_ts, pr.siblings, pr.lefts):
+        pw1.set_hash_target(ht, [int(x) for x in sib])
+        pw1.set_bool_target(bt, bool(left))
+    for i, pk in enumerate(pr.peaks):
+        pw1.set_hash_target(inner.prover_only.public_inputs[4 * i:4 * i + 4], [int(x) for x in pk])
+    t0 = time.perf_counter()
+    outer, pt, vd, peak_ts = pkg.complete_verification_circuit_with_inner_proof(inner.common, len(pr.peaks))
+    outer_build_ms = (time.perf_counter() - t0) * 1e3
+    inner_proof = np.zeros(inner.info.proof_len, np.uint64)
+    final_proof = np.zeros(outer.info.proof_len, np.uint64)
+    pw2 = pkg.PartialWitness()
+    times = {"inner": 0.0, "outer": 0.0}
+
+    def one(timed=False):
+        t0 = time.perf_counter()
+        Nn.check(lib.p2mt_circuit_prove(inner._h, pw1._h, Nn.ptr(inner_proof), inner_proof.size))
+        t1 = time.perf_counter()
+        Nn.check(lib.p2mt_pw_clear(pw2._h))
+        pw2.set_proof_with_pis_target(pt, inner_proof)
+        pw2.set_verifier_data_target(vd, inner.verifier_only)
+        for t, pk in zip(peak_ts, pr.peaks):
+            pw2.set_hash_target(t, [int(x) for x in pk])
+        for k, t in enumerate(outer.prover_only.public_inputs):
+            pw2.set_target(t, int(root[k]))
+        Nn.check(lib.p2mt_circuit_prove(outer._h, pw2._h, Nn.ptr(final_proof), final_proof.size))
+        if timed:
+            times["inner"] += t1 - t0
+            times["outer"] += time.perf_counter() - t1
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one(True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    assert outer.verify(final_proof), "the product's verifier rejects the outer proof"
+    assert np.array_equal(final_proof[-4:], root), "the outer proof's public input is not the MMR root"
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps // 4, 1)):
+        outer.verify(final_proof)
+    verify_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps // 4, 1)
+    counts = list(outer.info.gate_counts)
+    out = {"metric": "ms/proof mmr_plonky2_verifier_1_recursion (inner + outer prove, one leaf of a 2^20-leaf MMR)", "value": ms,
+           "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
+           "scaling": "replicas only", "vs_baseline": None, "dtype": "u64 (Goldilocks + quadratic extension)", "data": "synthetic",
+           "config": {"workload": "mmr_plonky2_verifier_1_recursion: inner_circuit_data.prove(pw1) (2^%d rows) + "
+                                  "main_circuit_data.prove(pw2) (outer circuit = in-circuit verifier of the inner proof, 2^%d rows), "
+                                  "standard_recursion_config, 20 path elements + 1 peak, host PartialWitness -> host proof words"
+                                  % (inner.degree_bits, outer.degree_bits),
+                      "inner_ms": times["inner"] * 1e3 / args.steps, "outer_ms": times["outer"] * 1e3 / args.steps,
+                      "inner_proof_words": int(inner.info.proof_len), "outer_proof_words": int(outer.info.proof_len),
+                      "circuit_build_ms": {"inner": inner_build_ms, "outer": outer_build_ms},
+                      "outer_gate_rows": {k: int(counts[i]) for i, k in enumerate(
+                          ("noop", "constant", "public_input", "arithmetic", "poseidon", "base_sum", "arithmetic_extension",
+                           "mul_extension", "reducing", "reducing_extension", "random_access", "coset_interpolation",
+                           "poseidon_mds"))}},
+           "verify_outer_ms": verify_ms, "public_inputs": [int(x) for x in final_proof[-4:]],
+           "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                        "note": "dependency chains (witness levels, transcript, Merkle levels), not bandwidth: per-kernel split in "
+                                "profiles/r02_prove_timeline_recursion.txt"}}
+    if cpu_baseline:
+        from oracle import circuit as OC, recursion as R
+        o = _oracle().Oracle()
+        t0 = time.perf_counter()
+        oi, oleaf, oproof_ts = OC.verify_inner_merkle_proof_circuit(o, len(pr.siblings), len(pr.peaks))
+        opw = {oleaf: int(leaves[idx])}
+        for (ht, bt), sib, left in zip(oproof_ts, pr.siblings, pr.lefts):
+            for k in range(4):
+                opw[ht[k]] = int(sib[k])
+            opw[bt] = int(left)
+        for i, pk in enumerate(pr.peaks):
+            for k in range(4):
+                opw[oi.public_inputs[4 * i + k]] = int(pk[k])
+        oo, opt, ovd, opeak_ts = R.complete_verification_circuit_with_inner_proof(o, R.CommonData(oi), len(pr.peaks))
+        build_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        want_inner = oi.prove(opw)
+        opw2 = {}
+        R.set_proof_with_pis_target(opw2.__setitem__, opt, want_inner)
+        R.set_verifier_data_target(opw2.__setitem__, ovd, oi)
+        for t, pk in zip(opeak_ts, pr.peaks):
+            for k in range(4):
+                opw2[t[k]] = int(pk[k])
+        for k in range(4):
+            opw2[oo.public_inputs[k]] = int(root[k])
+        want = oo.prove(opw2)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        assert np.array_equal(inner_proof, want_inner) and np.array_equal(final_proof, want), "GPU proofs != oracle proofs"
+        assert oo.verify(final_proof) == (True, 0), "oracle verifier rejects the GPU outer proof"
+        out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": "oracle/circuit.py + oracle/recursion.py + oracle/*.c: inner + outer prove of the same "
+                                         "circuits and witnesses, 1 proof (Python host logic + C field work, 1 thread; circuit "
+                                         "builds excluded: %.1f s)" % build_s,
+                               "cpu_over_gpu": cpu_ms / ms, "proofs_equal": True}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -511,7 +636,7 @@ def main():
                          "MMR; strong: one 2^log_leaves-leaf MMR split over the ranks (BASELINE's 2^24 at 1/2/4/8 GPUs).  "
                          "Config 5 (2^26 over 8 GPUs): --gpus 8 --log-leaves 23, or --scaling strong --log-leaves 26.")
     ap.add_argument("--variant", default=None, help="mds,partial (e.g. 2,0) Poseidon kernel variant")
-    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri", "prove"])
+    ap.add_argument("--workload", default="mmr", choices=["mmr", "commit", "fri", "prove", "recursion"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="mmr workload: skip the secondary ms/proof leg")
     ap.add_argument("--threads", type=int, default=32, help="--workload prove: concurrent provers for the throughput leg (1 = skip)")
@@ -552,6 +677,8 @@ def main():
         out = run_fri(args, torch, pkg, lib) if rank == 0 else None
     elif args.workload == "prove":
         out = run_prove(args, torch, pkg, lib) if rank == 0 else None
+    elif args.workload == "recursion":
+        out = run_recursion(args, torch, pkg, lib, cpu_baseline=not args.no_cpu_baseline) if rank == 0 else None
     else:
         out = run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist)
     if rank == 0 and out is not None:

@@ -1,0 +1,107 @@
+//! Cross-check of libp2mt_hip.so's prover conventions against real plonky2 @3b21b87d (run: `cargo +nightly run --release`).
+//!
+//! 1. builds the reference's `verify_mmr_proof_circuit(1, 2)` with real plonky2 and compares the deterministic circuit-level
+//!    values with p2mt_vectors.json: degree_bits, sorted gate ids, selector groups, circuit_digest, constants_sigmas_cap[0];
+//! 2. rebuilds a `ProofWithPublicInputs` from the proof WORDS this repository produced for that circuit (the word order is the one
+//!    documented in include/p2mt.h at p2mt_circuit_prove) and feeds it to plonky2's own `circuit_data.verify`.
+//! If (1) matches and (2) is accepted, every convention in DESIGN.md's "recalled conventions" checklist is confirmed at once
+//! (gate wire layouts, selector grouping, k_is, sigma, transcript order, FRI layout, PoW rule), and the "parity unpinned" label of
+//! the prover rows can be dropped.  A mismatch in (1) prints which value differs; that localises the convention to fix.
+use anyhow::Result;
+use plonky2::field::extension::quadratic::QuadraticExtension;
+use plonky2::field::goldilocks_field::GoldilocksField as F;
+use plonky2::field::polynomial::PolynomialCoeffs;
+use plonky2::field::types::Field;
+use plonky2::fri::proof::{FriInitialTreeProof, FriProof, FriQueryRound, FriQueryStep};
+use plonky2::hash::hash_types::HashOut;
+use plonky2::hash::merkle_proofs::MerkleProof;
+use plonky2::hash::merkle_tree::MerkleCap;
+use plonky2::hash::poseidon::PoseidonHash;
+use plonky2::plonk::config::PoseidonGoldilocksConfig as C;
+use plonky2::plonk::proof::{OpeningSet, Proof, ProofWithPublicInputs};
+use plonky2_merkle_trees::mmr::mmr_plonky2_verifier::verify_mmr_proof_circuit;
+
+type FE = QuadraticExtension<F>;
+const D: usize = 2;
+
+struct Words<'a> { w: &'a [u64], at: usize }
+impl<'a> Words<'a> {
+    fn f(&mut self) -> F { let v = F::from_canonical_u64(self.w[self.at]); self.at += 1; v }
+    fn fs(&mut self, n: usize) -> Vec<F> { (0..n).map(|_| self.f()).collect() }
+    fn e(&mut self) -> FE { let a = self.f(); let b = self.f(); FE::from_basefield_array([a, b]) }  // needs plonky2::field::extension::FieldExtension in scope
+    fn es(&mut self, n: usize) -> Vec<FE> { (0..n).map(|_| self.e()).collect() }
+    fn hash(&mut self) -> HashOut<F> { HashOut { elements: [self.f(), self.f(), self.f(), self.f()] } }
+    fn cap(&mut self, n: usize) -> MerkleCap<F, PoseidonHash> { MerkleCap((0..n).map(|_| self.hash()).collect()) }
+    fn path(&mut self, n: usize) -> MerkleProof<F, PoseidonHash> { MerkleProof { siblings: (0..n).map(|_| self.hash()).collect() } }
+}
+
+fn main() -> Result<()> {
+    let v: serde_json::Value = serde_json::from_str(&std::fs::read_to_string("p2mt_vectors.json")?)?;
+    let u = |x: &serde_json::Value| x.as_u64().unwrap();
+    let (data, _leaf_t, _proof_ts, _peak_ts) = verify_mmr_proof_circuit(1, 2);
+    let common = &data.common;
+
+    // ---- (1) circuit-level values
+    println!("degree_bits        plonky2 {}  p2mt {}", common.degree_bits(), v["degree_bits"]);
+    let ids: Vec<String> = common.gates.iter().map(|g| g.0.id()).collect();
+    println!("gates (sorted)     plonky2 {:?}\n                   p2mt    {}", ids, v["gates_sorted"]);
+    println!("selector groups    plonky2 {:?}  p2mt {}", common.selectors_info.groups, v["selector_groups"]);
+    println!("k_is[0..4]         plonky2 {:?}  p2mt {}", &common.k_is[..4], v["k_is_first4"]);
+    let digest: Vec<u64> = data.verifier_only.circuit_digest.elements.iter().map(|x| x.to_canonical_u64()).collect();
+    let cap0: Vec<u64> = data.verifier_only.constants_sigmas_cap.0[0].elements.iter().map(|x| x.to_canonical_u64()).collect();
+    println!("circuit_digest     plonky2 {:?}\n                   p2mt    {}", digest, v["circuit_digest"]);
+    println!("cs_cap[0]          plonky2 {:?}\n                   p2mt    {}", cap0, v["constants_sigmas_cap_0"]);
+    let digest_ok = digest == v["circuit_digest"].as_array().unwrap().iter().map(u).collect::<Vec<_>>();
+    let cap_ok = cap0 == v["constants_sigmas_cap_0"].as_array().unwrap().iter().map(u).collect::<Vec<_>>();
+    println!("=> circuit_digest {}  constants_sigmas_cap[0] {}", if digest_ok { "MATCH" } else { "DIFFER" }, if cap_ok { "MATCH" } else { "DIFFER" });
+
+    // ---- (2) this repository's proof through plonky2's verifier
+    let words: Vec<u64> = v["proof_words"].as_array().unwrap().iter().map(u).collect();
+    let mut w = Words { w: &words, at: 0 };
+    let cfg = &common.config;
+    let fri = &common.fri_params;
+    let n_cap = 1 << fri.config.cap_height;
+    let wires_cap = w.cap(n_cap);
+    let plonk_zs_partial_products_cap = w.cap(n_cap);
+    let quotient_polys_cap = w.cap(n_cap);
+    let nch = cfg.num_challenges;
+    let openings = OpeningSet {
+        constants: w.es(common.num_constants),
+        plonk_sigmas: w.es(cfg.num_routed_wires),
+        wires: w.es(cfg.num_wires),
+        plonk_zs: w.es(nch),
+        plonk_zs_next: w.es(nch),
+        partial_products: w.es(nch * common.num_partial_products),
+        quotient_polys: w.es(nch * common.quotient_degree_factor),
+    };
+    let commit_phase_merkle_caps: Vec<_> = fri.reduction_arity_bits.iter().map(|_| w.cap(n_cap)).collect();
+    let widths = [common.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + common.num_partial_products), nch * common.quotient_degree_factor];
+    let lde_bits = common.degree_bits() + fri.config.rate_bits;
+    let mut query_round_proofs = Vec::new();
+    for _ in 0..fri.config.num_query_rounds {
+        let mut plen = lde_bits - fri.config.cap_height;
+        let evals_proofs = widths.iter().map(|&wd| { let leaf = w.fs(wd); (leaf, w.path(plen)) }).collect();
+        let mut steps = Vec::new();
+        for &ab in &fri.reduction_arity_bits {
+            plen -= ab;
+            let evals = w.es(1 << ab);
+            steps.push(FriQueryStep { evals, merkle_proof: w.path(plen) });
+        }
+        query_round_proofs.push(FriQueryRound { initial_trees_proof: FriInitialTreeProof { evals_proofs }, steps });
+    }
+    let final_len = 1 << (common.degree_bits() - fri.reduction_arity_bits.iter().sum::<usize>());
+    let final_poly = PolynomialCoeffs::new(w.es(final_len));
+    let pow_witness = w.f();
+    let public_inputs = w.fs(common.num_public_inputs);
+    assert_eq!(w.at, words.len(), "proof word count does not match plonky2's shape for this circuit");
+    let proof = ProofWithPublicInputs::<F, C, D> {
+        proof: Proof { wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap, openings,
+                       opening_proof: FriProof { commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness } },
+        public_inputs,
+    };
+    match data.verify(proof) {
+        Ok(()) => println!("=> plonky2's verify ACCEPTS the proof produced by this repository: prover conventions confirmed"),
+        Err(e) => println!("=> plonky2's verify REJECTS the proof: {e:?} (compare step (1) first; then the transcript order / FRI layout)"),
+    }
+    Ok(())
+}
