@@ -347,10 +347,23 @@ class PartialWitness {  // PartialWitness::new() (:123)
   void set_hash_target(const HashOutTarget& t, const HashOut& v) {
     for (int i = 0; i < 4; ++i) set_target(t.elements[i], v.elements[i]);
   }
+  // pw.set_proof_with_pis_target / pw.set_verifier_data_target (mmr_plonky2_verifier_1_recursion.rs:201-202): defined below
+  void set_proof_with_pis_target(const struct ProofWithPublicInputsTarget& target, const struct ProofWithPublicInputs& proof);
+  void set_verifier_data_target(const struct VerifierCircuitTarget& target, const class CircuitData& inner);
   p2mt_partial_witness* handle() const { return h_; }
 
  private:
   p2mt_partial_witness* h_ = nullptr;
+};
+
+// ProofWithPublicInputsTarget<2>: one target per word of a proof of the inner circuit (the order p2mt_circuit_prove writes)
+struct ProofWithPublicInputsTarget {
+  std::vector<Target> targets;
+  std::vector<Target> public_inputs;  // the last num_public_inputs targets
+};
+// VerifierCircuitTarget: constants_sigmas_cap [16][4] then circuit_digest [4]
+struct VerifierCircuitTarget {
+  std::vector<Target> targets;
 };
 
 // ProofWithPublicInputs as the words p2mt_circuit_prove returns (field order of plonky2's serialisation, see p2mt.h)
@@ -389,6 +402,10 @@ class CircuitData {  // CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2
     check(p2mt_circuit_constants_sigmas(h_, nullptr, nullptr, d.elements.data()));
     return d;
   }
+  p2mt_circuit_data* handle() const { return h_; }
+  // `inner_circuit_data.common` / `.verifier_only`: the handle carries both
+  const CircuitData& common() const { return *this; }
+  const CircuitData& verifier_only() const { return *this; }
   p2mt_circuit_info info{};
   struct {
     std::vector<Target> public_inputs;
@@ -397,6 +414,14 @@ class CircuitData {  // CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2
  private:
   p2mt_circuit_data* h_ = nullptr;
 };
+
+inline void PartialWitness::set_proof_with_pis_target(const ProofWithPublicInputsTarget& target, const ProofWithPublicInputs& proof) {
+  if (target.targets.size() != proof.words.size()) throw panic(P2MT_EINVAL, "proof does not match its target");
+  check(p2mt_pw_set_proof_with_pis_target(h_, target.targets.data(), proof.words.data(), proof.words.size()));
+}
+inline void PartialWitness::set_verifier_data_target(const VerifierCircuitTarget& target, const CircuitData& inner) {
+  check(p2mt_pw_set_verifier_data_target(h_, target.targets.data(), inner.handle()));
+}
 
 class CircuitBuilder {  // CircuitBuilder::<F, 2>::new(CircuitConfig::standard_recursion_config()) (:30-31)
  public:
@@ -444,6 +469,25 @@ class CircuitBuilder {  // CircuitBuilder::<F, 2>::new(CircuitConfig::standard_r
     HashOutTarget h;
     check(p2mt_cb_hash_n_to_hash_no_pad(h_, inputs.data(), inputs.size(), h.elements.data()));
     return h;
+  }
+  // ---- recursion (mmr_plonky2_verifier_1_recursion.rs:95-104): plonky2's in-circuit verifier, built inside the library
+  ProofWithPublicInputsTarget add_virtual_proof_with_pis(const CircuitData& inner_common) {
+    ProofWithPublicInputsTarget t;
+    t.targets.resize(inner_common.info.proof_len);
+    check(p2mt_cb_add_virtual_proof_with_pis(h_, inner_common.handle(), t.targets.data(), t.targets.size()));
+    t.public_inputs.assign(t.targets.end() - inner_common.info.num_public_inputs, t.targets.end());
+    return t;
+  }
+  VerifierCircuitTarget add_virtual_verifier_data(unsigned cap_height) {
+    VerifierCircuitTarget t;
+    t.targets.resize(68);
+    check(p2mt_cb_add_virtual_verifier_data(h_, cap_height, t.targets.data()));
+    return t;
+  }
+  void verify_proof(const ProofWithPublicInputsTarget& proof_with_pis, const VerifierCircuitTarget& inner_verifier_data,
+                    const CircuitData& inner_common) {  // builder.verify_proof::<PoseidonGoldilocksConfig>(...)
+    check(p2mt_cb_verify_proof(h_, proof_with_pis.targets.data(), proof_with_pis.targets.size(), inner_verifier_data.targets.data(),
+                               inner_common.handle()));
   }
   void register_public_inputs(const std::array<Target, 4>& t) { check(p2mt_cb_register_public_inputs(h_, t.data(), 4)); }
   void register_public_input(Target t) { check(p2mt_cb_register_public_inputs(h_, &t, 1)); }
@@ -577,6 +621,40 @@ inline InnerMerkleProofCircuit verify_inner_merkle_proof_circuit(std::size_t nr_
   builder.connect(builder.one(), hash_in_peaks.target);
   return InnerMerkleProofCircuit{builder.build(), leaf_to_prove, std::move(proof_targets)};
 }
-// complete_verification_circuit_with_inner_proof (:84-140) needs plonky2's in-circuit verifier (builder.verify_proof): not built.
+
+// ---------------------------------------------------------------- :84-140 (outer circuit)
+struct CompleteVerificationCircuit {
+  CircuitData data;
+  ProofWithPublicInputsTarget prev_proof_target;
+  VerifierCircuitTarget prev_proof_verifier_data;
+  std::vector<HashOutTarget> targets;
+};
+inline CompleteVerificationCircuit complete_verification_circuit_with_inner_proof(const CircuitData& inner_proof_circuit_data_common,
+                                                                                  std::size_t nr_peaks) {
+  CircuitBuilder builder;
+  ProofWithPublicInputsTarget prev_proof_target = builder.add_virtual_proof_with_pis(inner_proof_circuit_data_common);
+  VerifierCircuitTarget prev_proof_verifier_data = builder.add_virtual_verifier_data(4);  // common.config.fri_config.cap_height
+  builder.verify_proof(prev_proof_target, prev_proof_verifier_data, inner_proof_circuit_data_common);
+  std::vector<HashOutTarget> targets, peaks;
+  std::vector<BoolTarget> equals;
+  HashOutTarget prev_hash;  // HashOutTarget::from_vec(prev_proof_target.public_inputs[0..4]): the FIRST peak (quirk Q4)
+  for (int k = 0; k < 4; ++k) prev_hash.elements[k] = prev_proof_target.public_inputs.at(k);
+  for (std::size_t k = 0; k < nr_peaks; ++k) {
+    const HashOutTarget peak = builder.add_virtual_hash();
+    peaks.push_back(peak);
+    targets.push_back(peak);
+    equals.push_back(equal(builder, peak, prev_hash));
+  }
+  const BoolTarget hash_in_peaks = or_list(builder, equals);
+  builder.connect(builder.one(), hash_in_peaks.target);
+  if (peaks.size() > 1) {
+    std::vector<Target> all;
+    for (auto& p : peaks) all.insert(all.end(), p.elements.begin(), p.elements.end());
+    builder.register_public_inputs(builder.hash_n_to_hash_no_pad(all).elements);
+  } else {
+    builder.register_public_inputs(peaks.at(0).elements);
+  }
+  return CompleteVerificationCircuit{builder.build(), std::move(prev_proof_target), std::move(prev_proof_verifier_data), std::move(targets)};
+}
 
 }  // namespace p2mt

@@ -362,21 +362,32 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
   set[slot] = 1;
 }
 
+// bit 8 of WOp::kind: every output slot of this generator is still unset when it runs (the scheduler knows: it is the first
+// writer of each) -- the common case.  Such a generator stores without reading the slot first: a `put` is a dependent global
+// round trip, and a gate-row generator has up to 86 of them in sequence.
+constexpr u32 kFreshOutputs = 0x100;
+template <bool FRESH, typename Mem>
+GL_DEV void put_out(const Mem& m, u32 slot, u64 v, int* err, u32 op_index) {
+  if constexpr (FRESH) m.store(slot, gl::canon(v));
+  else put(m, slot, v, err, op_index);
+}
+
 // The generators of the recursion gates (one lane each).  tab: dense wire -> slot table [row * 135 + col]; args: the slot lists of
 // the generators that are not tied to a gate row.  What each computes is the gate's own generator in plonky2:
 // ArithmeticExtensionGenerator, MulExtensionGenerator, QuotientGeneratorExtension, ReducingGenerator (both gates),
 // WireSplitGenerator, BaseSplitGenerator<2>, RandomAccessGenerator, InterpolationGenerator, PoseidonMdsGenerator.
-template <typename Mem>
+// Operands are loaded up front (independent loads in flight together), then the dependent arithmetic, then the stores.
+template <bool FRESH, typename Mem>
 GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
                                     int* err) {
   const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
   auto G = [&](u32 col) { return m.get(S[col]); };
   auto GE = [&](u32 col) { return DE{m.get(S[col]), m.get(S[col + 1])}; };
   auto PE = [&](u32 col, DE v) {
-    put(m, S[col], v.a, err, o);
-    put(m, S[col + 1], v.b, err, o);
+    put_out<FRESH>(m, S[col], v.a, err, o);
+    put_out<FRESH>(m, S[col + 1], v.b, err, o);
   };
-  switch (op.kind) {
+  switch (op.kind & 0xFF) {
     case GEN_ARITH_EXT: {
       const u32 at = 8 * op.b;
       PE(at + 6, de_add(de_scale(de_mul(GE(at), GE(at + 2)), op.c0), de_scale(GE(at + 4), op.c1)));
@@ -391,29 +402,33 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       const u32* A = args + op.a;
       const DE num{m.get(A[0]), m.get(A[1])}, den{m.get(A[2]), m.get(A[3])};
       const DE q = de_mul(num, de_inv(den));
-      put(m, A[4], q.a, err, o);
-      put(m, A[5], q.b, err, o);
+      put_out<FRESH>(m, A[4], q.a, err, o);
+      put_out<FRESH>(m, A[5], q.b, err, o);
       break;
     }
     case GEN_REDUCING: {
+      u64 coeff[kReducingCoeffs];
+#pragma unroll
+      for (u32 i = 0; i < kReducingCoeffs; ++i) coeff[i] = G(6 + i);
       const DE alpha = GE(2);
       DE acc = GE(4);
-#pragma unroll 1
+#pragma unroll
       for (u32 i = 0; i < kReducingCoeffs; ++i) {
         acc = de_mul(acc, alpha);
-        acc.a = gl::add(acc.a, G(6 + i));
-        acc.a = gl::canon(acc.a), acc.b = gl::canon(acc.b);
+        acc.a = gl::add(acc.a, coeff[i]);
         PE(i == kReducingCoeffs - 1 ? 0 : 6 + kReducingCoeffs + 2 * i, acc);
       }
       break;
     }
     case GEN_REDUCING_EXT: {
+      DE coeff[kReducingExtCoeffs];
+#pragma unroll
+      for (u32 i = 0; i < kReducingExtCoeffs; ++i) coeff[i] = GE(6 + 2 * i);
       const DE alpha = GE(2);
       DE acc = GE(4);
-#pragma unroll 1
+#pragma unroll
       for (u32 i = 0; i < kReducingExtCoeffs; ++i) {
-        acc = de_add(de_mul(acc, alpha), GE(6 + 2 * i));
-        acc.a = gl::canon(acc.a), acc.b = gl::canon(acc.b);
+        acc = de_add(de_mul(acc, alpha), coeff[i]);
         PE(i == kReducingExtCoeffs - 1 ? 0 : 6 + 2 * kReducingExtCoeffs + 2 * i, acc);
       }
       break;
@@ -422,7 +437,7 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       const u32* A = args + op.a;
       u64 v = gl::canon(m.get(A[0]));
       for (u32 k = 1; k < op.b; ++k) {
-        put(m, A[k], v & ((1ull << kBaseSumLimbs) - 1), err, o);
+        put_out<FRESH>(m, A[k], v & ((1ull << kBaseSumLimbs) - 1), err, o);
         v >>= kBaseSumLimbs;
       }
       if (v) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in the BaseSumGates"
@@ -431,8 +446,8 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
     case GEN_BASE_SPLIT: {
       const u64 v = gl::canon(G(0));
       if (v >> kBaseSumLimbs) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in given number of limbs"
-#pragma unroll 1
-      for (u32 j = 0; j < kBaseSumLimbs; ++j) put(m, S[1 + j], (v >> j) & 1, err, o);
+#pragma unroll 9
+      for (u32 j = 0; j < kBaseSumLimbs; ++j) put_out<FRESH>(m, S[1 + j], (v >> j) & 1, err, o);
       break;
     }
     case GEN_RANDOM_ACCESS: {
@@ -442,45 +457,46 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
         atomicCAS(err, 0, (int)o + 1);  // "Access index is larger than the vector size"
         break;
       }
-      put(m, S[at + 1], G(at + 2 + (u32)idx), err, o);
-      for (u32 j = 0; j < kRaBits; ++j) put(m, S[74 + kRaBits * op.b + j], (idx >> j) & 1, err, o);
+      put_out<FRESH>(m, S[at + 1], G(at + 2 + (u32)idx), err, o);
+      for (u32 j = 0; j < kRaBits; ++j) put_out<FRESH>(m, S[74 + kRaBits * op.b + j], (idx >> j) & 1, err, o);
       break;
     }
     case GEN_INTERPOLATION: {
+      DE vals[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vals[i] = GE(1 + 2 * i);
       const DE point = GE(33);
       const DE x = de_scale(point, gl_inv(gl::canon(G(0))));  // shifted_evaluation_point = evaluation_point / shift
       PE(45, x);
       DE ev{0, 0}, pr{1, 0};
-      auto partial = [&](int from, int to) {
-#pragma unroll 1
-        for (int i = from; i < to; ++i) {
-          const DE term{gl::sub_c(x.a, gates_rec::kCosetDomainDev[i]), x.b};
-          const DE weighted = de_scale(GE(1 + 2 * i), gates_rec::kCosetWeightsDev[i]);
-          ev = de_add(de_mul(ev, term), de_mul(weighted, pr));
-          pr = de_mul(pr, term);
-        }
+      auto step = [&](int i) {
+        const DE term{gl::sub_c(x.a, gates_rec::kCosetDomainDev[i]), x.b};
+        const DE weighted = de_scale(vals[i], gates_rec::kCosetWeightsDev[i]);
+        ev = de_add(de_mul(ev, term), de_mul(weighted, pr));
+        pr = de_mul(pr, term);
       };
-      partial(0, 6);
-#pragma unroll 1
-      for (int i = 0; i < 2; ++i) {
-        ev.a = gl::canon(ev.a), ev.b = gl::canon(ev.b), pr.a = gl::canon(pr.a), pr.b = gl::canon(pr.b);
-        PE(37 + 2 * i, ev);
-        PE(41 + 2 * i, pr);
-        const int start = 1 + 5 * (i + 1);
-        partial(start, start + 5 < 16 ? start + 5 : 16);
-      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) step(i);
+      PE(37, ev);
+      PE(41, pr);
+#pragma unroll
+      for (int i = 6; i < 11; ++i) step(i);
+      PE(39, ev);
+      PE(43, pr);
+#pragma unroll
+      for (int i = 11; i < 16; ++i) step(i);
       PE(35, ev);
       break;
     }
     case GEN_POSEIDON_MDS: {
-#pragma unroll 1
+      DE st[12];
+#pragma unroll
+      for (u32 i = 0; i < 12; ++i) st[i] = GE(2 * i);
+#pragma unroll
       for (u32 r = 0; r < 12; ++r) {
-        DE acc = r == 0 ? de_scale(GE(0), 8) : DE{0, 0};
-#pragma unroll 1
-        for (u32 i = 0; i < 12; ++i) {
-          const u32 src = i + r >= 12 ? i + r - 12 : i + r;
-          acc = de_add(acc, de_scale(GE(2 * src), gates_rec::mds_circ((int)i)));
-        }
+        DE acc = r == 0 ? de_scale(st[0], 8) : DE{0, 0};
+#pragma unroll
+        for (u32 i = 0; i < 12; ++i) acc = de_add(acc, de_scale(st[(i + r) % 12], gates_rec::mds_circ((int)i)));
         PE(24 + 2 * r, acc);
       }
       break;
@@ -490,24 +506,31 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 }
 
 // ArithmeticBaseGenerator / EqualityGenerator (slots in the record itself) or one of the generators above
+template <bool FRESH, typename Mem>
+GL_DEV void run_lane_generator_f(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
+                                 int* err) {
+  const u32 kind = op.kind & 0xFF;
+  if (kind == GEN_ARITH) {
+    const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
+    put_out<FRESH>(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
+  } else if (kind == GEN_EQUALITY) {
+    const u64 x = m.get(op.a), y = m.get(op.b);
+    put_out<FRESH>(m, op.out, x == y ? 1 : 0, err, o);
+    put_out<FRESH>(m, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
+  } else {
+    run_recursion_generator<FRESH>(m, op, o, tab, args, err);
+  }
+}
 template <typename Mem>
 GL_DEV void run_lane_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args, int* err) {
-  if (op.kind == GEN_ARITH) {
-    const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
-    put(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
-  } else if (op.kind == GEN_EQUALITY) {
-    const u64 x = m.get(op.a), y = m.get(op.b);
-    put(m, op.out, x == y ? 1 : 0, err, o);
-    put(m, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
-  } else {
-    run_recursion_generator(m, op, o, tab, args, err);
-  }
+  if (op.kind & kFreshOutputs) run_lane_generator_f<true>(m, op, o, tab, args, err);
+  else run_lane_generator_f<false>(m, op, o, tab, args, err);
 }
 
 // PoseidonGenerator on one wavefront (lane w < 12 owns state word w): reads the 12 inputs and the swap bit, writes the 12 outputs.
 // ps: this lane's slot among the row's wires 0..24 (lane < 25).
 template <typename Mem>
-GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, int* err, const PermCtx& ctx) {
+GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, bool fresh, int* err, const PermCtx& ctx) {
   const u32 swap_slot = __shfl(ps, 24), out_slot = __shfl(ps, (lane + 12) & 31);
   u64 x = lane < 12 ? m.get(ps) : 0;
   const u64 swap = m.get(swap_slot);
@@ -515,7 +538,10 @@ GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, int* e
   if (lane < 4) x = gl::add(x, gl::mul(swap, fsub(partner, x)));       // the permutation runs on the swapped state
   else if (lane < 8) x = fsub(x, gl::mul(swap, fsub(x, partner)));
   x = permute_wave(x, ctx);  // outputs only: the row's delta / S-box wires are filled afterwards (k_poseidon_rows)
-  if (lane < 12) put(m, out_slot, x, err, o);
+  if (lane < 12) {
+    if (fresh) m.store(out_slot, gl::canon(x));
+    else put(m, out_slot, x, err, o);
+  }
 }
 
 // One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
@@ -574,11 +600,9 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
     if (l + 1 < n_levels && L[2 * (l + 1) + 2] <= ch_end) lookup(l + 1, nxt_ps);  // else: after the next staging
     for (u32 o = s + wave; o < s + np; o += n_waves) {  // wave-uniform
       u32 ps = cur_ps;
-      if (o != s + wave) {  // more PoseidonGate rows in this level than wavefronts
-        const WOp po = OP(o);
-        ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;
-      }
-      run_poseidon_generator(m, ps, lane, o, err, ctx);
+      const WOp po = OP(o);
+      if (o != s + wave) ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;  // more PoseidonGate rows in this level than wavefronts
+      run_poseidon_generator(m, ps, lane, o, (po.kind & kFreshOutputs) != 0, err, ctx);
     }
     for (u32 o = s + np + tid; o < e; o += kBlock) run_lane_generator(m, OP(o), o, tab, args, err);
     m.sync();
@@ -626,8 +650,9 @@ __global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
     for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
-      const u32 ps = lane < 25 ? pslots[(size_t)ops[o].b * 32 + lane] : 0;
-      run_poseidon_generator(m, ps, lane, o, err, ctx);
+      const u32 pb = ops[o].b, pk = ops[o].kind;
+      const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
+      run_poseidon_generator(m, ps, lane, o, (pk & kFreshOutputs) != 0, err, ctx);
     }
     for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
     // grid-wide barrier
@@ -1218,6 +1243,11 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
       level = std::max(level, set_level[out[k]]);  // a check waits for the value it checks
     }
     ++level;
+    bool fresh = true;  // first writer of every output slot (duplicates within the list count as already written)
+    for (u32 k = 0; k < n_out; ++k) {
+      fresh &= set_level[out[k]] < 0;
+      for (u32 j = 0; j < k; ++j) fresh &= out[j] != out[k];
+    }
     for (u32 k = 0; k < n_out; ++k)
       if (set_level[out[k]] < 0) {
         set_level[out[k]] = level;
@@ -1226,7 +1256,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
         watchers[out[k]].clear();
       }
     WOp op{};
-    op.kind = (u32)g.kind;
+    op.kind = (u32)g.kind | (fresh ? kFreshOutputs : 0);
     op.c0 = g.c0;
     op.c1 = g.c1;
     switch (g.kind) {
@@ -1253,7 +1283,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
   }
   if (items.size() != n_gens) return p2mt::fail(P2MT_EINVAL, "prove: some generators weren't run (a target they depend on was never set)");
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
-    return a.level != b.level ? a.level < b.level : (a.op.kind == GEN_POSEIDON) > (b.op.kind == GEN_POSEIDON);
+    return a.level != b.level ? a.level < b.level : ((a.op.kind & 0xFF) == GEN_POSEIDON) > ((b.op.kind & 0xFF) == GEN_POSEIDON);
   });
   std::vector<WOp> ops(items.size());
   std::vector<u32> lvl;
@@ -1265,7 +1295,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
       lvl.push_back((u32)k);
       lvl.push_back(0);
     }
-    if (items[k].op.kind == GEN_POSEIDON) ++lvl.back();
+    if ((items[k].op.kind & 0xFF) == GEN_POSEIDON) ++lvl.back();
   }
   lvl.push_back((u32)items.size());
   c->n_levels = (u32)(lvl.size() / 2);

@@ -230,6 +230,34 @@ static void test_inner_merkle_proof_3leaves() {
     for (int k = 0; k < 4; ++k) REQUIRE(proof.public_inputs[4 * i + k] == pr.peaks[i].elements[k]);
 }
 
+// mmr_plonky2_verifier_1_recursion.rs:152-221 test_complete_verification_circuit_with_inner_proof, leaves (1..7), leaf index 5
+// (:229-236: 3 peaks; the leaf sits in the second mountain, quirk Q4 lets the outer check pass)
+static void test_mmr_verifier_1_recursion_7leaves() {
+  MMR mmr = MMR::from_leaves({1, 2, 3, 4, 5, 6, 7});
+  const MMR_proof pr = mmr.get_proof(get_mmr_index(5));
+  InnerMerkleProofCircuit inner = verify_inner_merkle_proof_circuit(pr.merkle_proof.size(), pr.peaks.size());
+  PartialWitness pw1;
+  pw1.set_target(inner.leaf_to_prove, 6);
+  for (std::size_t i = 0; i < pr.merkle_proof.size(); ++i) {
+    pw1.set_hash_target(inner.proof_targets[i].first, pr.merkle_proof[i].first);
+    pw1.set_bool_target(inner.proof_targets[i].second, pr.merkle_proof[i].second);
+  }
+  for (std::size_t i = 0; i < pr.peaks.size(); ++i)
+    for (int k = 0; k < 4; ++k) pw1.set_target(inner.data.prover_only.public_inputs[4 * i + k], pr.peaks[i].elements[k]);
+  const ProofWithPublicInputs inner_proof = inner.data.prove(pw1);
+  CompleteVerificationCircuit outer = complete_verification_circuit_with_inner_proof(inner.data.common(), pr.peaks.size());
+  REQUIRE(outer.data.info.degree_bits == 12);
+  PartialWitness pw2;
+  pw2.set_proof_with_pis_target(outer.prev_proof_target, inner_proof);
+  pw2.set_verifier_data_target(outer.prev_proof_verifier_data, inner.data.verifier_only());
+  for (std::size_t i = 0; i < pr.peaks.size(); ++i) pw2.set_hash_target(outer.targets[i], pr.peaks[i]);
+  const HashOut root = mmr.bagging_the_peaks();
+  for (int k = 0; k < 4; ++k) pw2.set_target(outer.data.prover_only.public_inputs[k], root.elements[k]);
+  const ProofWithPublicInputs final_proof = outer.data.prove(pw2);
+  outer.data.verify(final_proof);
+  for (int k = 0; k < 4; ++k) REQUIRE(final_proof.public_inputs[k] == root.elements[k]);
+}
+
 int main() {
   if (p2mt_device_count() == 0) { std::fprintf(stderr, "no GPU: the product has no CPU fallback\n"); return 77; }
   check(p2mt_init(0));
@@ -244,6 +272,7 @@ int main() {
   test_challenger_and_fri();
   test_mmr_verifier_3leaves();
   test_inner_merkle_proof_3leaves();
-  std::puts("cpp mirror: 8 reference tests + prover pieces passed");
+  test_mmr_verifier_1_recursion_7leaves();
+  std::puts("cpp mirror: 8 reference tests + prover pieces + the recursion passed");
   return 0;
 }

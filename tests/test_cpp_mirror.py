@@ -31,4 +31,4 @@ def test_reference_unit_tests_through_cpp_mirror():
         _build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "8 reference tests + prover pieces passed" in r.stdout
+    assert "8 reference tests + prover pieces + the recursion passed" in r.stdout
