@@ -343,6 +343,39 @@ struct LMem {
   GL_DEV void sync() const { __syncthreads(); }
 };
 
+// Dataflow table (k_witness_flow): a value is its own "set" flag -- canonical field elements are < p, so the all-ones word never
+// occurs as a value and marks an unset slot.  get() WAITS for the slot (bounded: a wait that exceeds its budget raises err[2] and
+// from then on every wait returns at once, so the launch always drains).  `set` is kept up to date for k_witness_scatter.
+constexpr u64 kUnsetValue = ~0ull;
+constexpr u32 kFlowSpinBudget = 1u << 22;
+struct FMem {
+  u64* vals;
+  u32* set;
+  int* err;
+  GL_DEV u64 get(u32 s) const {
+    u64 v = ld64(vals + s);
+    u32 spins = 0;
+    while (v == kUnsetValue) {
+      if (ld32(reinterpret_cast<const u32*>(err) + 2) != 0 || ++spins > kFlowSpinBudget) {
+        atomicExch(err + 2, 1);
+        return 0;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      v = ld64(vals + s);
+    }
+    return v;
+  }
+  GL_DEV bool is_set(u32 s) const {  // a generator that re-derives an already written slot waits for its first writer, then compares
+    (void)get(s);
+    return true;
+  }
+  GL_DEV void store(u32 s, u64 v) const {
+    st64(vals + s, v);
+    st32(set + s, 1);
+  }
+  GL_DEV void sync() const {}
+};
+
 // PartitionWitness::set_target: a slot already holding a value must agree (plonky2 panics otherwise)
 template <typename Mem>
 GL_DEV void put(const Mem& m, u32 slot, u64 v, int* err, u32 op_index) {
@@ -673,6 +706,35 @@ __global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__
     }
     __syncthreads();
     if (abort_flag) return;  // block-uniform
+  }
+}
+
+// Dataflow form of the same schedule (the default for circuits whose table lives in global memory): no barrier at all.  The
+// generators keep their level order and their static assignment (PoseidonGate rows one per wavefront over all wavefronts of the
+// grid, the others one per lane over all lanes), but each simply WAITS for its operands (FMem::get) instead of for the whole
+// level.  Deadlock-free as long as every workgroup is resident (kGridBlocks << what the device holds): every wavefront runs its
+// generators in non-decreasing level order and a generator only reads slots written at strictly lower levels, so the unfinished
+// generator of lowest level can always run.  What it buys: a dependent step costs one store -> load hand-off (~2 us) instead of
+// a grid-wide barrier plus the slowest generator of the level (~15 us on top of a PoseidonGate row's 9.5 us); the outer
+// recursion circuit's 124 levels took 3.2 ms with barriers, 1.7 ms this way (critical path: the 110-permutation transcript).
+__global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                                                         u64* vals, u32* set, const u32* __restrict__ pslots,
+                                                         const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
+                                                         PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  ctx = stage_round_constants(rc_lds, ctx);
+  const FMem m{vals, set, err};
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = kBlock / 64;
+  const u32 gwave = blockIdx.x * waves_per_block + wave, n_gwaves = gridDim.x * waves_per_block;
+  const u32 gtid = blockIdx.x * kBlock + tid, n_gthreads = gridDim.x * kBlock;
+  for (u32 l = 0; l < n_levels; ++l) {
+    const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
+    for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
+      const u32 pb = ops[o].b, pk = ops[o].kind;
+      const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
+      run_poseidon_generator(m, ps, lane, o, (pk & kFreshOutputs) != 0, err, ctx);
+    }
+    for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
   }
 }
 
@@ -1368,16 +1430,21 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
     return fill_poseidon_rows(c);
   }
   P2MT_HIP(hipMemsetAsync(c->d_set, 0, (size_t)c->n_slots * 4, st));
+  P2MT_HIP(hipMemsetAsync(c->d_vals, 0xFF, (size_t)c->n_slots * 8, st));  // kUnsetValue everywhere (k_witness_flow waits on it)
   hipLaunchKernelGGL(k_witness_init, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
                      c->d_set);
   P2MT_LAUNCH_CHECK();
-  // Wide circuits (more generators than one workgroup can usefully hold per level) run the level interpreter over the whole grid;
-  // env P2MT_WITNESS_GRID=0 forces the single-workgroup interpreter (A/B and fallback).
-  static const bool grid_ok = [] {
+  // Interpreter for tables in global memory: 2 (default) = dataflow over the whole grid (k_witness_flow), 1 = level-synchronous
+  // over the whole grid (k_witness_grid), 0 = one workgroup (k_witness_run); env P2MT_WITNESS_GRID selects (A/B and fallback).
+  static const int mode = [] {
     const char* e = getenv("P2MT_WITNESS_GRID");
-    return !(e && e[0] == '0');
+    return e ? atoi(e) : 2;
   }();
-  if (grid_ok && c->gens.size() >= 4096) {
+  if (mode == 2) {
+    hipLaunchKernelGGL(k_witness_flow, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
+                       c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
+                       p2mt::perm_ctx());
+  } else if (mode == 1) {
     P2MT_HIP(hipMemsetAsync(c->d_sync, 0, 8, st));
     hipLaunchKernelGGL(k_witness_grid, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
                        c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
@@ -1399,7 +1466,7 @@ int witness_status(p2mt_circuit_data* c, const int* err) {
   if (err[0] == -1) return p2mt::fail(P2MT_EINVAL, "prove: a public input target was never set");
   if (err[0] != 0) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
   if (err[1] != 0) return p2mt::fail(P2MT_EINVAL, "prove: zero denominator in the permutation argument (plonky2 panics on this division)");
-  if (err[2] != 0) return p2mt::fail(P2MT_EHIP, "prove: the grid-wide witness interpreter gave up waiting at a level barrier");
+  if (err[2] != 0) return p2mt::fail(P2MT_EHIP, "prove: the grid-wide witness interpreter gave up waiting (level barrier / operand never written)");
   return P2MT_OK;
 }
 

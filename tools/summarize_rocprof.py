@@ -15,13 +15,13 @@ import sys
 
 def main(d, builds):
     out = []
-    for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
+    for f in glob.glob(os.path.join(d, "trace", "**", "*_kernel_stats.csv"), recursive=True):
         out.append("== kernel-trace --stats (%s)" % os.path.relpath(f, d))
         for r in csv.DictReader(open(f)):
             out.append("%-90s calls=%-5s total_ms=%9.3f avg_us=%10.2f  %5s%%  min_us=%9.2f max_us=%9.2f" % (
                 r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                 r["Percentage"], float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
-    for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv"))):
+    for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*_counter_collection.csv"), recursive=True)):
         out.append("== pmc pass %s (sums over all dispatches; %d builds in this run)" % (os.path.relpath(f, d), builds))
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         calls = collections.Counter()
