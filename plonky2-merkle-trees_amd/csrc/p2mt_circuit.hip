@@ -395,13 +395,26 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
   set[slot] = 1;
 }
 
-// bit 8 of WOp::kind: every output slot of this generator is still unset when it runs (the scheduler knows: it is the first
-// writer of each) -- the common case.  Such a generator stores without reading the slot first: a `put` is a dependent global
-// round trip, and a gate-row generator has up to 86 of them in sequence.
-constexpr u32 kFreshOutputs = 0x100;
-template <bool FRESH, typename Mem>
-GL_DEV void put_out(const Mem& m, u32 slot, u64 v, int* err, u32 op_index) {
-  if constexpr (FRESH) m.store(slot, gl::canon(v));
+// Which of a generator's outputs it is the FIRST writer of (the scheduler knows).  A first write stores without reading the slot
+// (a `put` is a dependent global round trip, and a gate-row generator has up to 86 of them in sequence); any other output is a
+// check: the slot is compared with the value derived here -- plonky2's "set twice with different values" panic -- which in the
+// dataflow interpreter first waits for the slot's first writer.  Encoding: bit 8 of WOp::kind = every output is a first write (the
+// common case).  Otherwise one bit per output, in the order gen_targets() lists them: ArithmeticBase / Equality in bits 9-10 of
+// kind; every other generator in the 96 bits (c, out, out2), which those kinds do not use otherwise.
+constexpr u32 kFreshOutputs = 0x100, kFreshBit0 = 0x200, kFreshBit1 = 0x400;
+struct Fresh {
+  bool all;
+  u32 m[3];
+  GL_DEV bool at(u32 ord) const { return all || ((m[ord >> 5] >> (ord & 31)) & 1); }
+};
+GL_DEV Fresh fresh_of(const WOp& op) {
+  const u32 kind = op.kind & 0xFF;
+  if (kind == GEN_ARITH || kind == GEN_EQUALITY) return Fresh{(op.kind & kFreshOutputs) != 0, {(op.kind >> 9) & 3, 0, 0}};
+  return Fresh{(op.kind & kFreshOutputs) != 0, {op.c, op.out, op.out2}};
+}
+template <typename Mem>
+GL_DEV void put_out(const Mem& m, u32 slot, u64 v, bool fresh, int* err, u32 op_index) {
+  if (fresh) m.store(slot, gl::canon(v));
   else put(m, slot, v, err, op_index);
 }
 
@@ -410,33 +423,34 @@ GL_DEV void put_out(const Mem& m, u32 slot, u64 v, int* err, u32 op_index) {
 // ArithmeticExtensionGenerator, MulExtensionGenerator, QuotientGeneratorExtension, ReducingGenerator (both gates),
 // WireSplitGenerator, BaseSplitGenerator<2>, RandomAccessGenerator, InterpolationGenerator, PoseidonMdsGenerator.
 // Operands are loaded up front (independent loads in flight together), then the dependent arithmetic, then the stores.
-template <bool FRESH, typename Mem>
+template <typename Mem>
 GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
                                     int* err) {
+  const Fresh fr = fresh_of(op);
   const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
   auto G = [&](u32 col) { return m.get(S[col]); };
   auto GE = [&](u32 col) { return DE{m.get(S[col]), m.get(S[col + 1])}; };
-  auto PE = [&](u32 col, DE v) {
-    put_out<FRESH>(m, S[col], v.a, err, o);
-    put_out<FRESH>(m, S[col + 1], v.b, err, o);
+  auto PE = [&](u32 col, DE v, u32 ord) {  // ord: ordinal of the pair's first word among the generator's outputs
+    put_out(m, S[col], v.a, fr.at(ord), err, o);
+    put_out(m, S[col + 1], v.b, fr.at(ord + 1), err, o);
   };
   switch (op.kind & 0xFF) {
     case GEN_ARITH_EXT: {
       const u32 at = 8 * op.b;
-      PE(at + 6, de_add(de_scale(de_mul(GE(at), GE(at + 2)), op.c0), de_scale(GE(at + 4), op.c1)));
+      PE(at + 6, de_add(de_scale(de_mul(GE(at), GE(at + 2)), op.c0), de_scale(GE(at + 4), op.c1)), 0);
       break;
     }
     case GEN_MUL_EXT: {
       const u32 at = 6 * op.b;
-      PE(at + 4, de_scale(de_mul(GE(at), GE(at + 2)), op.c0));
+      PE(at + 4, de_scale(de_mul(GE(at), GE(at + 2)), op.c0), 0);
       break;
     }
     case GEN_QUOTIENT_EXT: {
       const u32* A = args + op.a;
       const DE num{m.get(A[0]), m.get(A[1])}, den{m.get(A[2]), m.get(A[3])};
       const DE q = de_mul(num, de_inv(den));
-      put_out<FRESH>(m, A[4], q.a, err, o);
-      put_out<FRESH>(m, A[5], q.b, err, o);
+      put_out(m, A[4], q.a, fr.at(0), err, o);
+      put_out(m, A[5], q.b, fr.at(1), err, o);
       break;
     }
     case GEN_REDUCING: {
@@ -449,7 +463,8 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       for (u32 i = 0; i < kReducingCoeffs; ++i) {
         acc = de_mul(acc, alpha);
         acc.a = gl::add(acc.a, coeff[i]);
-        PE(i == kReducingCoeffs - 1 ? 0 : 6 + kReducingCoeffs + 2 * i, acc);
+        if (i == kReducingCoeffs - 1) PE(0, acc, 0);
+        else PE(6 + kReducingCoeffs + 2 * i, acc, 2 + 2 * i);
       }
       break;
     }
@@ -462,7 +477,8 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 #pragma unroll
       for (u32 i = 0; i < kReducingExtCoeffs; ++i) {
         acc = de_add(de_mul(acc, alpha), coeff[i]);
-        PE(i == kReducingExtCoeffs - 1 ? 0 : 6 + 2 * kReducingExtCoeffs + 2 * i, acc);
+        if (i == kReducingExtCoeffs - 1) PE(0, acc, 0);
+        else PE(6 + 2 * kReducingExtCoeffs + 2 * i, acc, 2 + 2 * i);
       }
       break;
     }
@@ -470,7 +486,7 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       const u32* A = args + op.a;
       u64 v = gl::canon(m.get(A[0]));
       for (u32 k = 1; k < op.b; ++k) {
-        put_out<FRESH>(m, A[k], v & ((1ull << kBaseSumLimbs) - 1), err, o);
+        put_out(m, A[k], v & ((1ull << kBaseSumLimbs) - 1), fr.at(k - 1), err, o);
         v >>= kBaseSumLimbs;
       }
       if (v) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in the BaseSumGates"
@@ -480,7 +496,7 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       const u64 v = gl::canon(G(0));
       if (v >> kBaseSumLimbs) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in given number of limbs"
 #pragma unroll 9
-      for (u32 j = 0; j < kBaseSumLimbs; ++j) put_out<FRESH>(m, S[1 + j], (v >> j) & 1, err, o);
+      for (u32 j = 0; j < kBaseSumLimbs; ++j) put_out(m, S[1 + j], (v >> j) & 1, fr.at(j), err, o);
       break;
     }
     case GEN_RANDOM_ACCESS: {
@@ -490,8 +506,8 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
         atomicCAS(err, 0, (int)o + 1);  // "Access index is larger than the vector size"
         break;
       }
-      put_out<FRESH>(m, S[at + 1], G(at + 2 + (u32)idx), err, o);
-      for (u32 j = 0; j < kRaBits; ++j) put_out<FRESH>(m, S[74 + kRaBits * op.b + j], (idx >> j) & 1, err, o);
+      put_out(m, S[at + 1], G(at + 2 + (u32)idx), fr.at(0), err, o);
+      for (u32 j = 0; j < kRaBits; ++j) put_out(m, S[74 + kRaBits * op.b + j], (idx >> j) & 1, fr.at(1 + j), err, o);
       break;
     }
     case GEN_INTERPOLATION: {
@@ -500,7 +516,7 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       for (int i = 0; i < 16; ++i) vals[i] = GE(1 + 2 * i);
       const DE point = GE(33);
       const DE x = de_scale(point, gl_inv(gl::canon(G(0))));  // shifted_evaluation_point = evaluation_point / shift
-      PE(45, x);
+      PE(45, x, 10);
       DE ev{0, 0}, pr{1, 0};
       auto step = [&](int i) {
         const DE term{gl::sub_c(x.a, gates_rec::kCosetDomainDev[i]), x.b};
@@ -510,15 +526,15 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       };
 #pragma unroll
       for (int i = 0; i < 6; ++i) step(i);
-      PE(37, ev);
-      PE(41, pr);
+      PE(37, ev, 2);
+      PE(41, pr, 6);
 #pragma unroll
       for (int i = 6; i < 11; ++i) step(i);
-      PE(39, ev);
-      PE(43, pr);
+      PE(39, ev, 4);
+      PE(43, pr, 8);
 #pragma unroll
       for (int i = 11; i < 16; ++i) step(i);
-      PE(35, ev);
+      PE(35, ev, 0);
       break;
     }
     case GEN_POSEIDON_MDS: {
@@ -530,7 +546,7 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
         DE acc = r == 0 ? de_scale(st[0], 8) : DE{0, 0};
 #pragma unroll
         for (u32 i = 0; i < 12; ++i) acc = de_add(acc, de_scale(st[(i + r) % 12], gates_rec::mds_circ((int)i)));
-        PE(24 + 2 * r, acc);
+        PE(24 + 2 * r, acc, 2 * r);
       }
       break;
     }
@@ -539,31 +555,25 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 }
 
 // ArithmeticBaseGenerator / EqualityGenerator (slots in the record itself) or one of the generators above
-template <bool FRESH, typename Mem>
-GL_DEV void run_lane_generator_f(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
-                                 int* err) {
+template <typename Mem>
+GL_DEV void run_lane_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args, int* err) {
   const u32 kind = op.kind & 0xFF;
   if (kind == GEN_ARITH) {
     const u64 m0 = m.get(op.a), m1 = m.get(op.b), ad = m.get(op.c);
-    put_out<FRESH>(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), err, o);
+    put_out(m, op.out, gl::mul_add(gl::mul(m0, m1), op.c0, gl::mul(ad, op.c1)), (op.kind & (kFreshOutputs | kFreshBit0)) != 0, err, o);
   } else if (kind == GEN_EQUALITY) {
     const u64 x = m.get(op.a), y = m.get(op.b);
-    put_out<FRESH>(m, op.out, x == y ? 1 : 0, err, o);
-    put_out<FRESH>(m, op.out2, gl_inv(gl::canon(fsub(x, y))), err, o);
+    put_out(m, op.out, x == y ? 1 : 0, (op.kind & (kFreshOutputs | kFreshBit0)) != 0, err, o);
+    put_out(m, op.out2, gl_inv(gl::canon(fsub(x, y))), (op.kind & (kFreshOutputs | kFreshBit1)) != 0, err, o);
   } else {
-    run_recursion_generator<FRESH>(m, op, o, tab, args, err);
+    run_recursion_generator(m, op, o, tab, args, err);
   }
-}
-template <typename Mem>
-GL_DEV void run_lane_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args, int* err) {
-  if (op.kind & kFreshOutputs) run_lane_generator_f<true>(m, op, o, tab, args, err);
-  else run_lane_generator_f<false>(m, op, o, tab, args, err);
 }
 
 // PoseidonGenerator on one wavefront (lane w < 12 owns state word w): reads the 12 inputs and the swap bit, writes the 12 outputs.
-// ps: this lane's slot among the row's wires 0..24 (lane < 25).
+// ps: this lane's slot among the row's wires 0..24 (lane < 25).  fresh_mask: bit w = output word w is a first write.
 template <typename Mem>
-GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, bool fresh, int* err, const PermCtx& ctx) {
+GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, u32 fresh_mask, int* err, const PermCtx& ctx) {
   const u32 swap_slot = __shfl(ps, 24), out_slot = __shfl(ps, (lane + 12) & 31);
   u64 x = lane < 12 ? m.get(ps) : 0;
   const u64 swap = m.get(swap_slot);
@@ -571,11 +581,9 @@ GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, bool f
   if (lane < 4) x = gl::add(x, gl::mul(swap, fsub(partner, x)));       // the permutation runs on the swapped state
   else if (lane < 8) x = fsub(x, gl::mul(swap, fsub(x, partner)));
   x = permute_wave(x, ctx);  // outputs only: the row's delta / S-box wires are filled afterwards (k_poseidon_rows)
-  if (lane < 12) {
-    if (fresh) m.store(out_slot, gl::canon(x));
-    else put(m, out_slot, x, err, o);
-  }
+  if (lane < 12) put_out(m, out_slot, x, ((fresh_mask >> lane) & 1) != 0, err, o);
 }
+GL_DEV u32 poseidon_fresh_mask(u32 kind, u32 c) { return (kind & kFreshOutputs) ? 0xFFFu : c; }
 
 // One workgroup runs the generators level by level (a level = generators whose inputs are all known; the host orders them
 // and puts the PoseidonGate rows first).  PoseidonGenerator: one wavefront per row, lane w < 12 owns state word w.
@@ -635,7 +643,7 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
       u32 ps = cur_ps;
       const WOp po = OP(o);
       if (o != s + wave) ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;  // more PoseidonGate rows in this level than wavefronts
-      run_poseidon_generator(m, ps, lane, o, (po.kind & kFreshOutputs) != 0, err, ctx);
+      run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(po.kind, po.c), err, ctx);
     }
     for (u32 o = s + np + tid; o < e; o += kBlock) run_lane_generator(m, OP(o), o, tab, args, err);
     m.sync();
@@ -683,9 +691,9 @@ __global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
     for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
-      const u32 pb = ops[o].b, pk = ops[o].kind;
+      const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
       const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
-      run_poseidon_generator(m, ps, lane, o, (pk & kFreshOutputs) != 0, err, ctx);
+      run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
     }
     for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
     // grid-wide barrier
@@ -730,9 +738,9 @@ __global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
     for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
-      const u32 pb = ops[o].b, pk = ops[o].kind;
+      const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
       const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
-      run_poseidon_generator(m, ps, lane, o, (pk & kFreshOutputs) != 0, err, ctx);
+      run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
     }
     for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
   }
@@ -1305,11 +1313,16 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
       level = std::max(level, set_level[out[k]]);  // a check waits for the value it checks
     }
     ++level;
-    bool fresh = true;  // first writer of every output slot (duplicates within the list count as already written)
+    // which outputs this generator is the first writer of (a slot listed twice counts once; any other output is a check)
+    u32 fmask[3] = {0, 0, 0};
+    bool fresh = true;
     for (u32 k = 0; k < n_out; ++k) {
-      fresh &= set_level[out[k]] < 0;
-      for (u32 j = 0; j < k; ++j) fresh &= out[j] != out[k];
+      bool f = set_level[out[k]] < 0;
+      for (u32 j = 0; j < k; ++j) f &= out[j] != out[k];
+      if (f && k < 96) fmask[k >> 5] |= 1u << (k & 31);
+      fresh &= f;
     }
+    if (n_out > 96) return p2mt::fail(P2MT_EINVAL, "internal: generator with more than 96 outputs");
     for (u32 k = 0; k < n_out; ++k)
       if (set_level[out[k]] < 0) {
         set_level[out[k]] = level;
@@ -1321,6 +1334,8 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
     op.kind = (u32)g.kind | (fresh ? kFreshOutputs : 0);
     op.c0 = g.c0;
     op.c1 = g.c1;
+    if (g.kind != GEN_ARITH && g.kind != GEN_EQUALITY) op.c = fmask[0], op.out = fmask[1], op.out2 = fmask[2];
+    else op.kind |= (fmask[0] & 3) << 9;
     switch (g.kind) {
       case GEN_ARITH: op.a = in[0], op.b = in[1], op.c = in[2], op.out = out[0]; break;
       case GEN_EQUALITY: op.a = in[0], op.b = in[1], op.out = out[0], op.out2 = out[1]; break;
