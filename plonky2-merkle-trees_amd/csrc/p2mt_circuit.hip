@@ -360,7 +360,10 @@ struct FMem {
         atomicExch(err + 2, 1);
         return 0;
       }
-      __builtin_amdgcn_s_sleep(2);
+      // back off: thousands of lanes poll at once, and their loads share the fabric with the producers' stores
+      if (spins < 4) __builtin_amdgcn_s_sleep(2);
+      else if (spins < 16) __builtin_amdgcn_s_sleep(8);
+      else __builtin_amdgcn_s_sleep(32);
       v = ld64(vals + s);
     }
     return v;
@@ -423,8 +426,10 @@ GL_DEV void put_out(const Mem& m, u32 slot, u64 v, bool fresh, int* err, u32 op_
 // ArithmeticExtensionGenerator, MulExtensionGenerator, QuotientGeneratorExtension, ReducingGenerator (both gates),
 // WireSplitGenerator, BaseSplitGenerator<2>, RandomAccessGenerator, InterpolationGenerator, PoseidonMdsGenerator.
 // Operands are loaded up front (independent loads in flight together), then the dependent arithmetic, then the stores.
+// NOT inlined: its operand arrays (up to 64 words) would otherwise set the register allocation of the whole interpreter and push
+// the wavefront permutation's scalar state into spills -- the PoseidonGate rows are the latency-critical path.
 template <typename Mem>
-GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
+__device__ __attribute__((noinline)) void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
                                     int* err) {
   const Fresh fr = fresh_of(op);
   const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
@@ -734,17 +739,28 @@ __global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__
   const FMem m{vals, set, err};
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = kBlock / 64;
   const u32 gwave = blockIdx.x * waves_per_block + wave, n_gwaves = gridDim.x * waves_per_block;
-  const u32 gtid = blockIdx.x * kBlock + tid, n_gthreads = gridDim.x * kBlock;
-  for (u32 l = 0; l < n_levels; ++l) {
-    const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
-    for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
-      const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
-      const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
-      run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
+  // Roles: three quarters of the wavefronts run PoseidonGate rows only, the rest the lane generators only.  A wavefront that did
+  // both would tie the transcript -- the critical chain, always the first PoseidonGate row of its level -- to the progress of
+  // unrelated arithmetic chains, and the whole schedule would degenerate to level-synchronous (measured: no gain over barriers).
+  const u32 n_pw = n_gwaves - n_gwaves / 4;
+  if (gwave < n_pw) {
+    for (u32 l = 0; l < n_levels; ++l) {
+      const u32 s = lvl[2 * l], np = lvl[2 * l + 1];
+      for (u32 o = s + gwave; o < s + np; o += n_pw) {  // wave-uniform
+        const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
+        const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
+        run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
+      }
     }
-    for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
+  } else {
+    const u32 lt = (gwave - n_pw) * 64 + lane, n_lt = (n_gwaves - n_pw) * 64;
+    for (u32 l = 0; l < n_levels; ++l) {
+      const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
+      for (u32 o = s + np + lt; o < e; o += n_lt) run_lane_generator(m, ops[o], o, tab, args, err);
+    }
   }
 }
+
 
 // The whole witness fill in one launch with the value table in LDS: initial assignments, generator levels, and
 // full_witness (wires[col][row], public inputs) straight from LDS.
