@@ -426,10 +426,10 @@ GL_DEV void put_out(const Mem& m, u32 slot, u64 v, bool fresh, int* err, u32 op_
 // ArithmeticExtensionGenerator, MulExtensionGenerator, QuotientGeneratorExtension, ReducingGenerator (both gates),
 // WireSplitGenerator, BaseSplitGenerator<2>, RandomAccessGenerator, InterpolationGenerator, PoseidonMdsGenerator.
 // Operands are loaded up front (independent loads in flight together), then the dependent arithmetic, then the stores.
-// NOT inlined: its operand arrays (up to 64 words) would otherwise set the register allocation of the whole interpreter and push
-// the wavefront permutation's scalar state into spills -- the PoseidonGate rows are the latency-critical path.
+// (Inlined on purpose: a noinline version -- tried to keep its operand arrays out of the interpreter's register allocation -- was
+// slower in the level-synchronous kernels and faulted in the dataflow one; the role split of k_witness_flow does that job.)
 template <typename Mem>
-__device__ __attribute__((noinline)) void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
+GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u32* __restrict__ tab, const u32* __restrict__ args,
                                     int* err) {
   const Fresh fr = fresh_of(op);
   const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
