@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
       const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
       store_hash(elements + 4 * (pos - 2), la);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
       store_hash(elements + 4 * (pos - 1), lb);
-      two_to_one_r<IMPL_FAST, 0>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+      two_to_one_r<IMPL_FAST, 0, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {  // leaf pair: 10 of the 12 first S-boxes are constants
         ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
         rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
       });

@@ -196,17 +196,32 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
 // OUT_ROWS: number of output words the caller needs (4 for a hash => the last MDS layer computes 4 rows).
 // EXACT: use the exact-form primitives (no flag is ever raised; ~8 % more instructions) -- the redo path of a
 //   flagged wave.
-template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false>
+// LEAF_PAIR (with CAP_ZERO): the caller additionally guarantees s[1..3] == s[5..7] == 0 -- two_to_one of two leaf digests
+//   [leaf, 0, 0, 0] (hash_or_noop's zero padding, quirk Q1), i.e. half of all hashes of a tree build.  Only words 0 and 4 go
+//   through the first S-box layer; the other ten S-box outputs are the constants (rc[i])^7, read from rc[360 + ..].
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
   u64 sticky = 0;
   auto sbox = [&](u64 x) -> u64 {
     if constexpr (EXACT) return exact::pow7(x);
     else return pow7(x, sticky);
   };
+  static_assert(!LEAF_PAIR || CAP_ZERO, "LEAF_PAIR implies zero capacity words");
   constexpr int kVar = CAP_ZERO ? 8 : 12;
+  if constexpr (LEAF_PAIR) {  // round 0: words 0 and 4 only
+    s[0] = sbox(gl::add_c(s[0], rc[0]));
+    s[4] = sbox(gl::add_c(s[4], rc[4]));
 #pragma unroll
-  for (int i = 0; i < kVar; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
-  {  // round 0
+    for (int i = 0; i < 3; ++i) {
+      s[1 + i] = rc[364 + i];
+      s[5 + i] = rc[367 + i];
+    }
+#pragma unroll
+    for (int i = 8; i < 12; ++i) s[i] = rc[360 + (i - 8)];
+    mds_layer<true, 12, EXACT>(s, rc + 12, sticky);
+  } else {  // round 0
+#pragma unroll
+    for (int i = 0; i < kVar; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
 #pragma unroll
     for (int i = 0; i < kVar; ++i) s[i] = sbox(s[i]);
     if constexpr (CAP_ZERO) {

@@ -155,12 +155,14 @@ extern "C" int p2mt_init(int device) {
   P2MT_HIP(hipEventCreate(&rt().ev_start));
   P2MT_HIP(hipEventCreate(&rt().ev_stop));
   if (rt().d_rc) (void)hipFree(rt().d_rc);
-  {  // 360 round constants + (rc[8..11])^7: the first-round S-box outputs of two_to_one's zero capacity words
-    uint64_t table[364];
+  {  // 360 round constants + first-round S-box outputs of words that are zero on entry, (rc[i])^7: [360..364) words 8..11 (the
+     // capacity of two_to_one), [364..367) words 1..3 and [367..370) words 5..7 (two_to_one of two leaf digests [leaf, 0, 0, 0])
+    uint64_t table[370];
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
-    for (int i = 0; i < 4; ++i) {
+    const int word_of[10] = {8, 9, 10, 11, 1, 2, 3, 5, 6, 7};
+    for (int i = 0; i < 10; ++i) {
       const unsigned __int128 p = 0xFFFFFFFF00000001ULL;
-      unsigned __int128 x = POSEIDON_RC[8 + i], x2 = x * x % p, x4 = x2 * x2 % p, x3 = x2 * x % p;
+      unsigned __int128 x = POSEIDON_RC[word_of[i]], x2 = x * x % p, x4 = x2 * x2 % p, x3 = x2 * x % p;
       table[360 + i] = (uint64_t)(x4 * x3 % p);
     }
     P2MT_HIP(hipMalloc((void**)&rt().d_rc, sizeof(table)));
