@@ -570,7 +570,9 @@ def test_device_resident_proof_service(pkg, oracle):
     {"P2MT_SUBTREE_BLOCK": "128"},
     {"P2MT_QUAD": "0", "P2MT_LDE12": "0"},              # no four-lane kernels, radix-2 LDE at 2^12
     {"P2MT_THROUGHPUT": "1"},                           # lane-efficient layouts instead of the latency-optimised ones
-    {"P2MT_WITNESS_LDS": "0"},                          # witness value table in global memory
+    {"P2MT_WITNESS_LDS": "0"},                          # witness value table in global memory (dataflow interpreter)
+    {"P2MT_WITNESS_LDS": "0", "P2MT_WITNESS_GRID": "1"},  # ... level-synchronous over the grid
+    {"P2MT_WITNESS_LDS": "0", "P2MT_WITNESS_GRID": "0"},  # ... one workgroup
 ])
 def test_env_knobs(env):
     """Every P2MT_* runtime knob selects kernels that stay bit-exact (each in a fresh process: read once at init)."""

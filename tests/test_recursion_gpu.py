@@ -136,3 +136,33 @@ def test_outer_witness_rejects_a_tampered_inner_proof(pkg, oracle):
     go, pwo, oo, opwo = outer_both(pkg, oracle, case, gi, oi, bad)
     with pytest.raises(pkg.P2mtPanic):
         go.prove(pwo)
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_outer_witness_interpreters_agree(mode):
+    """The three interpreters of the generator schedule (dataflow = default, level-synchronous over the grid, one workgroup)
+    produce the same outer proof (fresh process: the knob is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, hashlib, __graft_entry__ as ge\n"
+        "from oracle_lib import Oracle\n"
+        "from circuit_cases import mmr_case\n"
+        "import test_recursion_gpu as T\n"
+        "pkg = ge.load_package(); pkg.init(0); o = Oracle()\n"
+        "case = mmr_case(o, 8, 3)\n"
+        "gi, pwi, oi, opwi = T.inner_both(pkg, o, case)\n"
+        "ip = gi.prove(pwi)\n"
+        "go, pwo, oo, opwo = T.outer_both(pkg, o, case, gi, oi, ip)\n"
+        "print('SHA', hashlib.sha256(go.prove(pwo).tobytes()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for env in ({}, {"P2MT_WITNESS_GRID": mode}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
+    assert shas[0] == shas[1]

@@ -13,7 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace/runc" -- pyt
 echo "trace done" >> "$OUT/progress.log"
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d "$OUT/pmc_sq/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_sq.log" 2>&1
 echo "sq done" >> "$OUT/progress.log"
-rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_grbm.log" 2>&1
+# VALU-busy: numerator (SQ_ACTIVE_INST_VALU, quad-cycles summed over the SIMDs) and denominator (GRBM_GUI_ACTIVE, cycles summed over the
+# 8 XCDs) from the SAME dispatches (GRBM slots are independent of the SQ ones)
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_grbm.log" 2>&1
 echo "grbm done" >> "$OUT/progress.log"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_fetch.log" 2>&1
 echo "fetch done" >> "$OUT/progress.log"
