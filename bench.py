@@ -205,8 +205,11 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                              "bytes, so the HBM fraction is ~2 % by construction (SURVEY.md 8d)"},
         # counter evidence for "compute-bound, the right way": share of SIMD issue cycles spent on VALU instructions and VALU
         # instructions per hash, from the committed PMC passes (null when this configuration was not profiled)
-        "valu": {"valu_busy": pmc.get("valu_busy"), "valu_instr_per_hash": pmc.get("valu_instr_per_hash"),
-                 "source": pmc.get("source"), "in_kernel_hashes_per_s": in_kernel_rate},
+        "valu": {"valu_busy": pmc.get("valu_busy"), "valu_busy_raw_ratio": pmc.get("valu_busy_raw_ratio"),
+                 "valu_instr_per_hash": pmc.get("valu_instr_per_hash"), "effective_clock_ghz": pmc.get("effective_clock_ghz"),
+                 "source": pmc.get("source"), "in_kernel_hashes_per_s": in_kernel_rate,
+                 "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), both counters from the same "
+                         "dispatches; the raw ratio of the two counters (1.00 +- 0.7 %) is clamped to 1"},
         "device_ms_per_step": region_ms.value / args.steps,
         "root": [int(x) for x in root],
     }

@@ -55,6 +55,7 @@ struct p2mt_circuit_data {
   u32 degree_bits = 0, n = 0, num_selectors = 0, n_kinds = 0, n_cs = 0, n_slots = 0, n_pi = 0, n_act = 0;
   u32 kind[kMaxGateTypes] = {}, sel[kMaxGateTypes] = {}, gs[kMaxGateTypes] = {}, ge[kMaxGateTypes] = {}, counts[kMaxGateTypes] = {};
   bool has_recursion_gates = false;  // any gate type beyond Noop / Constant / PublicInput / Arithmetic / Poseidon
+  bool force_single_workgroup = false;  // set for the one retry after the grid-wide interpreter gave up waiting (see p2mt_circuit_prove)
   u64 n_virtual = 0;
   std::vector<Gen> gens;
   std::vector<u64> public_inputs;
@@ -1467,10 +1468,11 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
   P2MT_LAUNCH_CHECK();
   // Interpreter for tables in global memory: 2 (default) = dataflow over the whole grid (k_witness_flow), 1 = level-synchronous
   // over the whole grid (k_witness_grid), 0 = one workgroup (k_witness_run); env P2MT_WITNESS_GRID selects (A/B and fallback).
-  static const int mode = [] {
+  static const int env_mode = [] {
     const char* e = getenv("P2MT_WITNESS_GRID");
     return e ? atoi(e) : 2;
   }();
+  const int mode = c->force_single_workgroup ? 0 : env_mode;
   if (mode == 2) {
     hipLaunchKernelGGL(k_witness_flow, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
                        c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
@@ -1494,10 +1496,10 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
 
 int witness_status(p2mt_circuit_data* c, const int* err) {
   (void)c;
+  if (err[2] != 0) return p2mt::fail(P2MT_EHIP, "prove: the grid-wide witness interpreter gave up waiting (level barrier / operand never written)");
   if (err[0] == -1) return p2mt::fail(P2MT_EINVAL, "prove: a public input target was never set");
   if (err[0] != 0) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
   if (err[1] != 0) return p2mt::fail(P2MT_EINVAL, "prove: zero denominator in the permutation argument (plonky2 panics on this division)");
-  if (err[2] != 0) return p2mt::fail(P2MT_EHIP, "prove: the grid-wide witness interpreter gave up waiting (level barrier / operand never written)");
   return P2MT_OK;
 }
 
@@ -1985,10 +1987,27 @@ extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_pa
   return witness_status(c, err);
 }
 
+static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, int* gave_up);
+
+// circuit_data.prove(pw).  The grid-wide witness interpreters assume that all of their (few) workgroups are resident; if the device
+// is so oversubscribed by other work that a wait runs out of its budget, the launch drains with an error flag instead of hanging,
+// and the proof is redone ONCE with the single-workgroup interpreter, which has no such assumption.
 extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, size_t proof_cap) {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !pw || !proof_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_cap < c->proof_len) return p2mt::fail(P2MT_EINVAL, "prove: proof buffer too small (p2mt_circuit_get_info)");
+  int gave_up = 0;
+  int rc = prove_once(c, pw, proof_out, &gave_up);
+  if (gave_up && !c->force_single_workgroup) {
+    c->force_single_workgroup = true;
+    rc = prove_once(c, pw, proof_out, &gave_up);
+    c->force_single_workgroup = false;
+  }
+  return rc;
+}
+
+static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, int* gave_up) {
+  *gave_up = 0;
   hipStream_t st = rt().stream;
   const u32 n = c->n, log_n = c->degree_bits, log_big = log_n + kRateBits, big = n << kRateBits, n_cs = c->n_cs;
   u64 *d_digest = c->d_head, *d_pi_hash = c->d_head + 4, *d_proof = c->d_head + 8;
@@ -2082,6 +2101,7 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   std::copy(c->h_pin + 8, c->h_pin + 8 + c->proof_len, proof_out);
   int err[4];
   memcpy(err, c->h_pin + 8 + c->proof_len, sizeof err);
+  *gave_up = err[2] != 0;
   return witness_status(c, err);
 }
 
