@@ -125,7 +125,7 @@ class CircuitBuilder:
 
     def verify_proof(self, proof_with_pis, inner_verifier_data, inner_circuit_data):
         """builder.verify_proof::<PoseidonGoldilocksConfig>(&proof_with_pis, &inner_verifier_data, &inner.common)"""
-        pt, vd = _targets(proof_with_pis.targets), _targets(inner_verifier_data.targets)
+        pt, vd = proof_with_pis._array, inner_verifier_data._array
         N.check(N.lib().p2mt_cb_verify_proof(self._h, N.ptr(pt), pt.size, N.ptr(vd), inner_circuit_data._h))
 
     def build(self):
@@ -141,6 +141,7 @@ class ProofWithPublicInputsTarget:
     def __init__(self, targets, num_public_inputs):
         self.targets = targets
         self.public_inputs = targets[len(targets) - num_public_inputs:]
+        self._array = _targets(targets)   # the same handles as one contiguous u64 array (what the C ABI takes)
 
 
 class VerifierCircuitTarget:
@@ -150,6 +151,7 @@ class VerifierCircuitTarget:
         self.targets = targets
         self.constants_sigmas_cap = [targets[4 * i:4 * i + 4] for i in range(16)]
         self.circuit_digest = targets[64:68]
+        self._array = _targets(targets)
 
 
 class PartialWitness:
@@ -174,13 +176,13 @@ class PartialWitness:
 
     def set_proof_with_pis_target(self, proof_target, proof):
         """pw.set_proof_with_pis_target(&target, &proof) (mmr_plonky2_verifier_1_recursion.rs:201)"""
-        pt, words = _targets(proof_target.targets), N.as_u64(proof).reshape(-1)
+        pt, words = proof_target._array, N.as_u64(proof).reshape(-1)
         assert pt.size == words.size, "proof does not match its target"
         N.check(N.lib().p2mt_pw_set_proof_with_pis_target(self._h, N.ptr(pt), N.ptr(words), words.size))
 
     def set_verifier_data_target(self, verifier_data_target, inner_circuit_data):
         """pw.set_verifier_data_target(&target, &inner.verifier_only) (:202)"""
-        vd = _targets(verifier_data_target.targets)
+        vd = verifier_data_target._array
         N.check(N.lib().p2mt_pw_set_verifier_data_target(self._h, N.ptr(vd), inner_circuit_data._h))
 
 

@@ -584,16 +584,38 @@ GL_DEV void run_lane_generator(const Mem& m, const WOp& op, u32 o, const u32* __
 
 // PoseidonGenerator on one wavefront (lane w < 12 owns state word w): reads the 12 inputs and the swap bit, writes the 12 outputs.
 // ps: this lane's slot among the row's wires 0..24 (lane < 25).  fresh_mask: bit w = output word w is a first write.
-template <typename Mem>
-GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, u32 fresh_mask, int* err, const PermCtx& ctx) {
+// CHAIN (dataflow interpreter): the wavefront remembers the outputs of the row it ran last (slot and value per lane); an input of
+// this row that IS one of those slots is taken from the register instead of waiting for the store -> load hand-off -- the
+// transcript is a chain of ~110 such rows on one wavefront, each feeding its whole state (or its capacity words) to the next.
+template <bool CHAIN, typename Mem>
+GL_DEV void run_poseidon_generator(const Mem& m, u32 ps, u32 lane, u32 o, u32 fresh_mask, int* err, const PermCtx& ctx,
+                                   u32* prev_slot = nullptr, u64* prev_val = nullptr) {
   const u32 swap_slot = __shfl(ps, 24), out_slot = __shfl(ps, (lane + 12) & 31);
-  u64 x = lane < 12 ? m.get(ps) : 0;
+  u64 x = 0;
+  bool have = lane >= 12;
+  if constexpr (CHAIN) {
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+      const u32 sj = __shfl(*prev_slot, j);
+      const u64 vj = __shfl((unsigned long long)*prev_val, j);
+      if (!have && sj == ps) {
+        x = vj;
+        have = true;
+      }
+    }
+  }
+  if (!have) x = m.get(ps);
   const u64 swap = m.get(swap_slot);
   const u64 partner = __shfl_xor((unsigned long long)x, 4);
   if (lane < 4) x = gl::add(x, gl::mul(swap, fsub(partner, x)));       // the permutation runs on the swapped state
   else if (lane < 8) x = fsub(x, gl::mul(swap, fsub(x, partner)));
   x = permute_wave(x, ctx);  // outputs only: the row's delta / S-box wires are filled afterwards (k_poseidon_rows)
+  x = gl::canon(x);
   if (lane < 12) put_out(m, out_slot, x, ((fresh_mask >> lane) & 1) != 0, err, o);
+  if constexpr (CHAIN) {
+    *prev_slot = lane < 12 ? out_slot : kNoSlot;
+    *prev_val = x;
+  }
 }
 GL_DEV u32 poseidon_fresh_mask(u32 kind, u32 c) { return (kind & kFreshOutputs) ? 0xFFFu : c; }
 
@@ -655,7 +677,7 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
       u32 ps = cur_ps;
       const WOp po = OP(o);
       if (o != s + wave) ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;  // more PoseidonGate rows in this level than wavefronts
-      run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(po.kind, po.c), err, ctx);
+      run_poseidon_generator<false>(m, ps, lane, o, poseidon_fresh_mask(po.kind, po.c), err, ctx);
     }
     for (u32 o = s + np + tid; o < e; o += kBlock) run_lane_generator(m, OP(o), o, tab, args, err);
     m.sync();
@@ -705,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__
     for (u32 o = s + gwave; o < s + np; o += n_gwaves) {  // wave-uniform
       const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
       const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
-      run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
+      run_poseidon_generator<false>(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
     }
     for (u32 o = s + np + gtid; o < e; o += n_gthreads) run_lane_generator(m, ops[o], o, tab, args, err);
     // grid-wide barrier
@@ -751,12 +773,14 @@ __global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__
   // unrelated arithmetic chains, and the whole schedule would degenerate to level-synchronous (measured: no gain over barriers).
   const u32 n_pw = n_gwaves - n_gwaves / 4;
   if (gwave < n_pw) {
+    u32 prev_slot = kNoSlot;
+    u64 prev_val = 0;
     for (u32 l = 0; l < n_levels; ++l) {
       const u32 s = lvl[2 * l], np = lvl[2 * l + 1];
       for (u32 o = s + gwave; o < s + np; o += n_pw) {  // wave-uniform
         const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
         const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
-        run_poseidon_generator(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx);
+        run_poseidon_generator<true>(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx, &prev_slot, &prev_val);
       }
     }
   } else {
