@@ -82,7 +82,7 @@ struct p2mt_circuit_data {
   u64 *d_z_vals = nullptr, *d_z_coeffs = nullptr, *d_z_lde = nullptr, *d_z_leaves = nullptr, *d_z_dig = nullptr, *d_pp_q = nullptr;
   u64 *d_q_vals = nullptr, *d_q_coeffs = nullptr, *d_q_lde = nullptr, *d_q_leaves = nullptr, *d_q_dig = nullptr;
   u64 *d_head = nullptr, *d_open = nullptr, *d_chal = nullptr, *d_kis = nullptr, *d_vals = nullptr, *d_init = nullptr;
-  u64* d_q_extra = nullptr;  // [kNumCh][8n]: the recursion gates' share of the vanishing polynomial (k_quotient_extra)
+  u64* d_q_extra = nullptr;  // [gate type][kNumCh][8n]: the recursion gates' shares of the vanishing polynomial (k_quotient_extra)
   u32 *d_set = nullptr, *d_wire_slot = nullptr, *d_pi_slot = nullptr, *d_lvl = nullptr, *d_pslots = nullptr, *d_prows = nullptr;
   u32 *d_slot_tab = nullptr, *d_args = nullptr, *d_sync = nullptr;  // dense wire -> slot table; slot lists of free-standing generators; grid barrier
   WOp* d_ops = nullptr;
@@ -896,7 +896,7 @@ constexpr u32 kNumTerms = kNumCh + kNumCh * kNumChunks + kNumGateConstraints;
 __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
                                                   const u64* __restrict__ zl, const u64* __restrict__ pi_hash,
                                                   const u64* __restrict__ chal, const u64* __restrict__ k_is,
-                                                  const u64* __restrict__ rc, const u64* __restrict__ extra,
+                                                  const u64* __restrict__ rc, const u64* __restrict__ extra, u32 n_extra,
                                                   u64* __restrict__ qvals) {
   __shared__ u64 apow[kNumCh][kNumTerms];
   __shared__ u64 part[4][64][kNumCh];
@@ -1079,7 +1079,8 @@ __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __re
 #pragma unroll
     for (u32 c = 0; c < kNumCh; ++c) {
       u64 sum = gl::add(gl::add(part[0][lane][c], part[1][lane][c]), gl::add(part[2][lane][c], part[3][lane][c]));
-      if (extra) sum = gl::add(sum, extra[(size_t)c * big + i]);  // the recursion gates' filtered constraints (k_quotient_extra)
+      for (u32 e = 0; e < n_extra; ++e)  // the recursion gates' filtered constraints, one plane per gate type (k_quotient_extra)
+        sum = gl::add(sum, extra[((size_t)e * kNumCh + c) * big + i]);
       qvals[(size_t)c * big + i] = gl::canon(gl::mul(sum, zh_inv));
     }
   }
@@ -1111,42 +1112,39 @@ __global__ __launch_bounds__(kBlock) void k_quotient_extra(const QDesc d, const 
   const u32 r = blockIdx.x * kBlock + threadIdx.x;
   if (r >= big) return;
   const u32 i = __brev(r) >> (32 - log_big);
+  // blockIdx.y = which of the circuit's recursion gate types this workgroup evaluates (a lane per point evaluating all eight in
+  // sequence was a 220 us latency chain on half a wavefront per SIMD; one type per workgroup row runs them side by side)
+  u32 g = 0, seen = 0;
+  for (; g < d.n_kinds; ++g)
+    if (d.kind[g] > G_POSEIDON && seen++ == blockIdx.y) break;
   auto CS = [&](u32 j) { return cs[(size_t)j * big + r]; };
   auto W = [&](int j) { return wl[(size_t)j * big + r]; };
-  u64 acc[kNumCh], gacc[kNumCh];
+  u64 gacc[kNumCh];
 #pragma unroll
-  for (u32 c = 0; c < kNumCh; ++c) acc[c] = gacc[c] = 0;
+  for (u32 c = 0; c < kNumCh; ++c) gacc[c] = 0;
   auto G = [&](int j, u64 t) {
 #pragma unroll
     for (u32 c = 0; c < kNumCh; ++c) gacc[c] = gl::mul_add(apow[c][j], t, gacc[c]);
   };
   const u64 c0 = CS(d.num_selectors), c1 = CS(d.num_selectors + 1);
-#pragma unroll 1
-  for (u32 g = 0; g < d.n_kinds; ++g) {
-    switch (d.kind[g]) {
-      case G_BASE_SUM: gates_rec::base_sum_gate<FBaseDev>(W, G); break;
-      case G_ARITHMETIC_EXT: gates_rec::arithmetic_ext_gate<FBaseDev>(W, c0, c1, G); break;
-      case G_MUL_EXT: gates_rec::mul_ext_gate<FBaseDev>(W, c0, G); break;
-      case G_REDUCING: gates_rec::reducing_gate<FBaseDev>(W, G); break;
-      case G_REDUCING_EXT: gates_rec::reducing_ext_gate<FBaseDev>(W, G); break;
-      case G_RANDOM_ACCESS: gates_rec::random_access_gate<FBaseDev>(W, c0, c1, G); break;
-      case G_COSET_INTERPOLATION: gates_rec::coset_interpolation_gate<FBaseDev>(W, G); break;
-      case G_POSEIDON_MDS: gates_rec::poseidon_mds_gate<FBaseDev>(W, G); break;
-      default: continue;  // the five gate types k_quotient evaluates itself
-    }
-    const u64 sv = CS(d.sel[g]);  // compute_filter
-    u64 f = 1;
-    for (u32 k = d.gs[g]; k < d.ge[g]; ++k)
-      if (k != g) f = gl::mul(f, fsub((u64)k, sv));
-    if (d.num_selectors > 1) f = gl::mul(f, fsub(kUnusedSelector, sv));
-#pragma unroll
-    for (u32 c = 0; c < kNumCh; ++c) {
-      acc[c] = gl::mul_add(f, gacc[c], acc[c]);
-      gacc[c] = 0;
-    }
+  switch (d.kind[g]) {  // block-uniform
+    case G_BASE_SUM: gates_rec::base_sum_gate<FBaseDev>(W, G); break;
+    case G_ARITHMETIC_EXT: gates_rec::arithmetic_ext_gate<FBaseDev>(W, c0, c1, G); break;
+    case G_MUL_EXT: gates_rec::mul_ext_gate<FBaseDev>(W, c0, G); break;
+    case G_REDUCING: gates_rec::reducing_gate<FBaseDev>(W, G); break;
+    case G_REDUCING_EXT: gates_rec::reducing_ext_gate<FBaseDev>(W, G); break;
+    case G_RANDOM_ACCESS: gates_rec::random_access_gate<FBaseDev>(W, c0, c1, G); break;
+    case G_COSET_INTERPOLATION: gates_rec::coset_interpolation_gate<FBaseDev>(W, G); break;
+    case G_POSEIDON_MDS: gates_rec::poseidon_mds_gate<FBaseDev>(W, G); break;
+    default: break;
   }
+  const u64 sv = CS(d.sel[g]);  // compute_filter
+  u64 f = 1;
+  for (u32 k = d.gs[g]; k < d.ge[g]; ++k)
+    if (k != g) f = gl::mul(f, fsub((u64)k, sv));
+  if (d.num_selectors > 1) f = gl::mul(f, fsub(kUnusedSelector, sv));
 #pragma unroll
-  for (u32 c = 0; c < kNumCh; ++c) extra[(size_t)c * big + i] = gl::canon(acc[c]);
+  for (u32 c = 0; c < kNumCh; ++c) extra[((size_t)blockIdx.y * kNumCh + c) * big + i] = gl::canon(gl::mul(f, gacc[c]));
 }
 
 // OpeningSet order (constants | sigmas | wires | zs | zs_next | partial products | quotient) from the FriOpenings order the
@@ -1896,7 +1894,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   for (const auto& g : c->gens)
     if (g.kind == GEN_QUOTIENT_EXT || g.kind == GEN_WIRE_SPLIT) c->args_cap += g.t.size();
   const size_t o_slot_tab = carve((n * kNumWires + 1) / 2 + 1), o_args = carve(c->args_cap / 2 + 1), o_sync = carve(4);
-  const size_t o_q_extra = c->has_recursion_gates ? carve(kNumCh * big) : 0;
+  const size_t o_q_extra = c->has_recursion_gates ? carve((size_t)(G_KINDS - G_POSEIDON - 1) * kNumCh * big) : 0;
   if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");
   c->pin_pairs_off = 8 + c->proof_len + 2;
   if (hipHostMalloc((void**)&c->h_pin, (c->pin_pairs_off + 2 * c->init_cap) * 8, hipHostMallocDefault) != hipSuccess)
@@ -2104,14 +2102,16 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint
     qd.n_inv = h_pow(n, gl::P - 2);
     qd.w_big = h_root_of_unity(log_big);
   }
-  if (c->has_recursion_gates) {
-    hipLaunchKernelGGL(k_quotient_extra, dim3(grid_for(big)), dim3(kBlock), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
-                       (const u64*)c->d_chal, c->d_q_extra);
+  u32 n_extra = 0;
+  for (u32 g = 0; g < c->n_kinds; ++g) n_extra += c->kind[g] > G_POSEIDON;
+  if (n_extra) {
+    hipLaunchKernelGGL(k_quotient_extra, dim3(grid_for(big), n_extra), dim3(kBlock), 0, st, qd, (const u64*)c->d_cs_lde,
+                       (const u64*)c->d_w_lde, (const u64*)c->d_chal, c->d_q_extra);
     P2MT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_quotient, dim3((big + 63) / 64), dim3(256), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
                      (const u64*)c->d_z_lde, (const u64*)d_pi_hash, (const u64*)c->d_chal, (const u64*)c->d_kis,
-                     (const u64*)rt().d_rc, (const u64*)c->d_q_extra, c->d_q_vals);
+                     (const u64*)rt().d_rc, (const u64*)c->d_q_extra, n_extra, c->d_q_vals);
   P2MT_LAUNCH_CHECK();
   P2MT_TRY(p2mt::coset_ifft_dev(c->d_q_vals, log_big, kNumCh, 7, c->d_q_coeffs));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_q_coeffs, 0, kNumQuot, log_n, kRateBits, kCapHeight, nullptr, c->d_q_lde, c->d_q_leaves,
