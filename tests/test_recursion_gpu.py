@@ -166,3 +166,31 @@ def test_outer_witness_interpreters_agree(mode):
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         shas.append([l for l in r.stdout.splitlines() if l.startswith("SHA")][-1])
     assert shas[0] == shas[1]
+
+
+@pytest.fixture(scope="module")
+def outer_case(pkg, oracle):
+    case = mmr_case(oracle, 1031, 100)          # inner circuit with a FRI reduction layer: every recursion gate type occurs
+    gi, pwi, oi, opwi = inner_both(pkg, oracle, case)
+    inner_proof = gi.prove(pwi)
+    go, pwo, oo, opwo = outer_both(pkg, oracle, case, gi, oi, inner_proof)
+    return go, pwo, oo, opwo
+
+
+# (gate kind, wire column to corrupt): one wire of every gate type the in-circuit verifier adds
+@pytest.mark.parametrize("kind,col", [(OC.BASE_SUM, 5), (OC.ARITHMETIC_EXT, 6), (OC.MUL_EXT, 4), (OC.REDUCING, 60), (OC.REDUCING_EXT, 80),
+                                      (OC.RANDOM_ACCESS, 75), (OC.COSET_INTERPOLATION, 38), (OC.POSEIDON_MDS, 30)])
+def test_recursion_gate_constraints_are_enforced(pkg, oracle, outer_case, kind, col):
+    """A witness with one wire of a recursion gate changed after generation (so that exactly that gate's constraints break) must
+    not yield a proof either verifier accepts: the constraints of all eight new gate types are live in the quotient and in the
+    verifiers (the proof is made by the oracle's prover, which -- like plonky2's -- does not check the witness)."""
+    go, pwo, oo, opwo = outer_case
+    row = next(i for i, g in enumerate(oo.gate_instances) if g[0] == kind)
+
+    def hook(wires):
+        wires[col, row] = (int(wires[col, row]) + 1) % P
+
+    bad = oo.prove(opwo, wires_hook=hook)
+    assert oo.verify(bad)[0] is False
+    acc, reason = go.verify(bad, with_reason=True)
+    assert acc is False and reason == 11, (acc, reason)       # vanishing polynomial != Z_H * quotient at zeta
