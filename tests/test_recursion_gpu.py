@@ -194,3 +194,31 @@ def test_recursion_gate_constraints_are_enforced(pkg, oracle, outer_case, kind, 
     assert oo.verify(bad)[0] is False
     acc, reason = go.verify(bad, with_reason=True)
     assert acc is False and reason == 11, (acc, reason)       # vanishing polynomial != Z_H * quotient at zeta
+
+
+def test_concurrent_outer_provers(pkg, oracle):
+    """Four provers of the outer circuit at once (one handle and stream per thread inside the library): the dataflow witness
+    interpreter's wavefronts of different proofs share the device; every proof equals the single-prover one."""
+    case = mmr_case(oracle, 8, 3)
+    gi, pwi, oi, opwi = inner_both(pkg, oracle, case)
+    inner_proof = gi.prove(pwi)
+    handles, witnesses = [], []
+    for _ in range(4):
+        leaf, sib, lefts, peaks, root = case
+        go, gpt, gvd, gpeak_ts = pkg.complete_verification_circuit_with_inner_proof(gi.common, len(peaks))
+        handles.append(go)
+    for k in range(8):
+        go = handles[0]  # targets are the same in every build of the circuit
+        pw = pkg.PartialWitness()
+        pw.set_proof_with_pis_target(gpt, inner_proof)
+        pw.set_verifier_data_target(gvd, gi.verifier_only)
+        for pt, pk in zip(gpeak_ts, peaks):
+            pw.set_hash_target(pt, [int(x) for x in pk])
+        for j, t in enumerate(go.prover_only.public_inputs):
+            pw.set_target(t, int(root[j]))
+        witnesses.append(pw)
+    want = handles[0].prove(witnesses[0])
+    got = pkg.prove_many(handles, witnesses)
+    for k in range(8):
+        assert np.array_equal(got[k], want), k
+    assert handles[1].verify(got[5])
