@@ -30,8 +30,15 @@ def build_fast_port_native():
     import tempfile
     d = tempfile.mkdtemp(prefix="p2mt_fast_port_")
     so = os.path.join(d, "libfastport.so")
-    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", so,
-                           os.path.join(ORACLE_DIR, "poseidon_fast.c"), "-I", ORACLE_DIR])
+    # clang (ROCm's LLVM is in the image) schedules the 128-bit multiply / branch-free reduce chains ~30 % better than gcc 11
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    cc = [clang] if os.path.exists(clang) else ["gcc"]
+    try:
+        subprocess.check_call(cc + ["-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", so,
+                                    os.path.join(ORACLE_DIR, "poseidon_fast.c"), "-I", ORACLE_DIR])
+    except (subprocess.CalledProcessError, OSError):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", so,
+                               os.path.join(ORACLE_DIR, "poseidon_fast.c"), "-I", ORACLE_DIR])
     lib = C.CDLL(so)
     _bind_fast(lib)
     return lib
