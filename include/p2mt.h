@@ -414,6 +414,20 @@ int p2mt_circuit_prove(p2mt_circuit_data *c, const p2mt_partial_witness *pw, uin
  * hipSetDeviceFlags(hipDeviceScheduleBlockingSync) before the first HIP call of the process. */
 int p2mt_circuit_prove_many(p2mt_circuit_data *const *circuits, size_t n_handles, const p2mt_partial_witness *const *witnesses,
                             size_t n, uint64_t *proofs_out, size_t proof_stride, int *status_out);
+/* Batched prover: up to `batch` proofs of ONE circuit per pass of the pipeline, the proof index riding in a grid dimension of
+ * every launch (a pass costs the ~44 dispatch packets of one proof; the per-proof path above is bound by the device's packet
+ * rate when many provers run).  For circuits whose witness table fits LDS -- the reference's MMR-verifier circuits
+ * (mmr_plonky2_verifier.rs:148, and the inner prove of mmr_plonky2_verifier_1_recursion.rs:192); P2MT_EINVAL otherwise.
+ * Proofs are bit-identical to p2mt_circuit_prove's.  The prover borrows the circuit handle: one thread at a time, and the
+ * circuit must outlive it.  Device memory: ~2 MB per proof of the batch for a 64-row circuit, allocated on the first prove.
+ * witnesses[i] -> proofs_out + i * proof_stride for i < n (any n: passes of up to `batch`); every witness must set the same
+ * targets in the same order.  status_out[i] (may be NULL) = status of proof i; returns the first non-zero status. */
+typedef struct p2mt_batch_prover p2mt_batch_prover;
+int p2mt_batch_prover_create(p2mt_circuit_data *c, size_t batch, p2mt_batch_prover **out);
+int p2mt_batch_prover_destroy(p2mt_batch_prover *b);
+int p2mt_batch_prover_prove(p2mt_batch_prover *b, const p2mt_partial_witness *const *witnesses, size_t n, uint64_t *proofs_out,
+                            size_t proof_stride, int *status_out);
+size_t p2mt_batch_prover_batch(const p2mt_batch_prover *b);
 /* circuit_data.verify(proof) (:150).  The transcript (Challenger) and every Merkle path (28 queries x (4 oracle rows + one
  * coset per FRI layer), one wavefront each) run on the device; the field arithmetic (vanishing polynomial at zeta, FRI
  * folding) is a few thousand extension-field multiplications on the host.  Returns 0 with *accepted = 1/0 and *reason (may

@@ -11,7 +11,7 @@ from .hashing import (poseidon_gate_witness_batch, hash_no_pad, hash_no_pad_batc
                       two_to_one, two_to_one_batch)
 from .merkle_tree import MerkleTree, verify_merkle_proof, verify_merkle_proof_batch
 from . import circuit, commit, distributed, fri, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion, plonk, synthetic
-from .circuit import CircuitBuilder, CircuitData, PartialWitness, prove_many
+from .circuit import BatchProver, CircuitBuilder, CircuitData, PartialWitness, prove_many
 from .mmr_plonky2_verifier import verify_mmr_proof_circuit
 from .mmr_plonky2_verifier_1_recursion import complete_verification_circuit_with_inner_proof, verify_inner_merkle_proof_circuit
 from .commit import MerkleCapTree, PolynomialBatch, coset_lde, fft, ifft

@@ -251,6 +251,39 @@ class CircuitData:
         return out
 
 
+class BatchProver:
+    """Up to `batch` proofs of one circuit per pass of the prover pipeline (p2mt_batch_prover): the proof index rides in a
+    grid dimension of every launch.  Borrows `circuit` (keep it alive; one thread at a time).  prove(witnesses) ->
+    (len(witnesses), proof_len) proof words, bit-identical to circuit.prove(w) for each witness."""
+
+    def __init__(self, circuit, batch):
+        self.circuit = circuit
+        h = C.c_void_p()
+        N.check(N.lib().p2mt_batch_prover_create(circuit._h, int(batch), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().p2mt_batch_prover_destroy(h)
+
+    @property
+    def batch(self):
+        return int(N.lib().p2mt_batch_prover_batch(self._h))
+
+    def prove(self, witnesses, status=False):
+        n = len(witnesses)
+        plen = self.circuit.info.proof_len
+        out = np.zeros((n, plen), np.uint64)
+        warr = (C.c_void_p * n)(*[w._h for w in witnesses])
+        st = (C.c_int * n)()
+        rc = N.lib().p2mt_batch_prover_prove(self._h, warr, n, N.ptr(out), plen, st)
+        if status:
+            return out, rc, list(st)
+        N.check(rc)
+        return out
+
+
 def prove_many(circuits, witnesses):
     """Independent proves spread over len(circuits) worker threads inside the library (one per handle, each on its own
     stream).  circuits: distinct builds of the same circuit; witnesses: PartialWitness objects.  -> (len(witnesses), proof_len)."""

@@ -94,6 +94,7 @@ struct p2mt_circuit_data {
   // pinned host staging: [0..2) zeta, [2..4) err flags, [8..8+proof_len) proof, then the witness assignments (H2D)
   u64* h_pin = nullptr;
   size_t pin_pairs_off = 0;
+  size_t pin_pitch = 0;  // words between the staging areas of consecutive proofs (batched prover; one area otherwise)
   p2mt_challenger* vch = nullptr;
   u64 k_is[kNumRouted] = {};
 };
@@ -801,7 +802,11 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
                                                         u32 log_n, u64* __restrict__ wires,
                                                         const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
                                                         const u32* __restrict__ tab, const u32* __restrict__ args,
-                                                        int* err, PermCtx ctx) {
+                                                        int* err, BatchArg ba, PermCtx ctx) {
+  pairs = bp(pairs, ba);
+  wires = bp(wires, ba);
+  pi_out = bp(pi_out, ba);
+  err = bp(err, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   extern __shared__ __attribute__((aligned(16))) u64 sh[];
@@ -846,7 +851,8 @@ __global__ __launch_bounds__(kBlock) void k_witness_scatter(const u64* __restric
 // swap bit from the wire matrix and replays the permutation with a hook that stores delta (wires 25-28) and every S-box
 // input (wires 29-134).
 __global__ __launch_bounds__(kBlock) void k_poseidon_rows(const u32* __restrict__ rows, u32 n_rows, u64* __restrict__ wires,
-                                                          u32 log_n, PermCtx ctx) {
+                                                          u32 log_n, BatchArg ba, PermCtx ctx) {
+  wires = bp(wires, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   const u32 k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -897,7 +903,13 @@ __global__ __launch_bounds__(256) void k_quotient(const QDesc d, const u64* __re
                                                   const u64* __restrict__ zl, const u64* __restrict__ pi_hash,
                                                   const u64* __restrict__ chal, const u64* __restrict__ k_is,
                                                   const u64* __restrict__ rc, const u64* __restrict__ extra, u32 n_extra,
-                                                  u64* __restrict__ qvals) {
+                                                  u64* __restrict__ qvals, BatchArg ba) {
+  wl = bp(wl, ba);
+  zl = bp(zl, ba);
+  pi_hash = bp(pi_hash, ba);
+  chal = bp(chal, ba);
+  extra = bp(extra, ba);
+  qvals = bp(qvals, ba);
   __shared__ u64 apow[kNumCh][kNumTerms];
   __shared__ u64 part[4][64][kNumCh];
   const u32 log_big = d.log_n + 3, big = 1u << log_big;
@@ -1101,7 +1113,10 @@ struct FBaseDev {
   GL_DEV static T fromc(u64 c) { return c; }
 };
 __global__ __launch_bounds__(kBlock) void k_quotient_extra(const QDesc d, const u64* __restrict__ cs, const u64* __restrict__ wl,
-                                                           const u64* __restrict__ chal, u64* __restrict__ extra) {
+                                                           const u64* __restrict__ chal, u64* __restrict__ extra, BatchArg ba) {
+  wl = bp(wl, ba);
+  chal = bp(chal, ba);
+  extra = bp(extra, ba);
   __shared__ u64 apow[kNumCh][kNumGateConstraints];
   const u32 log_big = d.log_n + 3, big = 1u << log_big;
   for (u32 k = threadIdx.x; k < kNumCh * kNumGateConstraints; k += kBlock) {
@@ -1149,8 +1164,23 @@ __global__ __launch_bounds__(kBlock) void k_quotient_extra(const QDesc d, const 
 
 // OpeningSet order (constants | sigmas | wires | zs | zs_next | partial products | quotient) from the FriOpenings order the
 // challenger observed (... | zs | partial products | quotient || zs_next)
-__global__ __launch_bounds__(kBlock) void k_opening_set(const u64* __restrict__ fri_order, u64* __restrict__ out, u32 n_cs) {
+// Also plonky2's `ensure!(zeta^n != 1)`: err[3] is set when the opening point lies in the subgroup.
+__global__ __launch_bounds__(kBlock) void k_opening_set(const u64* __restrict__ fri_order, u64* __restrict__ out, u32 n_cs,
+                                                        const u64* __restrict__ zeta, u32 log_n, int* __restrict__ err, BatchArg ba) {
+  fri_order = bp(fri_order, ba);
+  out = bp(out, ba);
+  zeta = bp(zeta, ba);
+  err = bp(err, ba);
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  if (t == 0) {
+    u64 a = zeta[0], b = zeta[1];
+    for (u32 k = 0; k < log_n; ++k) {
+      const u64 na = gl::mul_add(a, a, gl::mul(7, gl::mul(b, b))), nb = gl::mul(2, gl::mul(a, b));
+      a = na;
+      b = nb;
+    }
+    err[3] = (gl::canon(a) == 1 && gl::canon(b) == 0) ? 1 : 0;
+  }
   const u32 a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot), total = a + 2 * kNumCh + tail;
   if (t >= total) return;
   u32 src;
@@ -1436,18 +1466,20 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
 int fill_poseidon_rows(p2mt_circuit_data* c) {
   const u32 n_rows = c->counts[G_POSEIDON];
   if (!n_rows) return P2MT_OK;
-  hipLaunchKernelGGL(k_poseidon_rows, dim3((n_rows + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, rt().stream,
-                     (const u32*)c->d_prows, n_rows, c->d_w_vals, c->degree_bits, p2mt::perm_ctx());
+  hipLaunchKernelGGL(k_poseidon_rows, bgrid((n_rows + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, rt().stream,
+                     (const u32*)c->d_prows, n_rows, c->d_w_vals, c->degree_bits, barg(), p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
 
 // witness fill for one PartialWitness: enqueue init / run / scatter (no synchronisation); wires -> d_w_vals, public inputs
 // -> the tail of the proof buffer
-int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
+int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, unsigned B) {
   // Provers call this with the same TARGET sequence proof after proof (only the values change): the target -> slot resolution,
   // the duplicate detection and the schedule lookup are memoised on that sequence, so the per-proof host work is one linear pass
   // (the outer recursion circuit sets ~11 300 targets per proof: 1.07 ms with a hash map per proof, ~0.03 ms this way).
+  // The proofs of a batch must all set that one sequence.
+  const p2mt_partial_witness* pw = pws[0];
   const size_t n_sets = pw->sets.size();
   bool same = c->memo_valid && c->memo_targets.size() == n_sets;
   for (size_t k = 0; same && k < n_sets; ++k) same = c->memo_targets[k] == pw->sets[k].first;
@@ -1481,37 +1513,52 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
     c->memo_valid = true;
   }
   // (slot, value) pairs straight into the pinned staging area: constants first, then every first assignment
-  u64* pairs = c->h_pin + c->pin_pairs_off;
   size_t np2 = 0;
-  for (const auto& ci : c->const_inits) {
-    pairs[np2++] = ci.first;
-    pairs[np2++] = ci.second;
-  }
-  for (size_t k = 0; k < n_sets; ++k) {
-    const int first = c->memo_first[k];
-    const u64 v = pw->sets[k].second;
-    if (first == -2) {
-      pairs[np2++] = c->memo_slot[k];
-      pairs[np2++] = v;
-    } else {  // PartitionWitness::set_target on an already set partition: the values must agree
-      const u64 prev = first >= 0 ? pw->sets[(size_t)first].second : c->memo_const_value[c->memo_slot[k]];
-      if (prev != v) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values");
+  for (unsigned bi = 0; bi < B; ++bi) {
+    const p2mt_partial_witness* w = pws[bi];
+    if (bi) {
+      bool seq = w->sets.size() == n_sets;
+      for (size_t k = 0; seq && k < n_sets; ++k) seq = w->sets[k].first == c->memo_targets[k];
+      if (!seq) return p2mt::fail(P2MT_EINVAL, "prove_batch: every witness of a batch must set the same targets in the same order");
+    }
+    u64* pairs = c->h_pin + (size_t)bi * c->pin_pitch + c->pin_pairs_off;
+    np2 = 0;
+    for (const auto& ci : c->const_inits) {
+      pairs[np2++] = ci.first;
+      pairs[np2++] = ci.second;
+    }
+    for (size_t k = 0; k < n_sets; ++k) {
+      const int first = c->memo_first[k];
+      const u64 v = w->sets[k].second;
+      if (first == -2) {
+        pairs[np2++] = c->memo_slot[k];
+        pairs[np2++] = v;
+      } else {  // PartitionWitness::set_target on an already set partition: the values must agree
+        const u64 prev = first >= 0 ? w->sets[(size_t)first].second : c->memo_const_value[c->memo_slot[k]];
+        if (prev != v) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values");
+      }
     }
   }
   const size_t n_pairs = np2 / 2;
   hipStream_t st = rt().stream;  // (pinned source: a DMA copy, no blit kernel on the queue)
-  P2MT_HIP(hipMemcpyAsync(c->d_init, c->h_pin + c->pin_pairs_off, np2 * 8, hipMemcpyHostToDevice, st));
+  if (B > 1) {
+    if (!c->lds_bytes) return p2mt::fail(P2MT_EINVAL, "prove_batch: the circuit's witness table must fit LDS");
+    P2MT_HIP(hipMemcpy2DAsync(c->d_init, p2mt::batch().arg.stride, c->h_pin + c->pin_pairs_off, c->pin_pitch * 8, np2 * 8, B,
+                              hipMemcpyHostToDevice, st));
+  } else {
+    P2MT_HIP(hipMemcpyAsync(c->d_init, c->h_pin + c->pin_pairs_off, np2 * 8, hipMemcpyHostToDevice, st));
+  }
   u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
   if (!c->lds_bytes) {
     P2MT_HIP(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), st));
     P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
   }
   if (c->lds_bytes) {
-    hipLaunchKernelGGL(k_witness_lds, dim3(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
+    hipLaunchKernelGGL(k_witness_lds, bgrid(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
                        (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, (const u32*)c->d_pslots, (const u32*)c->d_wire_slot,
                        c->n_act, c->degree_bits,
                        c->d_w_vals, (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, (const u32*)c->d_slot_tab, (const u32*)c->d_args,
-                       c->d_err, p2mt::perm_ctx());
+                       c->d_err, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return fill_poseidon_rows(c);
   }
@@ -1550,6 +1597,7 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw) {
 
 int witness_status(p2mt_circuit_data* c, const int* err) {
   (void)c;
+  if (err[3] != 0) return p2mt::fail(P2MT_EINVAL, "prove: opening point is in the subgroup");
   if (err[2] != 0) return p2mt::fail(P2MT_EHIP, "prove: the grid-wide witness interpreter gave up waiting (level barrier / operand never written)");
   if (err[0] == -1) return p2mt::fail(P2MT_EINVAL, "prove: a public input target was never set");
   if (err[0] != 0) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
@@ -2032,16 +2080,18 @@ extern "C" int p2mt_pw_clear(p2mt_partial_witness* pw) {
 extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* wires_out) {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !pw || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
-  P2MT_TRY(fill_witness(c, pw));
+  P2MT_TRY(fill_witness(c, &pw, 1));
   hipStream_t st = rt().stream;
   int err[4] = {0, 0, 0, 0};
   P2MT_HIP(hipMemcpyAsync(wires_out, c->d_w_vals, (size_t)kNumWires * c->n * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
+  err[3] = 0;  // (the opening-point flag belongs to prove)
   return witness_status(c, err);
 }
 
-static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, int* gave_up);
+static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, unsigned B, uint64_t* proofs_out,
+                      size_t proof_stride, int* status_out, int* gave_up);
 
 // circuit_data.prove(pw).  The grid-wide witness interpreters assume that all of their (few) workgroups are resident; if the device
 // is so oversubscribed by other work that a wait runs out of its budget, the launch drains with an error flag instead of hanging,
@@ -2050,17 +2100,22 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !pw || !proof_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_cap < c->proof_len) return p2mt::fail(P2MT_EINVAL, "prove: proof buffer too small (p2mt_circuit_get_info)");
+  if (p2mt::batch_B() != 1) return p2mt::fail(P2MT_EINVAL, "prove: called inside a batched prove");
   int gave_up = 0;
-  int rc = prove_once(c, pw, proof_out, &gave_up);
+  int rc = prove_once(c, &pw, 1, proof_out, 0, nullptr, &gave_up);
   if (gave_up && !c->force_single_workgroup) {
     c->force_single_workgroup = true;
-    rc = prove_once(c, pw, proof_out, &gave_up);
+    rc = prove_once(c, &pw, 1, proof_out, 0, nullptr, &gave_up);
     c->force_single_workgroup = false;
   }
   return rc;
 }
 
-static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, int* gave_up) {
+// One pass of the prover pipeline over B proofs (B = 1 outside a batch; inside one every launch carries the proofs in grid z
+// and the per-proof pointers below are those of block 0, see runtime.h BatchCtx).  Nothing but the proof-of-work result visits
+// the host before the proofs do.
+static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, unsigned B, uint64_t* proofs_out,
+                      size_t proof_stride, int* status_out, int* gave_up) {
   *gave_up = 0;
   hipStream_t st = rt().stream;
   const u32 n = c->n, log_n = c->degree_bits, log_big = log_n + kRateBits, big = n << kRateBits, n_cs = c->n_cs;
@@ -2071,10 +2126,10 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint
   u64* d_pi = d_proof + (c->proof_len - c->n_pi);
 
   // witness, public-input hash, wires commitment
-  P2MT_TRY(fill_witness(c, pw));
+  P2MT_TRY(fill_witness(c, pws, B));
   // (the circuit digest has been sitting at d_head[0..4) since build(): nothing to upload)
   if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(d_pi, 1, c->n_pi, 0, d_pi_hash));
-  else P2MT_HIP(hipMemsetAsync(d_pi_hash, 0, 32, st));
+  else P2MT_TRY(p2mt::batch_fill(d_pi_hash, 0, 32));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_w_vals, 1, kNumWires, log_n, kRateBits, kCapHeight, c->d_w_coeffs, c->d_w_lde, c->d_w_leaves,
                                   c->n_digests ? c->d_w_dig : nullptr, d_w_cap));
   // challenger: circuit digest, public-input hash, wires cap -> betas, gammas
@@ -2105,30 +2160,21 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint
   u32 n_extra = 0;
   for (u32 g = 0; g < c->n_kinds; ++g) n_extra += c->kind[g] > G_POSEIDON;
   if (n_extra) {
-    hipLaunchKernelGGL(k_quotient_extra, dim3(grid_for(big), n_extra), dim3(kBlock), 0, st, qd, (const u64*)c->d_cs_lde,
-                       (const u64*)c->d_w_lde, (const u64*)c->d_chal, c->d_q_extra);
+    hipLaunchKernelGGL(k_quotient_extra, bgrid(grid_for(big), n_extra), dim3(kBlock), 0, st, qd, (const u64*)c->d_cs_lde,
+                       (const u64*)c->d_w_lde, (const u64*)c->d_chal, c->d_q_extra, barg());
     P2MT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_quotient, dim3((big + 63) / 64), dim3(256), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
+  hipLaunchKernelGGL(k_quotient, bgrid((big + 63) / 64), dim3(256), 0, st, qd, (const u64*)c->d_cs_lde, (const u64*)c->d_w_lde,
                      (const u64*)c->d_z_lde, (const u64*)d_pi_hash, (const u64*)c->d_chal, (const u64*)c->d_kis,
-                     (const u64*)rt().d_rc, (const u64*)c->d_q_extra, n_extra, c->d_q_vals);
+                     (const u64*)rt().d_rc, (const u64*)c->d_q_extra, n_extra, c->d_q_vals, barg());
   P2MT_LAUNCH_CHECK();
   P2MT_TRY(p2mt::coset_ifft_dev(c->d_q_vals, log_big, kNumCh, 7, c->d_q_coeffs));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_q_coeffs, 0, kNumQuot, log_n, kRateBits, kCapHeight, nullptr, c->d_q_lde, c->d_q_leaves,
                                   c->n_digests ? c->d_q_dig : nullptr, d_q_cap));
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_q_cap, 64, c->d_chal + 3 * kNumCh, 2));  // zeta
-  P2MT_HIP(hipMemcpyAsync(c->h_pin, c->d_chal + 3 * kNumCh, 16, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipStreamSynchronize(st));
-  const u64 zeta[2] = {c->h_pin[0], c->h_pin[1]};
-  {  // plonky2: ensure!(zeta^n != 1)
-    u64 a = zeta[0], b2 = zeta[1];
-    for (u32 k = 0; k < log_n; ++k) {
-      const u64 na = h_add(h_mul(a, a), h_mul(7, h_mul(b2, b2))), nb = h_mul(2, h_mul(a, b2));
-      a = na;
-      b2 = nb;
-    }
-    if (a == 1 && b2 == 0) return p2mt::fail(P2MT_EINVAL, "prove: opening point is in the subgroup");
-  }
+  // zeta stays on the device: the openings, the FRI quotients and plonky2's `ensure!(zeta^n != 1)` (a flag that comes back with
+  // the proof) all read it there
+  u64* d_zeta = c->d_chal + 3 * kNumCh;
+  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_q_cap, 64, d_zeta, 2));
   // openings at zeta (every polynomial) and g zeta (the Z's), observed; then the FRI proof
   p2mt_fri_oracle oracles[4] = {{c->d_cs_coeffs, c->d_cs_leaves, c->d_cs_dig, n_cs},
                                 {c->d_w_coeffs, c->d_w_leaves, c->d_w_dig, kNumWires},
@@ -2144,21 +2190,31 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint
     next_polys.push_back(2);
     next_polys.push_back(k);
   }
-  const u64 g = h_root_of_unity(log_n);
-  p2mt_fri_batch batches[2] = {{{zeta[0], zeta[1]}, all_polys.data(), all_polys.size() / 2},
-                               {{h_mul(zeta[0], g), h_mul(zeta[1], g)}, next_polys.data(), next_polys.size() / 2}};
-  P2MT_TRY(p2mt_fri_openings_dev(oracles, 4, batches, 2, log_n, c->d_open));
+  p2mt_fri_batch batches[2] = {{{0, 0}, all_polys.data(), all_polys.size() / 2}, {{0, 0}, next_polys.data(), next_polys.size() / 2}};
+  p2mt::FriPointsDev pts{};
+  pts.d_point[0] = pts.d_point[1] = d_zeta;
+  pts.scale[0] = 1;
+  pts.scale[1] = h_root_of_unity(log_n);
+  P2MT_TRY(p2mt::fri_openings_points_dev(oracles, 4, batches, 2, pts, log_n, c->d_open));
   P2MT_TRY(p2mt_challenger_observe_dev(c->ch, c->d_open, 2 * n_open));
-  hipLaunchKernelGGL(k_opening_set, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs);
+  hipLaunchKernelGGL(k_opening_set, bgrid(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs,
+                     (const u64*)d_zeta, log_n, c->d_err, barg());
   P2MT_LAUNCH_CHECK();
-  // the proof (with the error flags right behind it) rides back on the FRI prover's own final synchronisation
-  P2MT_TRY(p2mt::fri_prove_openings_epilogue_dev(oracles, 4, batches, 2, &c->fri, c->ch, d_fri, c->h_pin + 8, d_proof,
-                                                 (c->proof_len + 2) * 8));
-  std::copy(c->h_pin + 8, c->h_pin + 8 + c->proof_len, proof_out);
-  int err[4];
-  memcpy(err, c->h_pin + 8 + c->proof_len, sizeof err);
-  *gave_up = err[2] != 0;
-  return witness_status(c, err);
+  // the proofs (with the error flags right behind them) ride back on the FRI prover's own final synchronisation
+  P2MT_TRY(p2mt::fri_prove_openings_epilogue_dev(oracles, 4, batches, 2, pts, &c->fri, c->ch, d_fri, c->h_pin + 8, d_proof,
+                                                 (c->proof_len + 2) * 8, c->pin_pitch * 8));
+  int rc = P2MT_OK;
+  for (unsigned bi = 0; bi < B; ++bi) {
+    const u64* h = c->h_pin + (size_t)bi * c->pin_pitch + 8;
+    std::copy(h, h + c->proof_len, proofs_out + (size_t)bi * proof_stride);
+    int err[4];
+    memcpy(err, h + c->proof_len, sizeof err);
+    if (err[2] != 0) *gave_up = 1;
+    const int r = witness_status(c, err);
+    if (status_out) status_out[bi] = r;
+    if (r != P2MT_OK && rc == P2MT_OK) rc = r;
+  }
+  return rc;
 }
 
 // intermediates of the last p2mt_circuit_prove on this circuit (parity tests)
@@ -2352,3 +2408,174 @@ extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_
   const int rc = first_err.load();
   return rc == P2MT_OK ? P2MT_OK : p2mt::fail(rc, "prove_many: at least one prove failed (see status_out)");
 }
+
+// ==================================================================================================== batched prover
+// B proofs of one circuit per pipeline pass: every launch of prove_once carries the proofs in grid dimension z, so a batch costs
+// the dispatch packets of ONE proof (the concurrent-prover path is bound by the device's packet rate).  Each proof
+// owns a block of device memory -- the per-proof buffers of p2mt_circuit_data, a scratch arena and a challenger state --, the
+// circuit's constants / schedule / sigma commitment stay shared.  Proofs are bit-identical to p2mt_circuit_prove's.
+namespace {
+struct PerProof {
+  u64 *w_vals, *w_coeffs, *w_lde, *w_leaves, *w_dig, *z_vals, *z_coeffs, *z_lde, *z_leaves, *z_dig, *pp_q;
+  u64 *q_vals, *q_coeffs, *q_lde, *q_leaves, *q_dig, *head, *open, *chal, *init, *q_extra;
+  int* err;
+  p2mt_challenger* ch;
+  u64* h_pin;
+  size_t pin_pitch;
+};
+void exchange(p2mt_circuit_data* c, PerProof& p) {
+  std::swap(c->d_w_vals, p.w_vals), std::swap(c->d_w_coeffs, p.w_coeffs), std::swap(c->d_w_lde, p.w_lde);
+  std::swap(c->d_w_leaves, p.w_leaves), std::swap(c->d_w_dig, p.w_dig);
+  std::swap(c->d_z_vals, p.z_vals), std::swap(c->d_z_coeffs, p.z_coeffs), std::swap(c->d_z_lde, p.z_lde);
+  std::swap(c->d_z_leaves, p.z_leaves), std::swap(c->d_z_dig, p.z_dig), std::swap(c->d_pp_q, p.pp_q);
+  std::swap(c->d_q_vals, p.q_vals), std::swap(c->d_q_coeffs, p.q_coeffs), std::swap(c->d_q_lde, p.q_lde);
+  std::swap(c->d_q_leaves, p.q_leaves), std::swap(c->d_q_dig, p.q_dig);
+  std::swap(c->d_head, p.head), std::swap(c->d_open, p.open), std::swap(c->d_chal, p.chal), std::swap(c->d_init, p.init);
+  std::swap(c->d_q_extra, p.q_extra), std::swap(c->d_err, p.err), std::swap(c->ch, p.ch), std::swap(c->h_pin, p.h_pin);
+  std::swap(c->pin_pitch, p.pin_pitch);
+}
+}  // namespace
+
+struct p2mt_batch_prover {
+  p2mt_circuit_data* c = nullptr;
+  unsigned B = 0;
+  bool ready = false;
+  size_t stride = 0;  // bytes per proof block
+  char* d_block = nullptr;
+  u64* h_pin = nullptr;
+  PerProof pp{};  // block 0's pointers (exchanged with the circuit's own for the duration of a pass)
+  size_t arena_off = 0, slot_off[p2mt::kScratchCount] = {}, slot_cap[p2mt::kScratchCount] = {};
+};
+
+extern "C" int p2mt_batch_prover_create(p2mt_circuit_data* c, size_t batch, p2mt_batch_prover** out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (batch == 0 || batch > 4096) return p2mt::fail(P2MT_EINVAL, "batch_prover: batch must be in 1..4096");
+  if (!c->lds_bytes || c->degree_bits > 11)
+    return p2mt::fail(P2MT_EINVAL, "batch_prover: only circuits whose witness table fits LDS (the reference's MMR-verifier circuits) are batched");
+  p2mt_batch_prover* b = new (std::nothrow) p2mt_batch_prover;
+  if (!b) return p2mt::fail(P2MT_ENOMEM, "out of host memory");
+  b->c = c;
+  b->B = (unsigned)batch;
+  *out = b;
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_batch_prover_destroy(p2mt_batch_prover* b) {
+  if (!b) return P2MT_OK;
+  if (b->d_block) {
+    (void)hipStreamSynchronize(rt().stream);
+    (void)hipFree(b->d_block);
+  }
+  if (b->h_pin) (void)hipHostFree(b->h_pin);
+  if (b->pp.ch) p2mt::challenger_unwrap(b->pp.ch);
+  delete b;
+  return P2MT_OK;
+}
+
+// first use: size the per-proof scratch arena from one tracked single-proof run, then allocate the blocks
+static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness* pw) {
+  p2mt_circuit_data* c = b->c;
+  std::vector<u64> tmp(c->proof_len);
+  p2mt::scratch_track_reset();
+  P2MT_TRY(p2mt_circuit_prove(c, pw, tmp.data(), tmp.size()));
+  const size_t n = c->n, big = n << kRateBits, nd = c->n_digests;
+  const size_t n_open = c->n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
+  size_t words = 0;
+  auto carve = [&](size_t w) {
+    const size_t at = words;
+    words += (w + 3) & ~(size_t)3;
+    return at;
+  };
+  struct Bt {
+    size_t vals, coeffs, lde, leaves, dig;
+  };
+  auto carve_batch = [&](size_t polys) { return Bt{carve(polys * n), carve(polys * n), carve(polys * big), carve(polys * big), carve(4 * (nd ? nd : 1))}; };
+  const Bt bw = carve_batch(kNumWires), bz = carve_batch(kNumZs), bq = carve_batch(kNumQuot);
+  const size_t o_qvals = carve(kNumCh * big), o_ppq = carve((size_t)kNumCh * kNumChunks * n);
+  const size_t o_head = carve(8 + c->proof_len + 2), o_open = carve(2 * n_open), o_chal = carve(8), o_init = carve(2 * c->init_cap);
+  const size_t o_q_extra = c->has_recursion_gates ? carve((size_t)(G_KINDS - G_POSEIDON - 1) * kNumCh * big) : 0;
+  const size_t o_ch = carve(p2mt::kChallengerStateBytes / 8);
+  b->arena_off = words * 8;
+  size_t arena = 0;
+  for (int k = 0; k < p2mt::kScratchCount; ++k) {
+    b->slot_off[k] = arena;
+    b->slot_cap[k] = (p2mt::scratch_track_max(k) + 255) & ~(size_t)255;
+    arena += b->slot_cap[k];
+  }
+  b->stride = (b->arena_off + arena + 255) & ~(size_t)255;
+  if (hipMalloc((void**)&b->d_block, b->stride * b->B) != hipSuccess) {
+    (void)hipGetLastError();
+    b->d_block = nullptr;
+    return p2mt::fail(P2MT_ENOMEM, "hipMalloc(batch prover blocks) failed");
+  }
+  hipStream_t st = rt().stream;
+  P2MT_HIP(hipMemsetAsync(b->d_block, 0, b->stride * b->B, st));
+  const size_t pitch = (c->pin_pairs_off + 2 * c->init_cap + 3) & ~(size_t)3;
+  if (hipHostMalloc((void**)&b->h_pin, pitch * 8 * b->B, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    b->h_pin = nullptr;
+    return p2mt::fail(P2MT_ENOMEM, "hipHostMalloc(batch prover staging) failed");
+  }
+  u64* base = reinterpret_cast<u64*>(b->d_block);
+  PerProof& p = b->pp;
+  p.w_vals = base + bw.vals, p.w_coeffs = base + bw.coeffs, p.w_lde = base + bw.lde, p.w_leaves = base + bw.leaves, p.w_dig = base + bw.dig;
+  p.z_vals = base + bz.vals, p.z_coeffs = base + bz.coeffs, p.z_lde = base + bz.lde, p.z_leaves = base + bz.leaves, p.z_dig = base + bz.dig;
+  p.q_coeffs = base + bq.coeffs, p.q_lde = base + bq.lde, p.q_leaves = base + bq.leaves, p.q_dig = base + bq.dig;
+  p.q_vals = base + o_qvals, p.pp_q = base + o_ppq, p.head = base + o_head, p.open = base + o_open, p.chal = base + o_chal;
+  p.init = base + o_init, p.q_extra = c->has_recursion_gates ? base + o_q_extra : nullptr;
+  p.err = reinterpret_cast<int*>(base + o_head + 8 + c->proof_len);
+  P2MT_TRY(p2mt::challenger_wrap(base + o_ch, &p.ch));
+  p.h_pin = b->h_pin;
+  p.pin_pitch = pitch;
+  // the circuit digest sits in front of every proof buffer (build() put it into the circuit's own)
+  for (unsigned i = 0; i < b->B; ++i)
+    P2MT_HIP(hipMemcpyAsync(b->d_block + (size_t)i * b->stride + o_head * 8, c->d_head, 32, hipMemcpyDeviceToDevice, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  b->ready = true;
+  return P2MT_OK;
+}
+
+// witnesses[i] -> proofs_out + i * proof_stride, i < n, in passes of up to `batch` proofs; status_out[i] (may be NULL) gets each
+// proof's status, the return value is the first non-zero one.  Every witness must set the same targets in the same order.
+extern "C" int p2mt_batch_prover_prove(p2mt_batch_prover* b, const p2mt_partial_witness* const* witnesses, size_t n,
+                                       uint64_t* proofs_out, size_t proof_stride, int* status_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!b || !witnesses || !proofs_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (proof_stride < b->c->proof_len) return p2mt::fail(P2MT_EINVAL, "prove_batch: proof_stride < proof_len (p2mt_circuit_get_info)");
+  for (size_t i = 0; i < n; ++i)
+    if (!witnesses[i]) return p2mt::fail(P2MT_EINVAL, "prove_batch: null witness");
+  if (n == 0) return P2MT_OK;
+  if (p2mt::batch_B() != 1) return p2mt::fail(P2MT_EINVAL, "prove_batch: called inside a batched prove");
+  if (!b->ready) P2MT_TRY(batch_prover_prepare(b, witnesses[0]));
+  p2mt_circuit_data* c = b->c;
+  struct Scope {  // the circuit drives block 0 for the duration of the call; the thread's launches carry the batch
+    p2mt_batch_prover* b;
+    explicit Scope(p2mt_batch_prover* bb) : b(bb) { exchange(b->c, b->pp); }
+    ~Scope() {
+      exchange(b->c, b->pp);
+      p2mt::batch() = p2mt::BatchCtx{};
+    }
+  } scope(b);
+  int rc = P2MT_OK;
+  for (size_t at = 0; at < n; at += b->B) {
+    const unsigned cnt = (unsigned)std::min<size_t>(b->B, n - at);
+    p2mt::BatchCtx& ctx = p2mt::batch();
+    ctx.B = cnt;
+    ctx.arg = p2mt::BatchArg{(uint64_t)b->d_block, (uint64_t)b->stride, (uint64_t)b->stride};
+    ctx.arena = b->d_block + b->arena_off;
+    for (int k = 0; k < p2mt::kScratchCount; ++k) ctx.slot_off[k] = b->slot_off[k], ctx.slot_cap[k] = b->slot_cap[k];
+    int gave_up = 0;
+    constexpr int kUnset = -0x7fffffff;  // a pass that fails before its proofs come back leaves no per-proof status
+    std::vector<int> st(cnt, kUnset);
+    const int r = prove_once(c, witnesses + at, cnt, proofs_out + at * proof_stride, proof_stride, st.data(), &gave_up);
+    if (r != P2MT_OK && rc == P2MT_OK) rc = r;
+    for (unsigned i = 0; i < cnt; ++i) {
+      if (st[i] == kUnset) st[i] = r != P2MT_OK ? r : P2MT_EHIP;
+      if (status_out) status_out[at + i] = st[i];
+    }
+  }
+  return rc;
+}
+
+extern "C" size_t p2mt_batch_prover_batch(const p2mt_batch_prover* b) { return b ? b->B : 0; }

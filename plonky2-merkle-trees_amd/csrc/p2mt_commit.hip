@@ -28,6 +28,10 @@
 
 using gl::u32;
 using gl::u64;
+using p2mt::BatchArg;
+using p2mt_dev::barg;
+using p2mt_dev::bgrid;
+using p2mt_dev::bp;
 
 namespace {
 
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(kBlock) void k_bitrev_scale(const u64* __restrict__
 // the bit-reversal back to natural order fused with the 1/n (and, for coset_ifft, shift^-k) scaling.  Replaces the
 // copy + DIF + bit-reversal launches of the small circuits, where the launch count is what limits concurrent provers.
 __global__ __launch_bounds__(kBlock) void k_ifft_small(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_n,
-                                                       const u64* __restrict__ tw_inv, u64 n_inv, u64 shift_inv) {
+                                                       const u64* __restrict__ tw_inv, u64 n_inv, u64 shift_inv, BatchArg ba) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   extern __shared__ __attribute__((aligned(16))) u64 buf[];
   const unsigned n = 1u << log_n;
   const u64* src = in + ((size_t)blockIdx.x << log_n);
@@ -134,7 +140,9 @@ __global__ __launch_bounds__(kBlock) void k_ifft_small(const u64* __restrict__ i
 // NTT_n[c_m * cp[j][m]], cp[j][m] = (shift * w_N^j)^m.
 __global__ __launch_bounds__(kBlock) void k_coset_lde(const u64* __restrict__ coeffs, unsigned log_n, unsigned rate_bits,
                                                       const u64* __restrict__ coset_pow, const u64* __restrict__ tw,
-                                                      u64* __restrict__ out) {
+                                                      u64* __restrict__ out, BatchArg ba) {
+  coeffs = bp(coeffs, ba);
+  out = bp(out, ba);
   extern __shared__ __attribute__((aligned(16))) u64 buf[];
   const unsigned n = 1u << log_n;
   const unsigned poly = blockIdx.x >> rate_bits, j = blockIdx.x & ((1u << rate_bits) - 1);
@@ -153,7 +161,10 @@ __global__ __launch_bounds__(kBlock) void k_coset_lde(const u64* __restrict__ co
 __global__ __launch_bounds__(kBlock) void k_ifft_coset_lde(const u64* __restrict__ vals, unsigned log_n, unsigned rate_bits,
                                                            const u64* __restrict__ coset_pow, const u64* __restrict__ tw,
                                                            const u64* __restrict__ tw_inv, u64 n_inv, u64* __restrict__ coeffs,
-                                                           u64* __restrict__ out) {
+                                                           u64* __restrict__ out, BatchArg ba) {
+  vals = bp(vals, ba);
+  coeffs = bp(coeffs, ba);
+  out = bp(out, ba);
   extern __shared__ __attribute__((aligned(16))) u64 buf[];  // 2 n words
   const unsigned n = 1u << log_n;
   u64* cf = buf + n;
@@ -304,7 +315,9 @@ __global__ __launch_bounds__(kBlock) void k_coset_lde12(const u64* __restrict__ 
 // ---------------------------------------------------------------- leaves
 // Poly-major [w][n_pts] -> leaf-major [n_pts][w] through a 32x32 LDS tile (+1 pad: conflict-free column reads).
 __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in, u64* __restrict__ out, size_t w,
-                                                      size_t n_pts) {
+                                                      size_t n_pts, BatchArg ba) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   __shared__ u64 tile[32][33];
   const size_t p0 = (size_t)blockIdx.y * 32, i0 = (size_t)blockIdx.x * 32;
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -318,7 +331,9 @@ __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in
 // hash_or_noop of leaf i = column i of the poly-major matrix: lane i reads in[p * n_pts + i] (coalesced).
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__ in, size_t w, size_t n_pts,
-                                                         u64* __restrict__ digests, p2mt::PermCtx ctx) {
+                                                         u64* __restrict__ digests, BatchArg ba, p2mt::PermCtx ctx) {
+  in = bp(in, ba);
+  digests = bp(digests, ba);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_pts) return;
   u64 s[12];
@@ -357,7 +372,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__
 // The same leaf sponge on four lanes per column (latency path for <= 2^16 leaves): lane q of a quad owns state words
 // 3q..3q+2, so of each 8-word chunk it loads the (up to 3) words it owns.
 __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restrict__ in, size_t w, size_t n_pts,
-                                                              u64* __restrict__ digests, p2mt::PermCtx ctx) {
+                                                              u64* __restrict__ digests, BatchArg ba, p2mt::PermCtx ctx) {
+  in = bp(in, ba);
+  digests = bp(digests, ba);
   const size_t col = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 2;
   if (col >= n_pts) return;  // quad-uniform
   poseidon_quad::Lane ln;
@@ -387,7 +404,10 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_quad(const u64* __restr
 // on a quad), so a 135-wide leaf costs 17 x 11 us.
 __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restrict__ in, size_t w, size_t n_pts,
                                                               u64* __restrict__ digests, u64* __restrict__ leaves,
-                                                              p2mt::PermCtx ctx) {
+                                                              BatchArg ba, p2mt::PermCtx ctx) {
+  in = bp(in, ba);
+  digests = bp(digests, ba);
+  leaves = bp(leaves, ba);
   __shared__ u64 rc_lds[360];
   ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
   const size_t col = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -411,7 +431,10 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restr
 // dispatch packets, not the CUs.  in: 2^cap subtrees of 2^log_sub nodes each; next: where the level after `in` goes in the
 // level-major digest array (null = the caller keeps no digests); cap: the 2^cap results.
 __global__ __launch_bounds__(1024) void k_merkle_top(const u64* __restrict__ in, unsigned log_sub, u64* __restrict__ next,
-                                                     size_t n_in, u64* __restrict__ cap, p2mt::PermCtx ctx) {
+                                                     size_t n_in, u64* __restrict__ cap, BatchArg ba, p2mt::PermCtx ctx) {
+  in = bp(in, ba);
+  next = bp(next, ba);
+  cap = bp(cap, ba);
   __shared__ u64 rc_lds[360];
   __shared__ u64 buf[2][16][4];
   ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
@@ -636,13 +659,14 @@ int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned
   P2MT_TRY(get_coset_pows(log_n, rate_bits, shift, &cp));
   const int slot = p2mt::prof_begin();  // the LDE is the HBM-streaming kernel of the commit step
   if (log_n == 12 && rt().use_lde12) {
+    if (p2mt::batch_B() > 1) return p2mt::fail(P2MT_EINVAL, "batched pipeline: 2^12-row polynomials are not supported");
     const u64* twf;
     P2MT_TRY(get_full_twiddles(12, &twf));
     hipLaunchKernelGGL(k_coset_lde12, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
                        rate_bits, cp, twf, tw, d_out);
   } else {
-    hipLaunchKernelGGL(k_coset_lde, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,
-                       d_coeffs, log_n, rate_bits, cp, tw, d_out);
+    hipLaunchKernelGGL(k_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,
+                       d_coeffs, log_n, rate_bits, cp, tw, d_out, barg());
   }
   p2mt::prof_end(slot);
   P2MT_LAUNCH_CHECK();
@@ -693,8 +717,7 @@ static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u6
   const int k = log2_strict(n);
   // level-major digests: level j has n >> j entries, levels 0 .. k-cap_height-1; the next row is the cap
   if ((unsigned)k == cap_height) {
-    P2MT_HIP(hipMemcpyAsync(d_cap_out, d_level0, n * 32, hipMemcpyDeviceToDevice, rt().stream));
-    return P2MT_OK;
+    return p2mt::batch_copy(d_cap_out, d_level0, n * 32);
   }
   u64* cur = d_level0;
   size_t cur_n = n;
@@ -704,8 +727,8 @@ static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u6
   for (unsigned level = 0; level < (unsigned)k - cap_height; ++level) {
     const unsigned remaining = (unsigned)k - cap_height - level;
     if (remaining >= 2 && remaining <= 5 && rt().mds == 2 && rt().use_quad && !rt().throughput) {  // the top of the tree in one launch
-      hipLaunchKernelGGL(k_merkle_top, dim3(1u << cap_height), dim3(1024), 0, rt().stream, (const u64*)cur, remaining,
-                         d_digests_out ? next_store : nullptr, cur_n, d_cap_out, p2mt::perm_ctx());
+      hipLaunchKernelGGL(k_merkle_top, bgrid(1u << cap_height), dim3(1024), 0, rt().stream, (const u64*)cur, remaining,
+                         d_digests_out ? next_store : nullptr, cur_n, d_cap_out, barg(), p2mt::perm_ctx());
       P2MT_LAUNCH_CHECK();
       return P2MT_OK;
     }
@@ -840,8 +863,8 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
     P2MT_TRY(get_twiddles(log_n, 1, &twi));
     P2MT_TRY(get_coset_pows(log_n, rate_bits, 7, &cp));
     const int slot = p2mt::prof_begin();
-    hipLaunchKernelGGL(k_ifft_coset_lde, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)16 << log_n, st, d_polys,
-                       log_n, rate_bits, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde);
+    hipLaunchKernelGGL(k_ifft_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)16 << log_n, st, d_polys,
+                       log_n, rate_bits, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde, barg());
     p2mt::prof_end(slot);
     P2MT_LAUNCH_CHECK();
     d_coeffs = coeffs;
@@ -851,11 +874,12 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
     if (!coeffs) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8, (void**)&coeffs));
     const u64* twi;
     P2MT_TRY(get_twiddles(log_n, 1, &twi));
-    hipLaunchKernelGGL(k_ifft_small, dim3((unsigned)n_polys), dim3(kBlock), (size_t)8 << log_n, st, d_polys, coeffs, log_n, twi,
-                       h_pow((u64)n % gl::P, gl::P - 2), (u64)1);
+    hipLaunchKernelGGL(k_ifft_small, bgrid((unsigned)n_polys), dim3(kBlock), (size_t)8 << log_n, st, d_polys, coeffs, log_n, twi,
+                       h_pow((u64)n % gl::P, gl::P - 2), (u64)1, barg());
     P2MT_LAUNCH_CHECK();
     d_coeffs = coeffs;
   } else if (is_values) {  // IFFT: DIF with inverse roots, then bit-reversal + 1/n
+    if (p2mt::batch_B() > 1) return p2mt::fail(P2MT_EINVAL, "batched pipeline: polynomials above 2^12 rows are not supported");
     u64* buf;
     P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8 * 2, (void**)&buf));
     u64* work = buf + n_polys * n;
@@ -868,28 +892,29 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
     P2MT_LAUNCH_CHECK();
     d_coeffs = coeffs;
   } else if (d_coeffs_out && d_coeffs_out != d_polys) {
-    P2MT_HIP(hipMemcpyAsync(d_coeffs_out, d_polys, n_polys * n * 8, hipMemcpyDeviceToDevice, st));
+    P2MT_TRY(p2mt::batch_copy(d_coeffs_out, d_polys, n_polys * n * 8));
   }
   if (!lde_done) P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, 7, n_polys, lde));
-  const bool wave_sponge = n_polys > 4 && big <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad && !rt().throughput;
+  const size_t big_all = big * p2mt::batch_B();  // (inside a batch the layout is chosen for all the leaves of the launch)
+  const bool wave_sponge = n_polys > 4 && big_all <= ((size_t)1 << 12) && rt().mds == 2 && rt().use_quad && !rt().throughput;
   if (d_leaves_out && !wave_sponge) {
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
-                       (const u64*)lde, d_leaves_out, n_polys, big);
+    hipLaunchKernelGGL(k_transpose, bgrid((unsigned)((big + 31) / 32), (unsigned)((n_polys + 31) / 32)), dim3(kBlock), 0, st,
+                       (const u64*)lde, d_leaves_out, n_polys, big, barg());
     P2MT_LAUNCH_CHECK();
   }
   const bool cap_is_leaves = cap_height == log_big;
   u64* d_level0 = (d_digests_out && !cap_is_leaves) ? d_digests_out : nullptr;
   if (!d_level0) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, big * 32, (void**)&d_level0));
   if (wave_sponge) {
-    hipLaunchKernelGGL(k_hash_columns_wave, dim3((unsigned)((big + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
-                       (const u64*)lde, n_polys, big, d_level0, d_leaves_out, p2mt::perm_ctx());
+    hipLaunchKernelGGL(k_hash_columns_wave, bgrid((unsigned)((big + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
+                       (const u64*)lde, n_polys, big, d_level0, d_leaves_out, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
-  } else if (n_polys > 4 && big <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
-    hipLaunchKernelGGL(k_hash_columns_quad, dim3(grid_for(4 * big)), dim3(kBlock), 0, st, (const u64*)lde, n_polys, big,
-                       d_level0, p2mt::perm_ctx());
+  } else if (n_polys > 4 && big_all <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_hash_columns_quad, bgrid(grid_for(4 * big)), dim3(kBlock), 0, st, (const u64*)lde, n_polys, big,
+                       d_level0, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
   } else {
-    P2MT_DISPATCH(k_hash_columns, grid_for(big), kBlock, (const u64*)lde, n_polys, big, d_level0);
+    P2MT_DISPATCH(k_hash_columns, bgrid(grid_for(big)), kBlock, (const u64*)lde, n_polys, big, d_level0, barg());
   }
   return merkle_levels_to_cap(d_level0, big, cap_height, cap_is_leaves ? nullptr : d_digests_out, d_cap_out);
 }
@@ -920,11 +945,12 @@ int p2mt::coset_ifft_dev(uint64_t* d_vals, unsigned log_n, size_t n_polys, uint6
   if (log_n <= kLdsLog) {
     const u64* twi;
     P2MT_TRY(get_twiddles(log_n, 1, &twi));
-    hipLaunchKernelGGL(k_ifft_small, dim3((unsigned)n_polys), dim3(kBlock), (size_t)8 << log_n, rt().stream, (const u64*)d_vals,
-                       d_coeffs_out, log_n, twi, n_inv, shift_inv);
+    hipLaunchKernelGGL(k_ifft_small, bgrid((unsigned)n_polys), dim3(kBlock), (size_t)8 << log_n, rt().stream, (const u64*)d_vals,
+                       d_coeffs_out, log_n, twi, n_inv, shift_inv, barg());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
+  if (p2mt::batch_B() > 1) return p2mt::fail(P2MT_EINVAL, "batched pipeline: polynomials above 2^12 points are not supported");
   P2MT_TRY(ntt_dif_dev(d_vals, log_n, n_polys, 1));
   hipLaunchKernelGGL(k_bitrev_coset_scale, dim3(grid_for(n_polys << log_n)), dim3(kBlock), 0, rt().stream, (const u64*)d_vals,
                      d_coeffs_out, log_n, n_polys, n_inv, shift_inv);

@@ -68,7 +68,12 @@ static_assert(sizeof(ChState) == 8 * (12 + 8 + 8) + 8, "layout shared with p2mt_
 // Observe obs[0..n_obs), then squeeze n_sq challenges into sq.  One wavefront; lane w < 12 owns sponge word w.
 __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, const u64* __restrict__ obs, u32 n_obs,
                                                    u64* __restrict__ sq, u32 n_sq, u32 fresh, ChState* __restrict__ save_to,
-                                                   unsigned long long* __restrict__ init_wit, PermCtx ctx) {
+                                                   unsigned long long* __restrict__ init_wit, BatchArg ba, PermCtx ctx) {
+  st = bp(st, ba);
+  obs = bp(obs, ba);
+  sq = bp(sq, ba);
+  save_to = bp(save_to, ba);
+  init_wit = bp(init_wit, ba);
   __shared__ u64 s_in[8], s_out[8];
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
@@ -163,9 +168,12 @@ __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, con
 // challenge after it (word 7 of the permuted state).  *result = smallest passing candidate (init ~0).
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ st, u32 pow_bits, u64 base, u64 count,
-                                                    unsigned long long* __restrict__ result, PermCtx ctx) {
+                                                    unsigned long long* __restrict__ result, BatchArg ba, PermCtx ctx) {
+  st = bp(st, ba);
+  result = bp(result, ba);
   const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= count) return;
+  if (*result < base) return;  // (batched grind) an earlier chunk already found this proof's witness
   const u64 cand = base + gid;
   const u32 n_in = st->n_in;  // < 8: a full buffer is duplexed at once
   u64 s[12];
@@ -187,9 +195,13 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ 
 // The same grind with four lanes per candidate (poseidon_quad.hip.h): a third of the single-hash latency, which is what
 // bounds a 2^17-candidate launch.
 __global__ __launch_bounds__(kBlock) void k_fri_pow_quad(const ChState* __restrict__ st, u32 pow_bits, u64 base, u64 count,
-                                                         unsigned long long* __restrict__ result, PermCtx ctx) {
+                                                         unsigned long long* __restrict__ result, BatchArg ba, PermCtx ctx) {
+  st = bp(st, ba);
+  result = bp(result, ba);
   const u64 gid = ((u64)blockIdx.x * kBlock + threadIdx.x) >> 2;
   if (gid >= count) return;  // quad-uniform
+  if (*result < base) return;  // (batched grind) an earlier chunk already found this proof's witness; workgroup-uniform enough:
+                               // values found by this launch are >= base
   poseidon_quad::Lane ln;
   poseidon_quad::lane_init(ln, ctx.rc);
   const u64 cand = base + gid;
@@ -212,7 +224,9 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_quad(const ChState* __restri
 
 // ---------------------------------------------------------------- alpha-composition
 // table[j] = base^j, j < count (canonical pairs)
-__global__ __launch_bounds__(kBlock) void k_ext_powers(const u64* __restrict__ base, u32 count, u64* __restrict__ table) {
+__global__ __launch_bounds__(kBlock) void k_ext_powers(const u64* __restrict__ base, u32 count, u64* __restrict__ table, BatchArg ba) {
+  base = bp(base, ba);
+  table = bp(table, ba);
   const u32 j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= count) return;
   const Ext r = ext_pow(Ext{base[0], base[1]}, j);
@@ -224,14 +238,17 @@ constexpr u32 kComposeGroup = 32;  // polynomials per partial sum
 
 // partial[g][c][i] = sum_{j in group g} (alpha^j)_c * f_j[i]   (ReducingFactor::reduce_polys_base as a dot product)
 __global__ __launch_bounds__(kBlock) void k_fri_compose(const u64* const* __restrict__ ptrs, u32 cnt, u32 n,
-                                                        const u64* __restrict__ apow, u64* __restrict__ partial) {
+                                                        const u64* __restrict__ apow, u64* __restrict__ partial, BatchArg ba) {
+  ptrs = bp(ptrs, ba);
+  apow = bp(apow, ba);
+  partial = bp(partial, ba);
   const u32 i = blockIdx.x * kBlock + threadIdx.x, g = blockIdx.y;
   if (i >= n) return;
   const u32 j0 = g * kComposeGroup, j1 = min(cnt, j0 + kComposeGroup);
   u64 re = 0, im = 0;
 #pragma unroll 4
   for (u32 j = j0; j < j1; ++j) {
-    const u64 c = ptrs[j][i];
+    const u64 c = bp(ptrs[j], ba)[i];
     re = gl::mul_add(apow[2 * j], c, re);
     im = gl::mul_add(apow[2 * j + 1], c, im);
   }
@@ -244,15 +261,19 @@ __global__ __launch_bounds__(kBlock) void k_fri_compose(const u64* const* __rest
 // The recurrence is a suffix scan: each thread reduces its chunk to one value, a log-step scan over the chunk values
 // gives every chunk its carry-in, then the chunk is replayed.
 constexpr int kQBlock = 1024, kQMaxLen = 4;  // n <= 2^12 coefficients: at most 4 per thread, kept in registers
-struct ZPows {  // z^(len 2^k), k < 10: the scan's multipliers, computed on the host (z is a host value)
-  u64 v[20];
-};
-__global__ __launch_bounds__(kQBlock) void k_fri_quotient(const u64* __restrict__ partial, u32 n_groups, u32 n, u64 za, u64 zb,
-                                                          ZPows zpw, const u64* __restrict__ apow_cnt, int first,
-                                                          u64* __restrict__ fin, u64* __restrict__ shifted) {
+// The opening point z = point * scale is read from device memory (the transcript's zeta; scale = 1 or the subgroup generator).
+__global__ __launch_bounds__(kQBlock) void k_fri_quotient(const u64* __restrict__ partial, u32 n_groups, u32 n,
+                                                          const u64* __restrict__ point, u64 scale,
+                                                          const u64* __restrict__ apow_cnt, int first,
+                                                          u64* __restrict__ fin, u64* __restrict__ shifted, BatchArg ba) {
+  partial = bp(partial, ba);
+  point = bp(point, ba);
+  apow_cnt = bp(apow_cnt, ba);
+  fin = bp(fin, ba);
+  shifted = bp(shifted, ba);
   __shared__ Ext S[kQBlock];
   const u32 len = n >= (u32)kQBlock ? n / kQBlock : 1, T = n / len, t = threadIdx.x;
-  const Ext z{za, zb};
+  const Ext z{gl::mul(point[0], scale), gl::mul(point[1], scale)};
   const u32 s = t * len;
   Ext c[kQMaxLen];  // this thread's composition coefficients (partial sums added up)
 #pragma unroll
@@ -270,13 +291,14 @@ __global__ __launch_bounds__(kQBlock) void k_fri_quotient(const u64* __restrict_
     if ((u32)i < len) loc = ext_add(ext_mul(loc, z), c[i]);
   S[t] = loc;
   __syncthreads();
-  u32 k = 0;
-  for (u32 d = 1; d < T; d *= 2, ++k) {
+  Ext zp = ext_pow(z, len);  // z^(len 2^k) in step k
+  for (u32 d = 1; d < T; d *= 2) {
     Ext v = S[t];
-    if (t + d < T) v = ext_add(v, ext_mul(Ext{zpw.v[2 * k], zpw.v[2 * k + 1]}, S[t + d]));
+    if (t + d < T) v = ext_add(v, ext_mul(zp, S[t + d]));
     __syncthreads();
     S[t] = v;
     __syncthreads();
+    zp = ext_mul(zp, zp);
   }
   if (t >= T) return;
   Ext acc = t + 1 < T ? S[t + 1] : Ext{0, 0};  // b at the end of this chunk
@@ -305,7 +327,9 @@ __global__ __launch_bounds__(kQBlock) void k_fri_quotient(const u64* __restrict_
 
 // (a, b) pairs from component-major arrays: the layer's Merkle leaves (2^arity_bits consecutive pairs per row) and
 // the final polynomial's proof words
-__global__ __launch_bounds__(kBlock) void k_fri_pairs(const u64* __restrict__ comp, u32 n, u64* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_fri_pairs(const u64* __restrict__ comp, u32 n, u64* __restrict__ out, BatchArg ba) {
+  comp = bp(comp, ba);
+  out = bp(out, ba);
   const u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   reinterpret_cast<ulonglong2*>(out)[i] = make_ulonglong2(comp[i], comp[n + i]);
@@ -313,7 +337,10 @@ __global__ __launch_bounds__(kBlock) void k_fri_pairs(const u64* __restrict__ co
 
 // P(x) = sum_{i<r} x^i P_i(x^r)  ->  sum_{i<r} beta^i P_i(x): out[k] = sum_i beta^i in[k r + i]
 __global__ __launch_bounds__(kBlock) void k_fri_fold(const u64* __restrict__ in, u32 n_in, u32 arity_bits,
-                                                     const u64* __restrict__ beta, u64* __restrict__ out) {
+                                                     const u64* __restrict__ beta, u64* __restrict__ out, BatchArg ba) {
+  in = bp(in, ba);
+  beta = bp(beta, ba);
+  out = bp(out, ba);
   const u32 n_out = n_in >> arity_bits, k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= n_out) return;
   const Ext b{beta[0], beta[1]};
@@ -342,19 +369,22 @@ struct QArgs {
 };
 
 // One workgroup per query round: x_index = challenge mod N; per tree the opened row and its Merkle path.
-__global__ __launch_bounds__(kBlock) void k_fri_queries(QArgs a, const u64* __restrict__ qch, u64* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_fri_queries(QArgs a, const u64* __restrict__ qch, u64* __restrict__ out, BatchArg ba) {
+  qch = bp(qch, ba);
+  out = bp(out, ba);
   const u64 x_index = qch[blockIdx.x] & (((u64)1 << a.log_big) - 1);
   u64* w = out + (u64)blockIdx.x * a.per_query;
   for (u32 ti = 0; ti < a.n_trees; ++ti) {
     const QTree& tr = a.t[ti];
+    const u64 *tr_leaves = bp(tr.leaves, ba), *tr_digests = bp(tr.digests, ba);
     const u64 row = x_index >> tr.idx_shift;
-    for (u32 i = threadIdx.x; i < tr.width; i += kBlock) w[i] = tr.leaves[row * tr.width + i];
+    for (u32 i = threadIdx.x; i < tr.width; i += kBlock) w[i] = tr_leaves[row * tr.width + i];
     w += tr.width;
     const u64 rows = (u64)1 << tr.log_rows;
     for (u32 i = threadIdx.x; i < 4 * tr.n_sib; i += kBlock) {
       const u32 s = i >> 2;
       const u64 off = 2 * rows - 2 * (rows >> s);  // rows + rows/2 + ... (s terms)
-      w[i] = tr.digests[4 * (off + ((row >> s) ^ 1)) + (i & 3)];
+      w[i] = tr_digests[4 * (off + ((row >> s) ^ 1)) + (i & 3)];
     }
     w += 4 * tr.n_sib;
   }
@@ -385,16 +415,21 @@ __global__ __launch_bounds__(kBlock) void k_eval_ext(const u64* __restrict__ coe
   }
 }
 
-// The same for a table of polynomials with a point each (FriOpenings in one launch): entry = {coeff pointer, za, zb, -}
+// The same for a table of polynomials with a point each (FriOpenings in one launch).  The point is point[0..2) * scale, read
+// from device memory: the prover's zeta never visits the host.  The table itself is shared by the proofs of a batch (it lives
+// outside the per-proof blocks); its pointers are rebased per proof.
 struct EvalEntry {
   const u64* coeffs;
-  u64 za, zb, pad;
+  const u64* point;
+  u64 scale, pad;
 };
-__global__ __launch_bounds__(kBlock) void k_eval_ext_table(const EvalEntry* __restrict__ tab, u32 log_n, u64* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_eval_ext_table(const EvalEntry* __restrict__ tab, u32 log_n, u64* __restrict__ out, BatchArg ba) {
+  out = bp(out, ba);
   __shared__ Ext S[kBlock];
   const u32 n = 1u << log_n, len = n >= (u32)kBlock ? n / kBlock : 1, T = n / len, t = threadIdx.x;
-  const u64* c = tab[blockIdx.x].coeffs;
-  const Ext z{tab[blockIdx.x].za, tab[blockIdx.x].zb};
+  const u64* c = bp(tab[blockIdx.x].coeffs, ba);
+  const u64* pt = bp(tab[blockIdx.x].point, ba);
+  const Ext z{gl::mul(pt[0], tab[blockIdx.x].scale), gl::mul(pt[1], tab[blockIdx.x].scale)};
   Ext loc{0, 0};
   if (t < T)
     for (u32 m = (t + 1) * len; m-- > t * len;) loc = ext_mul_add_base(loc, z, c[m]);
@@ -456,8 +491,8 @@ size_t digests_count(size_t rows, unsigned cap_height) {
 int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, size_t n_sq, bool fresh = false,
                       ChState* save_to = nullptr, unsigned long long* init_wit = nullptr) {
   if (n_obs > 0xFFFFFFFFull || n_sq > 0xFFFFFFFFull) return p2mt::fail(P2MT_EINVAL, "challenger: too many elements");
-  hipLaunchKernelGGL(k_challenger, dim3(1), dim3(64), 0, rt().stream, st, d_obs, (u32)n_obs, d_sq, (u32)n_sq, fresh ? 1u : 0u,
-                     save_to, init_wit, p2mt::perm_ctx());
+  hipLaunchKernelGGL(k_challenger, bgrid(1), dim3(64), 0, rt().stream, st, d_obs, (u32)n_obs, d_sq, (u32)n_sq, fresh ? 1u : 0u,
+                     save_to, init_wit, barg(), p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
@@ -466,7 +501,18 @@ int launch_challenger(ChState* st, const u64* d_obs, size_t n_obs, u64* d_sq, si
 
 struct p2mt_challenger {
   ChState* d = nullptr;
+  bool owned = true;
 };
+static_assert(sizeof(ChState) == p2mt::kChallengerStateBytes, "runtime.h");
+int p2mt::challenger_wrap(void* d_state, p2mt_challenger** out) {
+  p2mt_challenger* c = new (std::nothrow) p2mt_challenger;
+  if (!c) return p2mt::fail(P2MT_ENOMEM, "out of host memory");
+  c->d = static_cast<ChState*>(d_state);
+  c->owned = false;
+  *out = c;
+  return P2MT_OK;
+}
+void p2mt::challenger_unwrap(p2mt_challenger* c) { delete c; }
 
 // =================================================================== Challenger
 extern "C" int p2mt_challenger_create(p2mt_challenger** out) {
@@ -485,7 +531,7 @@ extern "C" int p2mt_challenger_create(p2mt_challenger** out) {
 
 extern "C" int p2mt_challenger_destroy(p2mt_challenger* c) {
   if (!c) return P2MT_OK;
-  if (c->d) {
+  if (c->d && c->owned) {
     (void)hipStreamSynchronize(rt().stream);
     (void)hipFree(c->d);
   }
@@ -615,10 +661,29 @@ extern "C" int p2mt_eval_polys_ext(const uint64_t* coeffs, size_t n_polys, unsig
 }
 
 // FriOpenings: every batch's polynomials at the batch's point, batches concatenated, one launch
-extern "C" int p2mt_fri_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
-                                     size_t n_batches, unsigned degree_bits, uint64_t* d_out) {
-  P2MT_TRY(p2mt::ensure_init());
-  if (!oracles || !batches || !d_out || n_oracles == 0 || degree_bits > 24) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
+namespace {
+// upload the host points of the public entry points (canonical) to a small device array
+int upload_points(const p2mt_fri_batch* batches, size_t n_batches, p2mt::FriPointsDev* pts) {
+  if (n_batches > (size_t)p2mt::kMaxFriBatches) return p2mt::fail(P2MT_EINVAL, "fri: too many batches");
+  u64* d_pts;
+  P2MT_TRY(p2mt::scratch_get_shared(p2mt::kScratchPoints, 2 * p2mt::kMaxFriBatches * 8, (void**)&d_pts));
+  u64 h[2 * p2mt::kMaxFriBatches] = {};
+  for (size_t b = 0; b < n_batches; ++b) {
+    h[2 * b] = batches[b].point[0] % gl::P;
+    h[2 * b + 1] = batches[b].point[1] % gl::P;
+    pts->d_point[b] = d_pts + 2 * b;
+    pts->scale[b] = 1;
+  }
+  P2MT_HIP(hipMemcpyAsync(d_pts, h, sizeof h, hipMemcpyHostToDevice, rt().stream));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));  // `h` is on the stack
+  return P2MT_OK;
+}
+}  // namespace
+
+int p2mt::fri_openings_points_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                  size_t n_batches, const FriPointsDev& pts, unsigned degree_bits, uint64_t* d_out) {
+  if (!oracles || !batches || !d_out || n_oracles == 0 || degree_bits > 24 || n_batches > (size_t)kMaxFriBatches)
+    return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
   std::vector<EvalEntry> tab;
   for (size_t b = 0; b < n_batches; ++b) {
     if (batches[b].n_polys && !batches[b].polys) return p2mt::fail(P2MT_EINVAL, "fri_openings: null batch");
@@ -626,18 +691,42 @@ extern "C" int p2mt_fri_openings_dev(const p2mt_fri_oracle* oracles, size_t n_or
       const uint32_t o = batches[b].polys[2 * j], pi = batches[b].polys[2 * j + 1];
       if (o >= n_oracles || !oracles[o].coeffs || pi >= oracles[o].n_polys)
         return p2mt::fail(P2MT_EINVAL, "fri_openings: batch polynomial index out of range");
-      tab.push_back(EvalEntry{oracles[o].coeffs + ((size_t)pi << degree_bits), batches[b].point[0] % gl::P,
-                              batches[b].point[1] % gl::P, 0});
+      tab.push_back(EvalEntry{oracles[o].coeffs + ((size_t)pi << degree_bits), pts.d_point[b], pts.scale[b] % gl::P, 0});
     }
   }
   if (tab.empty()) return P2MT_OK;
   EvalEntry* d_tab;
-  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchTmp, tab.size() * sizeof(EvalEntry), (void**)&d_tab));
+  P2MT_TRY(p2mt::scratch_get_shared(p2mt::kScratchTables, tab.size() * sizeof(EvalEntry), (void**)&d_tab));
   hipStream_t st = rt().stream;
-  P2MT_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(EvalEntry), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_eval_ext_table, dim3((unsigned)tab.size()), dim3(kBlock), 0, st, (const EvalEntry*)d_tab, degree_bits, d_out);
+  {  // the table is the same for every proof of a circuit (the points are device values): upload it only when it changed
+    thread_local std::vector<u64> last;
+    thread_local const EvalEntry* last_dst = nullptr;
+    thread_local uint64_t last_epoch = ~0ull;
+    const u64* words = reinterpret_cast<const u64*>(tab.data());
+    const size_t n_words = tab.size() * sizeof(EvalEntry) / 8;
+    if (last_dst != d_tab || last_epoch != p2mt::scratch_epoch() || last.size() != n_words ||
+        memcmp(last.data(), words, n_words * 8) != 0) {
+      P2MT_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(EvalEntry), hipMemcpyHostToDevice, st));
+      P2MT_HIP(hipStreamSynchronize(st));  // `tab` is pageable host memory; rare
+      last.assign(words, words + n_words);
+      last_dst = d_tab;
+      last_epoch = p2mt::scratch_epoch();
+    }
+  }
+  hipLaunchKernelGGL(k_eval_ext_table, bgrid((unsigned)tab.size()), dim3(kBlock), 0, st, (const EvalEntry*)d_tab, degree_bits, d_out,
+                     barg());
   P2MT_LAUNCH_CHECK();
-  P2MT_HIP(hipStreamSynchronize(st));  // `tab` is pageable host memory
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_fri_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
+                                     size_t n_batches, unsigned degree_bits, uint64_t* d_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!oracles || !batches || !d_out || n_oracles == 0 || degree_bits > 24) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
+  p2mt::FriPointsDev pts{};
+  P2MT_TRY(upload_points(batches, n_batches, &pts));
+  P2MT_TRY(p2mt::fri_openings_points_dev(oracles, n_oracles, batches, n_batches, pts, degree_bits, d_out));
+  P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
 }
 
@@ -703,16 +792,23 @@ extern "C" size_t p2mt_fri_proof_len(const p2mt_fri_params* p, size_t n_oracles,
 extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                            size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch,
                                            uint64_t* d_proof) {
-  return p2mt::fri_prove_openings_epilogue_dev(oracles, n_oracles, batches, n_batches, p, ch, d_proof, nullptr, nullptr, 0);
+  P2MT_TRY(p2mt::ensure_init());
+  if (!batches || n_batches == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
+  p2mt::FriPointsDev pts{};
+  P2MT_TRY(upload_points(batches, n_batches, &pts));
+  return p2mt::fri_prove_openings_epilogue_dev(oracles, n_oracles, batches, n_batches, pts, p, ch, d_proof, nullptr, nullptr, 0, 0);
 }
 
-// The same with a device-to-host copy enqueued behind the speculative tail of the proof, in front of the synchronisation
-// that reads the proof-of-work result: the caller's proof comes back with that one wait (dst is valid when this returns 0).
+// The same with the opening points as device values and a device-to-host copy enqueued behind the speculative tail of the
+// proof, in front of the synchronisation that reads the proof-of-work result: the caller's proof comes back with that one wait
+// (dst is valid when this returns 0).
 int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
-                                          size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch, uint64_t* d_proof,
-                                          void* epi_dst, const void* epi_src, size_t epi_bytes) {
+                                          size_t n_batches, const FriPointsDev& pts, const p2mt_fri_params* p,
+                                          p2mt_challenger* ch, uint64_t* d_proof, void* epi_dst, const void* epi_src,
+                                          size_t epi_bytes, size_t epi_dpitch) {
   P2MT_TRY(p2mt::ensure_init());
   if (!oracles || !batches || !ch || !d_proof || n_oracles == 0 || n_batches == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
+  if (n_batches > (size_t)kMaxFriBatches) return p2mt::fail(P2MT_EINVAL, "fri: too many batches");
   if (!params_ok(p)) return p2mt::fail(P2MT_EINVAL, "fri: unsupported FriParams (degree_bits <= 12, arity_bits in 1..4, layer trees >= cap)");
   if (n_oracles + p->num_reductions > (size_t)kMaxQTrees) return p2mt::fail(P2MT_EINVAL, "fri: too many oracles");
   const unsigned log_n = p->degree_bits, log_big = log_n + p->rate_bits;
@@ -746,7 +842,7 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     return at;
   };
   const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds), o_chsave = carve(32);
-  const size_t o_apow = carve(2 * (max_cnt + 1)), o_ptrs = carve(total_cnt), o_partial = carve(max_groups * 2 * n);
+  const size_t o_apow = carve(2 * (max_cnt + 1)), o_partial = carve(max_groups * 2 * n);
   const size_t o_fin = carve(2 * (size_t)n), o_c0 = carve(2 * (size_t)n), o_c1 = carve(2 * (size_t)n);
   size_t o_vals[8], o_leaves[8], o_dig[8];
   {
@@ -761,12 +857,15 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
   }
   u64* ws;
   P2MT_TRY(p2mt::scratch_get(p2mt::kScratchFri, wsz * 8, (void**)&ws));
+  u64* d_ptrs;  // the table of coefficient pointers is shared by the proofs of a batch (k_fri_compose rebases its entries)
+  P2MT_TRY(p2mt::scratch_get_shared(p2mt::kScratchPtrs, total_cnt * 8, (void**)&d_ptrs));
   hipStream_t st = rt().stream;
+  const unsigned B = p2mt::batch_B();
 
   // ---- alpha, composition, quotients
   P2MT_TRY(launch_challenger(ch->d, nullptr, 0, ws + o_alpha, 2));
-  hipLaunchKernelGGL(k_ext_powers, dim3(grid_for(max_cnt + 1)), dim3(kBlock), 0, st, (const u64*)(ws + o_alpha),
-                     (u32)max_cnt + 1, ws + o_apow);
+  hipLaunchKernelGGL(k_ext_powers, bgrid(grid_for(max_cnt + 1)), dim3(kBlock), 0, st, (const u64*)(ws + o_alpha),
+                     (u32)max_cnt + 1, ws + o_apow, barg());
   P2MT_LAUNCH_CHECK();
   std::vector<const u64*> h_ptrs(total_cnt);
   {
@@ -779,11 +878,11 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     thread_local std::vector<const u64*> last_ptrs;
     thread_local const u64* last_dst = nullptr;
     thread_local uint64_t last_epoch = ~0ull;
-    if (last_dst != ws + o_ptrs || last_epoch != p2mt::scratch_epoch() || last_ptrs != h_ptrs) {
-      P2MT_HIP(hipMemcpyAsync(ws + o_ptrs, h_ptrs.data(), total_cnt * 8, hipMemcpyHostToDevice, st));
+    if (last_dst != d_ptrs || last_epoch != p2mt::scratch_epoch() || last_ptrs != h_ptrs) {
+      P2MT_HIP(hipMemcpyAsync(d_ptrs, h_ptrs.data(), total_cnt * 8, hipMemcpyHostToDevice, st));
       P2MT_HIP(hipStreamSynchronize(st));  // pageable source; rare
       last_ptrs = h_ptrs;
-      last_dst = ws + o_ptrs;
+      last_dst = d_ptrs;
       last_epoch = p2mt::scratch_epoch();
     }
   }
@@ -791,23 +890,12 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     size_t k = 0;
     for (size_t b = 0; b < n_batches; ++b) {
       const u32 cnt = (u32)batches[b].n_polys, groups = (cnt + kComposeGroup - 1) / kComposeGroup;
-      hipLaunchKernelGGL(k_fri_compose, dim3(grid_for(n), groups), dim3(kBlock), 0, st,
-                         reinterpret_cast<const u64* const*>(ws + o_ptrs + k), cnt, n, (const u64*)(ws + o_apow), ws + o_partial);
+      hipLaunchKernelGGL(k_fri_compose, bgrid(grid_for(n), groups), dim3(kBlock), 0, st,
+                         reinterpret_cast<const u64* const*>(d_ptrs + k), cnt, n, (const u64*)(ws + o_apow), ws + o_partial, barg());
       P2MT_LAUNCH_CHECK();
-      ZPows zpw;
-      {
-        const u32 len = n >= (u32)kQBlock ? n / kQBlock : 1;
-        u64 zp[2] = {1, 0}, zz[2] = {batches[b].point[0] % gl::P, batches[b].point[1] % gl::P};
-        for (u32 i = 0; i < len; ++i) h_ext_mul(zp, zz, zp);
-        for (int kk = 0; kk < 10; ++kk) {
-          zpw.v[2 * kk] = zp[0];
-          zpw.v[2 * kk + 1] = zp[1];
-          h_ext_mul(zp, zp, zp);
-        }
-      }
-      hipLaunchKernelGGL(k_fri_quotient, dim3(1), dim3(kQBlock), 0, st, (const u64*)(ws + o_partial), groups, n,
-                         batches[b].point[0] % gl::P, batches[b].point[1] % gl::P, zpw, (const u64*)(ws + o_apow + 2 * cnt),
-                         b == 0 ? 1 : 0, ws + o_fin, b + 1 == n_batches ? ws + o_c0 : (u64*)nullptr);
+      hipLaunchKernelGGL(k_fri_quotient, bgrid(1), dim3(kQBlock), 0, st, (const u64*)(ws + o_partial), groups, n, pts.d_point[b],
+                         pts.scale[b] % gl::P, (const u64*)(ws + o_apow + 2 * cnt), b == 0 ? 1 : 0, ws + o_fin,
+                         b + 1 == n_batches ? ws + o_c0 : (u64*)nullptr, barg());
       P2MT_LAUNCH_CHECK();
       k += cnt;
     }
@@ -832,12 +920,12 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     u64* dig = nd ? ws + o_dig[l] : nullptr;
     // values on the coset shift * <w>, already in the bit-reversed order the leaves are chunked in
     P2MT_TRY(p2mt::coset_lde_leaf_order_dev(cur, log_deg, p->rate_bits, shift, 2, vals));
-    hipLaunchKernelGGL(k_fri_pairs, dim3(grid_for(sz)), dim3(kBlock), 0, st, (const u64*)vals, (u32)sz, leaves);
+    hipLaunchKernelGGL(k_fri_pairs, bgrid(grid_for(sz)), dim3(kBlock), 0, st, (const u64*)vals, (u32)sz, leaves, barg());
     P2MT_LAUNCH_CHECK();
     P2MT_TRY(p2mt_merkle_cap_commit_dev(leaves, rows, (size_t)2 << ab, p->cap_height, dig, d_proof + l * cap_words));
     P2MT_TRY(launch_challenger(ch->d, d_proof + l * cap_words, cap_words, ws + o_betas + 2 * l, 2));
-    hipLaunchKernelGGL(k_fri_fold, dim3(grid_for((size_t)1 << (log_deg - ab))), dim3(kBlock), 0, st, (const u64*)cur, 1u << log_deg,
-                       ab, (const u64*)(ws + o_betas + 2 * l), nxt);
+    hipLaunchKernelGGL(k_fri_fold, bgrid(grid_for((size_t)1 << (log_deg - ab))), dim3(kBlock), 0, st, (const u64*)cur, 1u << log_deg,
+                       ab, (const u64*)(ws + o_betas + 2 * l), nxt, barg());
     P2MT_LAUNCH_CHECK();
     idx_shift += ab;
     qa.t[qa.n_trees++] = QTree{leaves, dig, (u32)(2u << ab), log_sz - ab, idx_shift, log_sz - ab - p->cap_height};
@@ -847,7 +935,8 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     log_deg -= ab;
   }
   // final polynomial -> proof words, observe
-  hipLaunchKernelGGL(k_fri_pairs, dim3(grid_for(final_len)), dim3(kBlock), 0, st, (const u64*)cur, (u32)final_len, d_proof + off_final);
+  hipLaunchKernelGGL(k_fri_pairs, bgrid(grid_for(final_len)), dim3(kBlock), 0, st, (const u64*)cur, (u32)final_len,
+                     d_proof + off_final, barg());
   P2MT_LAUNCH_CHECK();
   // (the same launch keeps a copy of the transcript for the proof-of-work rollback and marks "no witness yet")
   P2MT_TRY(launch_challenger(ch->d, d_proof + off_final, 2 * final_len, nullptr, 0, false,
@@ -861,24 +950,53 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     ChState* d_saved = reinterpret_cast<ChState*>(ws + o_chsave);
     const u64 chunk = (u64)1 << (p->proof_of_work_bits + 1 < 17 ? 17 : p->proof_of_work_bits + 1);
     qa.per_query = p->num_query_rounds ? (off_final - p->num_reductions * cap_words) / p->num_query_rounds : 0;
+    const bool quad_grind = rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput && B == 1;
+    auto grind = [&](u64 base) -> int {
+      if (quad_grind) {
+        hipLaunchKernelGGL(k_fri_pow_quad, bgrid(grid_for(4 * chunk)), dim3(kBlock), 0, st, (const ChState*)ch->d,
+                           (u32)p->proof_of_work_bits, base, chunk, d_wit, barg(), p2mt::perm_ctx());
+        P2MT_LAUNCH_CHECK();
+      } else {
+        P2MT_DISPATCH(k_fri_pow, bgrid(grid_for(chunk)), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit,
+                      barg());
+      }
+      return P2MT_OK;
+    };
+    auto tail = [&]() -> int {  // observe the witness; pow_response + one challenge per query round; the query rounds
+      P2MT_TRY(launch_challenger(ch->d, d_proof + total - 1, 1, ws + o_qch, 1 + p->num_query_rounds));
+      if (p->num_query_rounds) {
+        hipLaunchKernelGGL(k_fri_queries, bgrid(p->num_query_rounds), dim3(kBlock), 0, st, qa, (const u64*)(ws + o_qch + 1),
+                           d_proof + p->num_reductions * cap_words, barg());
+        P2MT_LAUNCH_CHECK();
+      }
+      return P2MT_OK;
+    };
+    if (B > 1) {
+      // A batch grinds chunk after chunk until every proof has its witness (a chunk skips the proofs that already have one, and
+      // keeps the smallest witness like the single-proof search), then finishes all the proofs with one tail.
+      std::vector<unsigned long long> found(B);
+      for (u64 base = 0;; base += chunk) {
+        if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
+        P2MT_TRY(grind(base));
+        P2MT_HIP(hipMemcpy2DAsync(found.data(), 8, d_wit, p2mt::batch().arg.stride, 8, B, hipMemcpyDeviceToHost, st));
+        P2MT_HIP(hipStreamSynchronize(st));
+        bool all = true;
+        for (unsigned i = 0; i < B; ++i) all = all && found[i] != ~0ull;
+        if (all) break;
+      }
+      P2MT_TRY(tail());
+      if (epi_dst && epi_bytes)
+        P2MT_HIP(hipMemcpy2DAsync(epi_dst, epi_dpitch, epi_src, p2mt::batch().arg.stride, epi_bytes, B, hipMemcpyDeviceToHost, st));
+      P2MT_HIP(hipStreamSynchronize(st));
+      return P2MT_OK;
+    }
+    (void)d_saved;
     unsigned long long found = ~0ull;
     for (u64 base = 0;; base += chunk) {
       if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
       if (base != 0) P2MT_HIP(hipMemsetAsync(d_wit, 0xFF, 8, st));  // first chunk: marked by the launch above
-      if (rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput) {
-        hipLaunchKernelGGL(k_fri_pow_quad, dim3(grid_for(4 * chunk)), dim3(kBlock), 0, st, (const ChState*)ch->d,
-                           (u32)p->proof_of_work_bits, base, chunk, d_wit, p2mt::perm_ctx());
-        P2MT_LAUNCH_CHECK();
-      } else {
-        P2MT_DISPATCH(k_fri_pow, grid_for(chunk), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit);
-      }
-      // observe the witness; pow_response + one challenge per query round
-      P2MT_TRY(launch_challenger(ch->d, d_proof + total - 1, 1, ws + o_qch, 1 + p->num_query_rounds));
-      if (p->num_query_rounds) {
-        hipLaunchKernelGGL(k_fri_queries, dim3(p->num_query_rounds), dim3(kBlock), 0, st, qa, (const u64*)(ws + o_qch + 1),
-                           d_proof + p->num_reductions * cap_words);
-        P2MT_LAUNCH_CHECK();
-      }
+      P2MT_TRY(grind(base));
+      P2MT_TRY(tail());
       P2MT_HIP(hipMemcpyAsync(&found, d_wit, 8, hipMemcpyDeviceToHost, st));
       if (epi_dst && epi_bytes) P2MT_HIP(hipMemcpyAsync(epi_dst, epi_src, epi_bytes, hipMemcpyDeviceToHost, st));
       P2MT_HIP(hipStreamSynchronize(st));

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restri
 
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
-                                                      u64* __restrict__ out, PermCtx ctx) {
+                                                      u64* __restrict__ out, BatchArg ba, PermCtx ctx) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   u64 o[4];
@@ -64,7 +66,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in
 // the sponge's permutations are sequential, so a row costs len/8 wave-permutation latencies (~8 us each) instead of
 // len/8 single-lane ones (~60 us each).
 __global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
-                                                           u64* __restrict__ out, PermCtx ctx) {
+                                                           u64* __restrict__ out, BatchArg ba, PermCtx ctx) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   const size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -142,7 +146,9 @@ __global__ __launch_bounds__(kBlock) void k_leaf_digests(const u64* __restrict__
 // next_level_hashes (:21-25): out[j] = two_to_one(in[2j], in[2j+1])
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
-                                                         PermCtx ctx) {
+                                                         BatchArg ba, PermCtx ctx) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (j >= n_out) return;
   u64 o[4];
@@ -190,7 +196,9 @@ __global__ __launch_bounds__(kBlock) void k_verify_merkle_proof(const u64* __res
 
 // level-major tree level: out[j] = two_to_one(in[2j], in[2j+1])
 __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
-                                                              PermCtx ctx) {
+                                                              BatchArg ba, PermCtx ctx) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   const size_t j = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -199,7 +207,9 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restr
 }
 
 __global__ __launch_bounds__(kBlock) void k_merkle_level_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
-                                                              PermCtx ctx) {
+                                                              BatchArg ba, PermCtx ctx) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   const size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 2;
   if (j >= n_out) return;  // quad-uniform
   poseidon_quad::Lane ln;
@@ -216,32 +226,34 @@ namespace p2mt {
 // exported to the other translation units
 int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, u64* d_out) {
   if (n == 0) return P2MT_OK;
-  if (n <= ((size_t)1 << 12) && rt().mds == 2) {  // small batch: one wavefront per row (latency path)
+  // (inside a batch of B proofs the layout is chosen for all n B rows of the launch)
+  if (n * p2mt::batch_B() <= ((size_t)1 << 12) && rt().mds == 2) {  // small batch: one wavefront per row (latency path)
     const unsigned per_block = kBlock / 64;
-    hipLaunchKernelGGL(k_hash_rows_wave, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
-                       d_in, n, len, noop_short, d_out, p2mt::perm_ctx());
+    hipLaunchKernelGGL(k_hash_rows_wave, bgrid((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
+                       d_in, n, len, noop_short, d_out, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
-  P2MT_DISPATCH(k_hash_rows, grid_for(n), kBlock, d_in, n, len, noop_short, d_out);
+  P2MT_DISPATCH(k_hash_rows, bgrid(grid_for(n)), kBlock, d_in, n, len, noop_short, d_out, barg());
   return P2MT_OK;
 }
 int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
   if (n_out == 0) return P2MT_OK;
-  if (n_out <= ((size_t)1 << 12) && rt().mds == 2 && !(rt().throughput && n_out > 16)) {  // small level: one wavefront per node (latency path)
+  const size_t n_all = n_out * p2mt::batch_B();
+  if (n_all <= ((size_t)1 << 12) && rt().mds == 2 && !(rt().throughput && n_all > 16)) {  // small level: one wavefront per node (latency path)
     const unsigned per_block = kBlock / 64;
-    hipLaunchKernelGGL(k_merkle_level_wave, dim3((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
-                       rt().stream, d_in, d_out, n_out, p2mt::perm_ctx());
+    hipLaunchKernelGGL(k_merkle_level_wave, bgrid((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
+                       rt().stream, d_in, d_out, n_out, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
-  if (n_out <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
-    hipLaunchKernelGGL(k_merkle_level_quad, dim3(grid_for(4 * n_out)), dim3(kBlock), 0, rt().stream, d_in, d_out, n_out,
-                       p2mt::perm_ctx());
+  if (n_all <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
+    hipLaunchKernelGGL(k_merkle_level_quad, bgrid(grid_for(4 * n_out)), dim3(kBlock), 0, rt().stream, d_in, d_out, n_out,
+                       barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
-  P2MT_DISPATCH(k_merkle_level, grid_for(n_out), kBlock, d_in, d_out, n_out);
+  P2MT_DISPATCH(k_merkle_level, bgrid(grid_for(n_out)), kBlock, d_in, d_out, n_out, barg());
   return P2MT_OK;
 }
 

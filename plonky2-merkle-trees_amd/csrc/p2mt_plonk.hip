@@ -44,8 +44,15 @@ GL_DEV u64 gl_inv(u64 x) {
 __global__ __launch_bounds__(kBlock) void k_pp_chunks(const u64* __restrict__ wires, const u64* __restrict__ sigmas,
                                                       const u64* __restrict__ k_is, const u64* __restrict__ betas,
                                                       const u64* __restrict__ gammas, u32 num_routed, u32 log_n, u32 chunk,
-                                                      u32 num_chunks, u64 w, u64* __restrict__ q, int* __restrict__ zero_den) {
-  const u32 n = 1u << log_n, i = blockIdx.x * kBlock + threadIdx.x, k = blockIdx.y, c = blockIdx.z;
+                                                      u32 num_chunks, u64 w, u64* __restrict__ q, int* __restrict__ zero_den, BatchArg ba) {
+  wires = bp(wires, ba);
+  sigmas = bp(sigmas, ba);
+  k_is = bp(k_is, ba);
+  betas = bp(betas, ba);
+  gammas = bp(gammas, ba);
+  q = bp(q, ba);
+  zero_den = bp(zero_den, ba);
+  const u32 n = 1u << log_n, i = blockIdx.x * kBlock + threadIdx.x, k = blockIdx.y % num_chunks, c = blockIdx.y / num_chunks;
   if (i >= n) return;
   const u64 beta = betas[c], gamma = gammas[c];
   const u64 bx = gl::mul(beta, gl::pow(w, i));  // beta * x_i
@@ -64,7 +71,9 @@ __global__ __launch_bounds__(kBlock) void k_pp_chunks(const u64* __restrict__ wi
 // One workgroup per challenge: Z (exclusive running product of the row totals) and the partial products.
 constexpr int kScanBlock = 1024;
 __global__ __launch_bounds__(kScanBlock) void k_pp_scan(const u64* __restrict__ q, u32 log_n, u32 num_chunks, u32 num_challenges,
-                                                        u64* __restrict__ out) {
+                                                        u64* __restrict__ out, BatchArg ba) {
+  q = bp(q, ba);
+  out = bp(out, ba);
   __shared__ u64 S[kScanBlock];
   const u32 n = 1u << log_n, c = blockIdx.x, t = threadIdx.x;
   const u32 len = n >= (u32)kScanBlock ? n / kScanBlock : 1, T = n / len;
@@ -116,11 +125,12 @@ int p2mt::partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_
   hipStream_t st = rt().stream;
   u64 w = h_pow(7, (gl::P - 1) >> 32);  // primitive 2^degree_bits-th root of unity
   for (unsigned i = degree_bits; i < 32; ++i) w = h_mul(w, w);
-  hipLaunchKernelGGL(k_pp_chunks, dim3(grid_for(n), (unsigned)num_chunks, (unsigned)num_challenges), dim3(kBlock), 0, st, d_wires,
-                     d_sigmas, d_k_is, d_betas, d_gammas, (u32)num_routed, degree_bits, chunk, (u32)num_chunks, w, d_q, d_zero_den);
+  hipLaunchKernelGGL(k_pp_chunks, bgrid(grid_for(n), (unsigned)(num_chunks * num_challenges)), dim3(kBlock), 0, st, d_wires,
+                     d_sigmas, d_k_is, d_betas, d_gammas, (u32)num_routed, degree_bits, chunk, (u32)num_chunks, w, d_q, d_zero_den,
+                     barg());
   P2MT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_pp_scan, dim3((unsigned)num_challenges), dim3(kScanBlock), 0, st, (const u64*)d_q, degree_bits,
-                     (u32)num_chunks, (u32)num_challenges, d_out);
+  hipLaunchKernelGGL(k_pp_scan, bgrid((unsigned)num_challenges), dim3(kScanBlock), 0, st, (const u64*)d_q, degree_bits,
+                     (u32)num_chunks, (u32)num_challenges, d_out, barg());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }

@@ -60,8 +60,37 @@ inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ul
 
 // Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
-enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCircuit, kScratchCount };
+enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCircuit, kScratchTables, kScratchPtrs, kScratchPoints, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
+// the same, but never from a batch's per-proof arena: tables the host uploads once for all the proofs of a batch
+int scratch_get_shared(int slot, size_t bytes, void** out);
+// largest request per slot since the last scratch_track_reset() of this thread (sizes the batched prover's per-proof arena)
+void scratch_track_reset();
+size_t scratch_track_max(int slot);
+
+// Batched pipelines (p2mt_batch_prover): B independent proofs ride in grid dimension z of every launch.  Each proof owns one
+// block of `stride` bytes; the host enqueues the pipeline ONCE with the pointers of block 0, and a kernel moves every pointer that
+// lies inside block 0 (base <= p < base + span) to its own block (device helper bp() in tree_common.hip.h).  Pointers outside
+// block 0 (circuit constants, twiddles, round constants) are shared by all proofs.  B = 1 / span = 0 outside a batch: bp() is
+// the identity.  Per host thread, like the stream and the scratch.
+struct BatchArg {
+  uint64_t base, span, stride;  // bytes
+};
+struct BatchCtx {
+  unsigned B = 1;
+  BatchArg arg{0, 0, 0};
+  // scratch_get() inside a batch is served from block 0's arena
+  char* arena = nullptr;
+  size_t slot_off[kScratchCount] = {}, slot_cap[kScratchCount] = {};
+};
+BatchCtx& batch();
+inline unsigned batch_B() { return batch().B; }
+// copy [p, p + bytes) of block 0 into every other block (tables the host uploaded once); no-op outside a batch
+int batch_broadcast(void* p, size_t bytes);
+// device-to-device copy / fill on the library stream that follows the batch: every proof's block when dst / src are per-proof
+// buffers (bytes a multiple of 8), one plain hipMemcpyAsync / hipMemsetAsync outside a batch
+int batch_copy(void* dst, const void* src, size_t bytes);
+int batch_fill(void* dst, int byte_value, size_t bytes);
 uint64_t scratch_epoch();  // changes whenever this thread's scratch buffers were (re)allocated or freed: content caches key on it
 void scratch_release_thread();  // frees the calling thread's scratch (threads that end must call it)
 
@@ -118,10 +147,24 @@ int partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_sigmas
                                const uint64_t* d_betas, const uint64_t* d_gammas, size_t num_challenges, size_t num_routed,
                                unsigned degree_bits, unsigned chunk, uint64_t* d_q_scratch, uint64_t* d_out, int* d_zero_den);
 
-// exported by p2mt_fri.hip: p2mt_fri_prove_openings_dev + one device-to-host copy that rides on its final synchronisation
+// exported by p2mt_fri.hip: the opening points of the FRI batches as device values, point b = d_point[b][0..2) * scale[b]
+// (p2mt_fri_batch::point is ignored by the functions that take this)
+constexpr int kMaxFriBatches = 4;
+struct FriPointsDev {
+  const uint64_t* d_point[kMaxFriBatches];
+  uint64_t scale[kMaxFriBatches];
+};
+int fri_openings_points_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches, size_t n_batches,
+                            const FriPointsDev& pts, unsigned degree_bits, uint64_t* d_out);
+// p2mt_fri_prove_openings_dev + one device-to-host copy that rides on its final synchronisation.  Inside a batch (runtime.h
+// BatchCtx) epi_dst / epi_src are per-proof with the pitches epi_dpitch (host) and the batch stride (device).
 int fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
-                                    size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch, uint64_t* d_proof,
-                                    void* epi_dst, const void* epi_src, size_t epi_bytes);
+                                    size_t n_batches, const FriPointsDev& pts, const p2mt_fri_params* p, p2mt_challenger* ch,
+                                    uint64_t* d_proof, void* epi_dst, const void* epi_src, size_t epi_bytes, size_t epi_dpitch);
+// a challenger over caller-owned device state (the batched prover keeps one state per proof block)
+int challenger_wrap(void* d_state, p2mt_challenger** out);
+void challenger_unwrap(p2mt_challenger* c);
+constexpr size_t kChallengerStateBytes = 8 * (12 + 8 + 8) + 8;
 // exported by p2mt_verify_host.hip: the field arithmetic of CircuitData::verify (the hashing runs on the device)
 struct VerifyDesc {
   uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, n_kinds;

@@ -64,10 +64,80 @@ thread_local ScratchHolder tl_scratch_holder;
 
 uint64_t scratch_epoch() { return tl_scratch_epoch; }
 
-int scratch_get(int slot, size_t bytes, void** out) {
+namespace {
+thread_local size_t tl_scratch_req[kScratchCount] = {};
+thread_local BatchCtx tl_batch;
+__global__ __launch_bounds__(256) void k_batch_broadcast(uint64_t* p, size_t words, size_t stride_words) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < words) p[(size_t)(blockIdx.z + 1) * stride_words + i] = p[i];
+}
+__device__ __forceinline__ uint64_t* rebase(uint64_t* p, const BatchArg& ba) {
+  return ((uint64_t)p - ba.base) < ba.span ? reinterpret_cast<uint64_t*>((uint64_t)p + (uint64_t)blockIdx.z * ba.stride) : p;
+}
+__global__ __launch_bounds__(256) void k_batch_copy(uint64_t* dst, const uint64_t* src, size_t words, BatchArg ba) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < words) rebase(dst, ba)[i] = rebase(const_cast<uint64_t*>(src), ba)[i];
+}
+__global__ __launch_bounds__(256) void k_batch_fill(uint64_t* dst, uint64_t v, size_t words, BatchArg ba) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < words) rebase(dst, ba)[i] = v;
+}
+}  // namespace
+int batch_copy(void* dst, const void* src, size_t bytes) {
+  const BatchCtx& b = tl_batch;
+  if (b.B <= 1) {
+    P2MT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt().stream));
+    return P2MT_OK;
+  }
+  if (bytes & 7) return fail(P2MT_EINVAL, "batch_copy: size not a multiple of 8");
+  hipLaunchKernelGGL(k_batch_copy, dim3((unsigned)((bytes / 8 + 255) / 256), 1, b.B), dim3(256), 0, rt().stream, (uint64_t*)dst,
+                     (const uint64_t*)src, bytes / 8, b.arg);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+int batch_fill(void* dst, int byte_value, size_t bytes) {
+  const BatchCtx& b = tl_batch;
+  if (b.B <= 1) {
+    P2MT_HIP(hipMemsetAsync(dst, byte_value, bytes, rt().stream));
+    return P2MT_OK;
+  }
+  if (bytes & 7) return fail(P2MT_EINVAL, "batch_fill: size not a multiple of 8");
+  hipLaunchKernelGGL(k_batch_fill, dim3((unsigned)((bytes / 8 + 255) / 256), 1, b.B), dim3(256), 0, rt().stream, (uint64_t*)dst,
+                     0x0101010101010101ull * (uint64_t)(byte_value & 0xFF), bytes / 8, b.arg);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+void scratch_track_reset() {
+  for (int k = 0; k < kScratchCount; ++k) tl_scratch_req[k] = 0;
+}
+size_t scratch_track_max(int slot) { return tl_scratch_req[slot]; }
+BatchCtx& batch() { return tl_batch; }
+
+int batch_broadcast(void* p, size_t bytes) {
+  const BatchCtx& b = tl_batch;
+  if (b.B <= 1 || bytes == 0) return P2MT_OK;
+  if ((uint64_t)p - b.arg.base >= b.arg.span || (bytes & 7) || ((uint64_t)p & 7)) return fail(P2MT_EINVAL, "batch_broadcast: not a per-proof buffer");
+  const size_t words = bytes / 8;
+  hipLaunchKernelGGL(k_batch_broadcast, dim3((unsigned)((words + 255) / 256), 1, b.B - 1), dim3(256), 0, rt().stream, (uint64_t*)p,
+                     words, (size_t)(b.arg.stride / 8));
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
+static int scratch_get_impl(int slot, size_t bytes, void** out, bool shared);
+int scratch_get(int slot, size_t bytes, void** out) { return scratch_get_impl(slot, bytes, out, false); }
+int scratch_get_shared(int slot, size_t bytes, void** out) { return scratch_get_impl(slot, bytes, out, true); }
+
+static int scratch_get_impl(int slot, size_t bytes, void** out, bool shared) {
   void** ptr = tl_scratch_ptr;
   size_t* cap = tl_scratch_cap;
   if (bytes == 0) bytes = 8;
+  if (!shared && bytes > tl_scratch_req[slot]) tl_scratch_req[slot] = bytes;
+  if (tl_batch.arena && !shared) {  // inside a batch: block 0's arena, sized from a tracked single-proof run
+    if (bytes > tl_batch.slot_cap[slot]) return fail(P2MT_EINVAL, "batch: scratch request exceeds the per-proof arena");
+    *out = tl_batch.arena + tl_batch.slot_off[slot];
+    return P2MT_OK;
+  }
   if (bytes > cap[slot]) {
     if (ptr[slot]) {
       (void)hipStreamSynchronize(rt().stream);  // earlier kernels may still read the old buffer

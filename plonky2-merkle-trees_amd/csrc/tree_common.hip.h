@@ -9,8 +9,15 @@ namespace p2mt_dev {
 using gl::u32;
 using gl::u64;
 using p2mt::PermCtx;
+using p2mt::BatchArg;
 
 constexpr int kBlock = 256;
+
+// batched pipelines (runtime.h BatchCtx): a pointer into block 0 moves to the block of this workgroup's proof (grid z)
+template <typename T>
+GL_DEV T* bp(T* p, const BatchArg& ba) {
+  return ((uint64_t)p - ba.base) < ba.span ? reinterpret_cast<T*>((uint64_t)p + (uint64_t)blockIdx.z * ba.stride) : p;
+}
 
 GL_DEV void load_hash(const u64* p, u64 (&h)[4]) {
   const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
@@ -222,5 +229,8 @@ GL_DEV void two_to_one_quad(const u64* __restrict__ lp, const u64* __restrict__ 
 
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// grid with the proofs of a batch in z
+inline dim3 bgrid(unsigned x, unsigned y = 1) { return dim3(x, y, p2mt::batch().B); }
+inline BatchArg barg() { return p2mt::batch().arg; }
 
 }  // namespace p2mt_dev

@@ -1,0 +1,116 @@
+"""The batched prover (p2mt_batch_prover_*): B proofs of one mmr_plonky2_verifier circuit per pass of the prover pipeline, the proof
+index riding in a grid dimension of every launch.  The bar is the same as for prove itself: every proof's words equal the
+sequential `circuit_data.prove(pw)` bit for bit (which test_circuit_gpu.py pins against the CPU restatement), and verify accepts."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from circuit_cases import P, assign, synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = ge.load_package()
+    p.init(0)
+    return p
+
+
+def circuit_and_witnesses(pkg, oracle, n_sib, seeds):
+    cd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(n_sib, 1)
+    cases = [synthetic_case(oracle, n_sib, s) for s in seeds]
+    pws = []
+    for case in cases:
+        pw = pkg.PartialWitness()
+        assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, case, pw.set_target)
+        pws.append(pw)
+    return cd, (leaf_t, proof_ts, peak_ts), cases, pws
+
+
+@pytest.mark.parametrize("batch", [1, 4, 32])
+def test_batch_equals_sequential(pkg, oracle, batch):
+    """24 different statements (config 3's shape: 20 path elements, one peak) in passes of `batch` (the last pass is ragged for 32):
+    same words as 24 sequential proves; with 24 proofs some need a second proof-of-work chunk (13 % each), so the batch's
+    chunk loop runs more than once."""
+    cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, range(500, 524))
+    want = [cd.prove(pw) for pw in pws]
+    bp = pkg.BatchProver(cd, batch)
+    assert bp.batch == batch
+    got = bp.prove(pws)
+    assert got.shape == (len(pws), cd.info.proof_len)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert all(cd.verify(g) for g in got[:4])
+    # the circuit handle is its own again afterwards: a plain prove, then another batch
+    assert np.array_equal(cd.prove(pws[3]), want[3])
+    again = bp.prove(pws[5:11])
+    for g, w in zip(again, want[5:11]):
+        assert np.array_equal(g, w)
+
+
+def test_batch_layouts_agree(pkg, oracle):
+    """Throughput mode switches the leaf sponges / Merkle levels to the lane-per-hash layouts; the words do not change."""
+    cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, range(540, 548))
+    want = [cd.prove(pw) for pw in pws]
+    bp = pkg.BatchProver(cd, 8)
+    lib = pkg.lib()
+    try:
+        pkg._native.check(lib.p2mt_set_throughput_mode(1))
+        got = bp.prove(pws)
+    finally:
+        pkg._native.check(lib.p2mt_set_throughput_mode(0))
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_batch_larger_circuit(pkg, oracle):
+    """200 path elements: 512 rows (degree_bits 9), the largest circuit whose witness table still fits LDS."""
+    cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 200, range(560, 565))
+    assert cd.info.degree_bits == 9
+    want = [cd.prove(pw) for pw in pws]
+    got = pkg.BatchProver(cd, 3).prove(pws)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert cd.verify(got[4])
+
+
+def test_batch_reports_a_contradicting_witness(pkg, oracle):
+    """A witness with a wrong side bit (the recomputed peak differs): plonky2 panics in generate_partial_witness; here that proof's
+    status says so and the other proofs of the pass are unaffected."""
+    cd, (leaf_t, proof_ts, peak_ts), cases, pws = circuit_and_witnesses(pkg, oracle, 20, range(570, 576))
+    want = [cd.prove(pw) for pw in pws]
+    leaf, sib, lefts, peaks, root = cases[2]
+    flipped = lefts.copy()
+    flipped[0] ^= 1
+    bad = pkg.PartialWitness()
+    assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, (leaf, sib, flipped, peaks, root), bad.set_target)
+    with pytest.raises(pkg.P2mtPanic):
+        cd.prove(bad)
+    mixed = list(pws)
+    mixed[2] = bad
+    got, rc, status = pkg.BatchProver(cd, 6).prove(mixed, status=True)
+    assert rc != 0 and status[2] != 0 and [s for i, s in enumerate(status) if i != 2] == [0] * 5
+    for i, (g, w) in enumerate(zip(got, want)):
+        if i != 2:
+            assert np.array_equal(g, w)
+
+
+def test_batch_rejects_what_it_cannot_batch(pkg, oracle):
+    cd, (leaf_t, proof_ts, peak_ts), cases, pws = circuit_and_witnesses(pkg, oracle, 20, range(580, 583))
+    bp = pkg.BatchProver(cd, 4)
+    # witnesses that set their targets in another order
+    other = pkg.PartialWitness()
+    seq = []
+    assign(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs, cases[1], lambda t, v: seq.append((t, v)))
+    for t, v in reversed(seq):
+        other.set_target(t, v)
+    with pytest.raises(pkg.P2mtPanic, match="same targets"):
+        bp.prove([pws[0], other])
+    assert np.array_equal(bp.prove(pws)[1], cd.prove(pws[1]))  # still usable
+    with pytest.raises(pkg.P2mtPanic):
+        pkg.BatchProver(cd, 0)
+    # a circuit whose witness table lives in global memory (1500 path elements, 2^12 rows)
+    big, _, _, _ = pkg.verify_mmr_proof_circuit(1500, 1)
+    with pytest.raises(pkg.P2mtPanic, match="LDS"):
+        pkg.BatchProver(big, 2)
