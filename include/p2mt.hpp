@@ -415,6 +415,33 @@ class CircuitData {  // CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2
   p2mt_circuit_data* h_ = nullptr;
 };
 
+// Batched prover (p2mt_batch_prover_*): up to `batch` proofs of one circuit per pass of the pipeline; each proof equals
+// circuit.prove(pw) word for word.  Borrows the circuit (keep it alive; one thread at a time).
+class BatchProver {
+ public:
+  BatchProver(CircuitData& circuit, std::size_t batch) : circuit_(circuit) { check(p2mt_batch_prover_create(circuit.handle(), batch, &h_)); }
+  ~BatchProver() { p2mt_batch_prover_destroy(h_); }
+  BatchProver(const BatchProver&) = delete;
+  BatchProver& operator=(const BatchProver&) = delete;
+  std::vector<ProofWithPublicInputs> prove(const std::vector<const PartialWitness*>& witnesses) {
+    const std::size_t n = witnesses.size(), len = circuit_.info.proof_len;
+    std::vector<const p2mt_partial_witness*> hs(n);
+    for (std::size_t i = 0; i < n; ++i) hs[i] = witnesses[i]->handle();
+    std::vector<uint64_t> words(n * len);
+    check(p2mt_batch_prover_prove(h_, hs.data(), n, words.data(), len, nullptr));
+    std::vector<ProofWithPublicInputs> out(n);
+    for (std::size_t i = 0; i < n; ++i) {
+      out[i].words.assign(words.begin() + i * len, words.begin() + (i + 1) * len);
+      out[i].public_inputs.assign(out[i].words.end() - circuit_.info.num_public_inputs, out[i].words.end());
+    }
+    return out;
+  }
+
+ private:
+  CircuitData& circuit_;
+  p2mt_batch_prover* h_ = nullptr;
+};
+
 inline void PartialWitness::set_proof_with_pis_target(const ProofWithPublicInputsTarget& target, const ProofWithPublicInputs& proof) {
   if (target.targets.size() != proof.words.size()) throw panic(P2MT_EINVAL, "proof does not match its target");
   check(p2mt_pw_set_proof_with_pis_target(h_, target.targets.data(), proof.words.data(), proof.words.size()));

@@ -22,6 +22,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+
 #include <new>
 #include <vector>
 
@@ -166,14 +168,20 @@ __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, con
 
 // fri_proof_of_work: candidate = base + gid goes where the next observed element would; the response is the first
 // challenge after it (word 7 of the permuted state).  *result = smallest passing candidate (init ~0).
+// interleave != 0 (the grind of a batch): grid = (proofs, candidate blocks) so that the dispatcher walks the proofs in the fast
+// dimension and the candidates in the slow one -- a workgroup whose candidates all lie above a witness that is already known
+// exits at once, so a proof costs about the 2^pow_bits candidates up to its first hit plus the ~8 k that are in flight, not a
+// whole chunk (the smallest witness still wins: only larger candidates are skipped).
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ st, u32 pow_bits, u64 base, u64 count,
-                                                    unsigned long long* __restrict__ result, BatchArg ba, PermCtx ctx) {
-  st = bp(st, ba);
-  result = bp(result, ba);
-  const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+                                                    unsigned long long* __restrict__ result, u32 interleave, BatchArg ba,
+                                                    PermCtx ctx) {
+  const unsigned proof = interleave ? blockIdx.x : blockIdx.z, blk = interleave ? blockIdx.y : blockIdx.x;
+  st = bp_at(st, ba, proof);
+  result = bp_at(result, ba, proof);
+  const u64 gid = (u64)blk * kBlock + threadIdx.x;
   if (gid >= count) return;
-  if (*result < base) return;  // (batched grind) an earlier chunk already found this proof's witness
+  if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + (u64)blk * kBlock) return;
   const u64 cand = base + gid;
   const u32 n_in = st->n_in;  // < 8: a full buffer is duplexed at once
   u64 s[12];
@@ -951,14 +959,20 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     const u64 chunk = (u64)1 << (p->proof_of_work_bits + 1 < 17 ? 17 : p->proof_of_work_bits + 1);
     qa.per_query = p->num_query_rounds ? (off_final - p->num_reductions * cap_words) / p->num_query_rounds : 0;
     const bool quad_grind = rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput && B == 1;
+    const u64 batch_chunk = std::max<u64>(chunk, (u64)1 << (p->proof_of_work_bits + 4 < 32 ? p->proof_of_work_bits + 4 : 32));
     auto grind = [&](u64 base) -> int {
+      if (B > 1) {  // proofs in grid x, candidate blocks in grid y (early exit per workgroup, see k_fri_pow)
+        P2MT_DISPATCH(k_fri_pow, dim3(B, grid_for(batch_chunk), 1), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base,
+                      batch_chunk, d_wit, 1u, barg());
+        return P2MT_OK;
+      }
       if (quad_grind) {
         hipLaunchKernelGGL(k_fri_pow_quad, bgrid(grid_for(4 * chunk)), dim3(kBlock), 0, st, (const ChState*)ch->d,
                            (u32)p->proof_of_work_bits, base, chunk, d_wit, barg(), p2mt::perm_ctx());
         P2MT_LAUNCH_CHECK();
       } else {
         P2MT_DISPATCH(k_fri_pow, bgrid(grid_for(chunk)), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit,
-                      barg());
+                      0u, barg());
       }
       return P2MT_OK;
     };
@@ -972,10 +986,11 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
       return P2MT_OK;
     };
     if (B > 1) {
-      // A batch grinds chunk after chunk until every proof has its witness (a chunk skips the proofs that already have one, and
-      // keeps the smallest witness like the single-proof search), then finishes all the proofs with one tail.
+      // A batch grinds chunk after chunk (2^(pow_bits + 4) candidates: one chunk almost always) until every proof has its witness
+      // -- a chunk skips what lies above a witness that is already known, and keeps the smallest one like the single-proof
+      // search --, then finishes all the proofs with one tail.
       std::vector<unsigned long long> found(B);
-      for (u64 base = 0;; base += chunk) {
+      for (u64 base = 0;; base += batch_chunk) {
         if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
         P2MT_TRY(grind(base));
         P2MT_HIP(hipMemcpy2DAsync(found.data(), 8, d_wit, p2mt::batch().arg.stride, 8, B, hipMemcpyDeviceToHost, st));

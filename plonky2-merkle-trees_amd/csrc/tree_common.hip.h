@@ -15,8 +15,12 @@ constexpr int kBlock = 256;
 
 // batched pipelines (runtime.h BatchCtx): a pointer into block 0 moves to the block of this workgroup's proof (grid z)
 template <typename T>
+GL_DEV T* bp_at(T* p, const BatchArg& ba, unsigned proof) {
+  return ((uint64_t)p - ba.base) < ba.span ? reinterpret_cast<T*>((uint64_t)p + (uint64_t)proof * ba.stride) : p;
+}
+template <typename T>
 GL_DEV T* bp(T* p, const BatchArg& ba) {
-  return ((uint64_t)p - ba.base) < ba.span ? reinterpret_cast<T*>((uint64_t)p + (uint64_t)blockIdx.z * ba.stride) : p;
+  return bp_at(p, ba, blockIdx.z);
 }
 
 GL_DEV void load_hash(const u64* p, u64 (&h)[4]) {

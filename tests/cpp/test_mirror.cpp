@@ -228,6 +228,12 @@ static void test_inner_merkle_proof_3leaves() {
   c.data.verify(proof);
   for (std::size_t i = 0; i < pr.peaks.size(); ++i)
     for (int k = 0; k < 4; ++k) REQUIRE(proof.public_inputs[4 * i + k] == pr.peaks[i].elements[k]);
+  // the batched prover: three copies of the statement in passes of two -> the same words as prove
+  BatchProver batch(c.data, 2);
+  const std::vector<ProofWithPublicInputs> many = batch.prove({&pw, &pw, &pw});
+  REQUIRE(many.size() == 3);
+  for (const auto& p : many) REQUIRE(p.words == proof.words);
+  REQUIRE(c.data.prove(pw).words == proof.words);  // the circuit handle is its own again
 }
 
 // mmr_plonky2_verifier_1_recursion.rs:152-221 test_complete_verification_circuit_with_inner_proof, leaves (1..7), leaf index 5

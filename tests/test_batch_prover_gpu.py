@@ -31,8 +31,7 @@ def circuit_and_witnesses(pkg, oracle, n_sib, seeds):
 @pytest.mark.parametrize("batch", [1, 4, 32])
 def test_batch_equals_sequential(pkg, oracle, batch):
     """24 different statements (config 3's shape: 20 path elements, one peak) in passes of `batch` (the last pass is ragged for 32):
-    same words as 24 sequential proves; with 24 proofs some need a second proof-of-work chunk (13 % each), so the batch's
-    chunk loop runs more than once."""
+    same words as 24 sequential proves (each with the smallest proof-of-work witness, which the batch's early-exit grind must keep)."""
     cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, range(500, 524))
     want = [cd.prove(pw) for pw in pws]
     bp = pkg.BatchProver(cd, batch)
