@@ -168,20 +168,13 @@ __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, con
 
 // fri_proof_of_work: candidate = base + gid goes where the next observed element would; the response is the first
 // challenge after it (word 7 of the permuted state).  *result = smallest passing candidate (init ~0).
-// interleave != 0 (the grind of a batch): grid = (proofs, candidate blocks) so that the dispatcher walks the proofs in the fast
-// dimension and the candidates in the slow one -- a workgroup whose candidates all lie above a witness that is already known
-// exits at once, so a proof costs about the 2^pow_bits candidates up to its first hit plus the ~8 k that are in flight, not a
-// whole chunk (the smallest witness still wins: only larger candidates are skipped).
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ st, u32 pow_bits, u64 base, u64 count,
-                                                    unsigned long long* __restrict__ result, u32 interleave, BatchArg ba,
-                                                    PermCtx ctx) {
-  const unsigned proof = interleave ? blockIdx.x : blockIdx.z, blk = interleave ? blockIdx.y : blockIdx.x;
-  st = bp_at(st, ba, proof);
-  result = bp_at(result, ba, proof);
-  const u64 gid = (u64)blk * kBlock + threadIdx.x;
+                                                    unsigned long long* __restrict__ result, BatchArg ba, PermCtx ctx) {
+  st = bp(st, ba);
+  result = bp(result, ba);
+  const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= count) return;
-  if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + (u64)blk * kBlock) return;
   const u64 cand = base + gid;
   const u32 n_in = st->n_in;  // < 8: a full buffer is duplexed at once
   u64 s[12];
@@ -198,6 +191,63 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ 
   });
   const u64 resp = gl::canon(s[7]);
   if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
+}
+
+// The grind of a batch as a work queue.  Proofs need very different numbers of candidates (geometric, mean 2^pow_bits), so a
+// fixed chunk per proof would idle most of the chip while the slowest proofs finish.  Here a resident grid of workgroups
+// serves all the proofs: a workgroup looks for the next proof (round robin from where it last worked) that still has candidate
+// blocks below its best known witness, takes that proof's next block of 256 candidates from the proof's counter, evaluates it,
+// and moves on; it exits when no proof has work left, so the grid always drains.  Blocks are handed out in increasing order and
+// a taken block is always evaluated unless a smaller witness is already known, so the result is the smallest witness, as in
+// the single-proof search.  counter: one u32 per proof (zeroed by the host), blocks of [base, base + max_blocks * 256).
+template <int M, int PR>
+__global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restrict__ st0, u32 pow_bits, u64 base, u32 max_blocks,
+                                                          unsigned long long* __restrict__ result0, u32* __restrict__ counter0,
+                                                          u32 B, BatchArg ba, PermCtx ctx) {
+  __shared__ u32 s_dist, s_blk;
+  unsigned p = blockIdx.x % B;
+#pragma unroll 1
+  for (;;) {
+    if (threadIdx.x == 0) s_dist = ~0u;
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < B; k += kBlock) {  // distance to the next proof with unassigned candidates below its witness
+      const u32 q = (p + k) % B;
+      const u64 r = __hip_atomic_load(bp_at(result0, ba, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 nb = __hip_atomic_load(bp_at(counter0, ba, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nb < max_blocks && base + (u64)nb * kBlock < r) {
+        atomicMin(&s_dist, k);
+        break;
+      }
+    }
+    __syncthreads();
+    const u32 dist = s_dist;
+    if (dist == ~0u) return;  // workgroup-uniform
+    const u32 q = (p + dist) % B;
+    if (threadIdx.x == 0) s_blk = atomicAdd(bp_at(counter0, ba, q), 1u);
+    __syncthreads();
+    const u32 blk = s_blk;
+    unsigned long long* result = bp_at(result0, ba, q);
+    if (blk < max_blocks && base + (u64)blk * kBlock < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      const ChState* st = bp_at(st0, ba, q);
+      const u64 cand = base + (u64)blk * kBlock + threadIdx.x;
+      const u32 n_in = st->n_in;
+      u64 s[12];
+      permute_reloadable<M, PR>(s, ctx, [&](u64 (&t)[12]) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          u64 v = st->state[k];
+          if (k < 8) {
+            if ((u32)k < n_in) v = st->in[k];
+            else if ((u32)k == n_in) v = cand;
+          }
+          t[k] = v;
+        }
+      });
+      const u64 resp = gl::canon(s[7]);
+      if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
+    }
+    p = (q + 1) % B;
+  }
 }
 
 // The same grind with four lanes per candidate (poseidon_quad.hip.h): a third of the single-hash latency, which is what
@@ -849,7 +899,7 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     wsz += (words + 3) & ~(size_t)3;  // 32-byte granules
     return at;
   };
-  const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds), o_chsave = carve(32);
+  const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds), o_chsave = carve(32), o_cnt = carve(1);
   const size_t o_apow = carve(2 * (max_cnt + 1)), o_partial = carve(max_groups * 2 * n);
   const size_t o_fin = carve(2 * (size_t)n), o_c0 = carve(2 * (size_t)n), o_c1 = carve(2 * (size_t)n);
   size_t o_vals[8], o_leaves[8], o_dig[8];
@@ -961,9 +1011,12 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     const bool quad_grind = rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput && B == 1;
     const u64 batch_chunk = std::max<u64>(chunk, (u64)1 << (p->proof_of_work_bits + 4 < 32 ? p->proof_of_work_bits + 4 : 32));
     auto grind = [&](u64 base) -> int {
-      if (B > 1) {  // proofs in grid x, candidate blocks in grid y (early exit per workgroup, see k_fri_pow)
-        P2MT_DISPATCH(k_fri_pow, dim3(B, grid_for(batch_chunk), 1), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base,
-                      batch_chunk, d_wit, 1u, barg());
+      if (B > 1) {  // one resident grid serves every proof of the batch (k_fri_pow_queue)
+        P2MT_TRY(p2mt::batch_fill(ws + o_cnt, 0, 8));
+        const u32 max_blocks = (u32)(batch_chunk / kBlock);
+        const u64 wgs = std::min<u64>((u64)B * max_blocks, 2048);
+        P2MT_DISPATCH(k_fri_pow_queue, dim3((unsigned)wgs), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, max_blocks,
+                      d_wit, reinterpret_cast<u32*>(ws + o_cnt), B, barg());
         return P2MT_OK;
       }
       if (quad_grind) {
@@ -972,7 +1025,7 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
         P2MT_LAUNCH_CHECK();
       } else {
         P2MT_DISPATCH(k_fri_pow, bgrid(grid_for(chunk)), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, chunk, d_wit,
-                      0u, barg());
+                      barg());
       }
       return P2MT_OK;
     };
@@ -987,8 +1040,8 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     };
     if (B > 1) {
       // A batch grinds chunk after chunk (2^(pow_bits + 4) candidates: one chunk almost always) until every proof has its witness
-      // -- a chunk skips what lies above a witness that is already known, and keeps the smallest one like the single-proof
-      // search --, then finishes all the proofs with one tail.
+      // -- the work queue of k_fri_pow_queue keeps the smallest one, like the single-proof search --, then finishes all the
+      // proofs with one tail.
       std::vector<unsigned long long> found(B);
       for (u64 base = 0;; base += batch_chunk) {
         if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
