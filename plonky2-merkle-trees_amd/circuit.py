@@ -167,6 +167,10 @@ class PartialWitness:
     def set_target(self, target, value):
         N.check(N.lib().p2mt_pw_set_target(self._h, target, int(value)))
 
+    def clear(self):
+        """forget every assignment (the handle is reused for the next statement)"""
+        N.check(N.lib().p2mt_pw_clear(self._h))
+
     def set_bool_target(self, target, value):
         self.set_target(target, 1 if value else 0)
 

@@ -398,7 +398,10 @@ GL_DEV void put(const Mem& m, u32 slot, u64 v, int* err, u32 op_index) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__ pairs, u32 n_pairs, u64* vals, u32* set) {
+__global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__ pairs, u32 n_pairs, u64* vals, u32* set, BatchArg ba) {
+  pairs = bp(pairs, ba);
+  vals = bp(vals, ba);
+  set = bp(set, ba);
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= n_pairs) return;
   const u32 slot = (u32)pairs[2 * t];
@@ -696,7 +699,10 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
 __global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
                                                         u64* vals, u32* set, const u32* __restrict__ pslots,
                                                         const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
-                                                        PermCtx ctx) {
+                                                        BatchArg ba, PermCtx ctx) {
+  vals = bp(vals, ba);
+  set = bp(set, ba);
+  err = bp(err, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   run_levels(GMem{vals, set}, ops, lvl, n_levels, pslots, tab, args, err, ctx);
@@ -835,7 +841,12 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
 __global__ __launch_bounds__(kBlock) void k_witness_scatter(const u64* __restrict__ vals, const u32* __restrict__ set,
                                                             const u32* __restrict__ act, u32 n_act, u64* __restrict__ wires,
                                                             const u32* __restrict__ pi_slot, u32 n_pi, u64* __restrict__ pi_out,
-                                                            int* err) {
+                                                            int* err, BatchArg ba) {
+  vals = bp(vals, ba);
+  set = bp(set, ba);
+  wires = bp(wires, ba);
+  pi_out = bp(pi_out, ba);
+  err = bp(err, ba);
   const u32 k = blockIdx.x * kBlock + threadIdx.x;
   if (k < n_pi) {
     const u32 s = pi_slot[k];
@@ -1542,7 +1553,6 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
   const size_t n_pairs = np2 / 2;
   hipStream_t st = rt().stream;  // (pinned source: a DMA copy, no blit kernel on the queue)
   if (B > 1) {
-    if (!c->lds_bytes) return p2mt::fail(P2MT_EINVAL, "prove_batch: the circuit's witness table must fit LDS");
     P2MT_HIP(hipMemcpy2DAsync(c->d_init, p2mt::batch().arg.stride, c->h_pin + c->pin_pairs_off, c->pin_pitch * 8, np2 * 8, B,
                               hipMemcpyHostToDevice, st));
   } else {
@@ -1550,8 +1560,8 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
   }
   u64* d_pi_out = c->d_head + 8 + (c->proof_len - c->n_pi);
   if (!c->lds_bytes) {
-    P2MT_HIP(hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), st));
-    P2MT_HIP(hipMemsetAsync(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8, st));  // wires nothing sets are zero
+    P2MT_TRY(p2mt::batch_fill(c->d_err, 0, 4 * sizeof(int)));
+    P2MT_TRY(p2mt::batch_fill(c->d_w_vals, 0, (size_t)kNumWires * c->n * 8));  // wires nothing sets are zero
   }
   if (c->lds_bytes) {
     hipLaunchKernelGGL(k_witness_lds, bgrid(1), dim3(kBlock), c->lds_bytes, st, (const u64*)c->d_init, (u32)n_pairs, c->n_slots,
@@ -1562,18 +1572,20 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
     P2MT_LAUNCH_CHECK();
     return fill_poseidon_rows(c);
   }
-  P2MT_HIP(hipMemsetAsync(c->d_set, 0, (size_t)c->n_slots * 4, st));
-  P2MT_HIP(hipMemsetAsync(c->d_vals, 0xFF, (size_t)c->n_slots * 8, st));  // kUnsetValue everywhere (k_witness_flow waits on it)
-  hipLaunchKernelGGL(k_witness_init, dim3(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
-                     c->d_set);
+  P2MT_TRY(p2mt::batch_fill(c->d_set, 0, ((size_t)c->n_slots * 4 + 7) & ~(size_t)7));
+  P2MT_TRY(p2mt::batch_fill(c->d_vals, 0xFF, (size_t)c->n_slots * 8));  // kUnsetValue everywhere (k_witness_flow waits on it)
+  hipLaunchKernelGGL(k_witness_init, bgrid(grid_for(n_pairs)), dim3(kBlock), 0, st, (const u64*)c->d_init, (u32)n_pairs, c->d_vals,
+                     c->d_set, barg());
   P2MT_LAUNCH_CHECK();
   // Interpreter for tables in global memory: 2 (default) = dataflow over the whole grid (k_witness_flow), 1 = level-synchronous
   // over the whole grid (k_witness_grid), 0 = one workgroup (k_witness_run); env P2MT_WITNESS_GRID selects (A/B and fallback).
+  // The proofs of a batch take the one-workgroup interpreter each: the grid-wide ones assume that their workgroups are all
+  // resident, which B grids at once are not.
   static const int env_mode = [] {
     const char* e = getenv("P2MT_WITNESS_GRID");
     return e ? atoi(e) : 2;
   }();
-  const int mode = c->force_single_workgroup ? 0 : env_mode;
+  const int mode = (c->force_single_workgroup || B > 1) ? 0 : env_mode;
   if (mode == 2) {
     hipLaunchKernelGGL(k_witness_flow, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
                        c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
@@ -1584,13 +1596,14 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
                        c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
                        c->d_sync, p2mt::perm_ctx());
   } else {
-    hipLaunchKernelGGL(k_witness_run, dim3(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
-                       c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err, p2mt::perm_ctx());
+    hipLaunchKernelGGL(k_witness_run, bgrid(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
+                       c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err, barg(),
+                       p2mt::perm_ctx());
   }
   P2MT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_witness_scatter, dim3(grid_for(std::max<size_t>(c->n_act, c->n_pi))), dim3(kBlock), 0, st,
+  hipLaunchKernelGGL(k_witness_scatter, bgrid(grid_for(std::max<size_t>(c->n_act, c->n_pi))), dim3(kBlock), 0, st,
                      (const u64*)c->d_vals, (const u32*)c->d_set, (const u32*)c->d_wire_slot, c->n_act, c->d_w_vals,
-                     (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, c->d_err);
+                     (const u32*)c->d_pi_slot, c->n_pi, d_pi_out, c->d_err, barg());
   P2MT_LAUNCH_CHECK();
   return fill_poseidon_rows(c);
 }
@@ -2417,7 +2430,8 @@ extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_
 namespace {
 struct PerProof {
   u64 *w_vals, *w_coeffs, *w_lde, *w_leaves, *w_dig, *z_vals, *z_coeffs, *z_lde, *z_leaves, *z_dig, *pp_q;
-  u64 *q_vals, *q_coeffs, *q_lde, *q_leaves, *q_dig, *head, *open, *chal, *init, *q_extra;
+  u64 *q_vals, *q_coeffs, *q_lde, *q_leaves, *q_dig, *head, *open, *chal, *init, *q_extra, *vals;
+  u32* set;
   int* err;
   p2mt_challenger* ch;
   u64* h_pin;
@@ -2431,6 +2445,7 @@ void exchange(p2mt_circuit_data* c, PerProof& p) {
   std::swap(c->d_q_vals, p.q_vals), std::swap(c->d_q_coeffs, p.q_coeffs), std::swap(c->d_q_lde, p.q_lde);
   std::swap(c->d_q_leaves, p.q_leaves), std::swap(c->d_q_dig, p.q_dig);
   std::swap(c->d_head, p.head), std::swap(c->d_open, p.open), std::swap(c->d_chal, p.chal), std::swap(c->d_init, p.init);
+  std::swap(c->d_vals, p.vals), std::swap(c->d_set, p.set);
   std::swap(c->d_q_extra, p.q_extra), std::swap(c->d_err, p.err), std::swap(c->ch, p.ch), std::swap(c->h_pin, p.h_pin);
   std::swap(c->pin_pitch, p.pin_pitch);
 }
@@ -2451,8 +2466,6 @@ extern "C" int p2mt_batch_prover_create(p2mt_circuit_data* c, size_t batch, p2mt
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (batch == 0 || batch > 4096) return p2mt::fail(P2MT_EINVAL, "batch_prover: batch must be in 1..4096");
-  if (!c->lds_bytes || c->degree_bits > 11)
-    return p2mt::fail(P2MT_EINVAL, "batch_prover: only circuits whose witness table fits LDS (the reference's MMR-verifier circuits) are batched");
   p2mt_batch_prover* b = new (std::nothrow) p2mt_batch_prover;
   if (!b) return p2mt::fail(P2MT_ENOMEM, "out of host memory");
   b->c = c;
@@ -2496,6 +2509,7 @@ static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness
   const size_t o_head = carve(8 + c->proof_len + 2), o_open = carve(2 * n_open), o_chal = carve(8), o_init = carve(2 * c->init_cap);
   const size_t o_q_extra = c->has_recursion_gates ? carve((size_t)(G_KINDS - G_POSEIDON - 1) * kNumCh * big) : 0;
   const size_t o_ch = carve(p2mt::kChallengerStateBytes / 8);
+  const size_t o_vals = c->lds_bytes ? 0 : carve(c->n_slots), o_set = c->lds_bytes ? 0 : carve((c->n_slots + 1) / 2);
   b->arena_off = words * 8;
   size_t arena = 0;
   for (int k = 0; k < p2mt::kScratchCount; ++k) {
@@ -2525,6 +2539,8 @@ static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness
   p.q_vals = base + o_qvals, p.pp_q = base + o_ppq, p.head = base + o_head, p.open = base + o_open, p.chal = base + o_chal;
   p.init = base + o_init, p.q_extra = c->has_recursion_gates ? base + o_q_extra : nullptr;
   p.err = reinterpret_cast<int*>(base + o_head + 8 + c->proof_len);
+  p.vals = c->lds_bytes ? nullptr : base + o_vals;
+  p.set = c->lds_bytes ? nullptr : reinterpret_cast<u32*>(base + o_set);
   P2MT_TRY(p2mt::challenger_wrap(base + o_ch, &p.ch));
   p.h_pin = b->h_pin;
   p.pin_pitch = pitch;

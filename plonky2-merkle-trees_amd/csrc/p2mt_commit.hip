@@ -59,7 +59,8 @@ __global__ __launch_bounds__(kBlock) void k_powers(u64* __restrict__ tw, u64 roo
 // ---------------------------------------------------------------- DIF butterflies
 // One DIF stage in global memory: n-point transforms, stage s pairs elements `half = n >> (s+1)` apart.
 __global__ __launch_bounds__(kBlock) void k_ntt_global_stage(u64* __restrict__ data, unsigned log_n, unsigned s,
-                                                             const u64* __restrict__ tw, size_t n_polys) {
+                                                             const u64* __restrict__ tw, size_t n_polys, BatchArg ba) {
+  data = bp(data, ba);
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const size_t half_n = (size_t)1 << (log_n - 1);
   if (t >= half_n * n_polys) return;
@@ -91,7 +92,8 @@ GL_DEV void lds_dif(u64* buf, unsigned c, unsigned first_stage, const u64* __res
 
 // Tail of a (possibly large) transform: one workgroup per 2^c chunk.  Output stays in DIF (bit-reversed) order.
 __global__ __launch_bounds__(kBlock) void k_ntt_lds_tail(u64* __restrict__ data, unsigned log_n, unsigned c,
-                                                         const u64* __restrict__ tw) {
+                                                         const u64* __restrict__ tw, BatchArg ba) {
+  data = bp(data, ba);
   extern __shared__ __attribute__((aligned(16))) u64 buf[];
   u64* chunk = data + ((size_t)blockIdx.x << c);
   const unsigned m = 1u << c;
@@ -103,7 +105,9 @@ __global__ __launch_bounds__(kBlock) void k_ntt_lds_tail(u64* __restrict__ data,
 
 // out[brev(q)] = in[q] * scale  (bit-reversal back to natural order, optional 1/n scaling for the inverse)
 __global__ __launch_bounds__(kBlock) void k_bitrev_scale(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_n,
-                                                         size_t n_polys, u64 scale) {
+                                                         size_t n_polys, u64 scale, BatchArg ba) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= (n_polys << log_n)) return;
   const size_t poly = t >> log_n, q = t & (((size_t)1 << log_n) - 1);
@@ -255,7 +259,9 @@ GL_DEV void dif16(u64 (&x)[16], u64& sticky) {
 
 __global__ __launch_bounds__(kBlock) void k_coset_lde12(const u64* __restrict__ coeffs, unsigned rate_bits,
                                                         const u64* __restrict__ coset_pow, const u64* __restrict__ tw_full,
-                                                        const u64* __restrict__ tw_half, u64* __restrict__ out) {
+                                                        const u64* __restrict__ tw_half, u64* __restrict__ out, BatchArg ba) {
+  coeffs = bp(coeffs, ba);
+  out = bp(out, ba);
   using namespace lde12;
   __shared__ __attribute__((aligned(16))) u64 buf[16 * kRowA];  // 34 KB; also holds the 256 x 17 layout (4352 words)
   const unsigned t = threadIdx.x;
@@ -559,12 +565,12 @@ int ntt_dif_dev(u64* d_data, unsigned log_n, size_t n_polys, int inverse) {
   hipStream_t st = p2mt::rt().stream;
   const unsigned c = log_n < kLdsLog ? log_n : kLdsLog;
   for (unsigned s = 0; s + c < log_n; ++s) {
-    hipLaunchKernelGGL(k_ntt_global_stage, dim3(grid_for(n_polys << (log_n - 1))), dim3(kBlock), 0, st, d_data, log_n, s,
-                       tw, n_polys);
+    hipLaunchKernelGGL(k_ntt_global_stage, bgrid(grid_for(n_polys << (log_n - 1))), dim3(kBlock), 0, st, d_data, log_n, s,
+                       tw, n_polys, barg());
     P2MT_LAUNCH_CHECK();
   }
   const size_t chunks = n_polys << (log_n - c);
-  hipLaunchKernelGGL(k_ntt_lds_tail, dim3((unsigned)chunks), dim3(kBlock), (size_t)8 << c, st, d_data, log_n, c, tw);
+  hipLaunchKernelGGL(k_ntt_lds_tail, bgrid((unsigned)chunks), dim3(kBlock), (size_t)8 << c, st, d_data, log_n, c, tw, barg());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
@@ -628,8 +634,8 @@ extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_pol
   P2MT_HIP(hipMemcpyAsync(tmp.p, d_data, total * 8, hipMemcpyDeviceToDevice, rt().stream));
   P2MT_TRY(ntt_dif_dev(tmp.as<u64>(), log_n, n_polys, inverse));
   const u64 scale = inverse ? h_pow(((u64)1 << log_n) % gl::P, gl::P - 2) : 1;
-  hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(total)), dim3(kBlock), 0, rt().stream, (const u64*)tmp.as<u64>(), d_data,
-                     log_n, n_polys, scale);
+  hipLaunchKernelGGL(k_bitrev_scale, bgrid(grid_for(total)), dim3(kBlock), 0, rt().stream, (const u64*)tmp.as<u64>(), d_data,
+                     log_n, n_polys, scale, barg());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamSynchronize(rt().stream));  // tmp dies with this call
   return P2MT_OK;
@@ -659,11 +665,10 @@ int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned
   P2MT_TRY(get_coset_pows(log_n, rate_bits, shift, &cp));
   const int slot = p2mt::prof_begin();  // the LDE is the HBM-streaming kernel of the commit step
   if (log_n == 12 && rt().use_lde12) {
-    if (p2mt::batch_B() > 1) return p2mt::fail(P2MT_EINVAL, "batched pipeline: 2^12-row polynomials are not supported");
     const u64* twf;
     P2MT_TRY(get_full_twiddles(12, &twf));
-    hipLaunchKernelGGL(k_coset_lde12, dim3((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
-                       rate_bits, cp, twf, tw, d_out);
+    hipLaunchKernelGGL(k_coset_lde12, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
+                       rate_bits, cp, twf, tw, d_out, barg());
   } else {
     hipLaunchKernelGGL(k_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,
                        d_coeffs, log_n, rate_bits, cp, tw, d_out, barg());
@@ -683,8 +688,8 @@ extern "C" int p2mt_coset_lde_batch_dev(const uint64_t* d_coeffs, unsigned log_n
   DevBuf tmp;
   P2MT_TRY(tmp.alloc(total * 8));
   P2MT_TRY(p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, shift, n_polys, tmp.as<u64>()));
-  hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(total)), dim3(kBlock), 0, rt().stream, (const u64*)tmp.as<u64>(), d_out,
-                     log_big, n_polys, (u64)1);
+  hipLaunchKernelGGL(k_bitrev_scale, bgrid(grid_for(total)), dim3(kBlock), 0, rt().stream, (const u64*)tmp.as<u64>(), d_out,
+                     log_big, n_polys, (u64)1, barg());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
@@ -879,16 +884,15 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
     P2MT_LAUNCH_CHECK();
     d_coeffs = coeffs;
   } else if (is_values) {  // IFFT: DIF with inverse roots, then bit-reversal + 1/n
-    if (p2mt::batch_B() > 1) return p2mt::fail(P2MT_EINVAL, "batched pipeline: polynomials above 2^12 rows are not supported");
     u64* buf;
     P2MT_TRY(p2mt::scratch_get(p2mt::kScratchCoeffs, n_polys * n * 8 * 2, (void**)&buf));
     u64* work = buf + n_polys * n;
     u64* coeffs = d_coeffs_out ? d_coeffs_out : buf;
-    P2MT_HIP(hipMemcpyAsync(work, d_polys, n_polys * n * 8, hipMemcpyDeviceToDevice, st));
+    P2MT_TRY(p2mt::batch_copy(work, d_polys, n_polys * n * 8));
     P2MT_TRY(ntt_dif_dev(work, log_n, n_polys, 1));
     const u64 n_inv = h_pow((u64)n % gl::P, gl::P - 2);
-    hipLaunchKernelGGL(k_bitrev_scale, dim3(grid_for(n_polys * n)), dim3(kBlock), 0, st, (const u64*)work, coeffs, log_n, n_polys,
-                       n_inv);
+    hipLaunchKernelGGL(k_bitrev_scale, bgrid(grid_for(n_polys * n)), dim3(kBlock), 0, st, (const u64*)work, coeffs, log_n, n_polys,
+                       n_inv, barg());
     P2MT_LAUNCH_CHECK();
     d_coeffs = coeffs;
   } else if (d_coeffs_out && d_coeffs_out != d_polys) {
@@ -930,7 +934,9 @@ extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_
 // PolynomialValues::coset_ifft(shift): plain IFFT gives c_k shift^k; the bit-reversal pass also divides by n shift^k.
 namespace {
 __global__ __launch_bounds__(kBlock) void k_bitrev_coset_scale(const u64* __restrict__ in, u64* __restrict__ out, unsigned log_n,
-                                                               size_t n_polys, u64 n_inv, u64 shift_inv) {
+                                                               size_t n_polys, u64 n_inv, u64 shift_inv, BatchArg ba) {
+  in = bp(in, ba);
+  out = bp(out, ba);
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= (n_polys << log_n)) return;
   const size_t poly = t >> log_n, q = t & (((size_t)1 << log_n) - 1);
@@ -950,10 +956,9 @@ int p2mt::coset_ifft_dev(uint64_t* d_vals, unsigned log_n, size_t n_polys, uint6
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
-  if (p2mt::batch_B() > 1) return p2mt::fail(P2MT_EINVAL, "batched pipeline: polynomials above 2^12 points are not supported");
   P2MT_TRY(ntt_dif_dev(d_vals, log_n, n_polys, 1));
-  hipLaunchKernelGGL(k_bitrev_coset_scale, dim3(grid_for(n_polys << log_n)), dim3(kBlock), 0, rt().stream, (const u64*)d_vals,
-                     d_coeffs_out, log_n, n_polys, n_inv, shift_inv);
+  hipLaunchKernelGGL(k_bitrev_coset_scale, bgrid(grid_for(n_polys << log_n)), dim3(kBlock), 0, rt().stream, (const u64*)d_vals,
+                     d_coeffs_out, log_n, n_polys, n_inv, shift_inv, barg());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }

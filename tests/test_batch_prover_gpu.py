@@ -109,7 +109,57 @@ def test_batch_rejects_what_it_cannot_batch(pkg, oracle):
     assert np.array_equal(bp.prove(pws)[1], cd.prove(pws[1]))  # still usable
     with pytest.raises(pkg.P2mtPanic):
         pkg.BatchProver(cd, 0)
-    # a circuit whose witness table lives in global memory (1500 path elements, 2^12 rows)
-    big, _, _, _ = pkg.verify_mmr_proof_circuit(1500, 1)
-    with pytest.raises(pkg.P2mtPanic, match="LDS"):
-        pkg.BatchProver(big, 2)
+
+
+def test_batch_circuit_with_a_global_witness_table(pkg, oracle):
+    """1500 path elements: 2^12 rows, the value table lives in global memory -- inside a batch every proof gets the one-workgroup
+    interpreter (the grid-wide ones want the chip to themselves) and the streaming 2^12 LDE / 2^15 NTT kernels carry the batch."""
+    cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 1500, range(590, 593))
+    assert cd.info.degree_bits == 12
+    want = [cd.prove(pw) for pw in pws]
+    got = pkg.BatchProver(cd, 2).prove(pws)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert cd.verify(got[2])
+
+
+def test_batch_of_recursion_proofs(pkg, oracle):
+    """mmr_plonky2_verifier_1_recursion in batches: three statements -> three inner proofs in one pass -> three outer witnesses ->
+    three outer proofs in passes of two; all equal to the one-at-a-time proofs (which test_recursion_gpu.py pins to the oracle)."""
+    from circuit_cases import mmr_case
+    cases = [mmr_case(oracle, 7, leaf) for leaf in (0, 1, 3)]  # 7 leaves: 3 peaks, leaves of the first mountain (2 path elements)
+    n_sib, n_peaks = len(cases[0][1]), len(cases[0][3])
+    cases = [c for c in cases if len(c[1]) == n_sib]
+    assert len(cases) >= 2
+    inner, leaf_t, proof_ts = pkg.verify_inner_merkle_proof_circuit(n_sib, n_peaks)
+    outer, pt, vd, peak_ts = pkg.complete_verification_circuit_with_inner_proof(inner.common, n_peaks)
+    pws = []
+    for leaf, sib, lefts, peaks, root in cases:
+        pw = pkg.PartialWitness()
+        pw.set_target(leaf_t, leaf)
+        for (ht, bt), s, l in zip(proof_ts, sib, lefts):
+            pw.set_hash_target(ht, [int(x) for x in s])
+            pw.set_target(bt, int(l))
+        for i, pk in enumerate(peaks):
+            for k in range(4):
+                pw.set_target(inner.prover_only.public_inputs[4 * i + k], int(pk[k]))
+        pws.append(pw)
+    inner_want = [inner.prove(pw) for pw in pws]
+    inner_got = pkg.BatchProver(inner, 4).prove(pws)
+    for g, w in zip(inner_got, inner_want):
+        assert np.array_equal(g, w)
+    opws = []
+    for (leaf, sib, lefts, peaks, root), ip in zip(cases, inner_got):
+        pw = pkg.PartialWitness()
+        pw.set_proof_with_pis_target(pt, ip)
+        pw.set_verifier_data_target(vd, inner.verifier_only)
+        for t, pk in zip(peak_ts, peaks):
+            pw.set_hash_target(t, [int(x) for x in pk])
+        for k, t in enumerate(outer.prover_only.public_inputs):
+            pw.set_target(t, int(root[k]))
+        opws.append(pw)
+    outer_want = [outer.prove(pw) for pw in opws]
+    outer_got = pkg.BatchProver(outer, 2).prove(opws)
+    for g, w in zip(outer_got, outer_want):
+        assert np.array_equal(g, w)
+    assert outer.verify(outer_got[-1])
