@@ -416,10 +416,11 @@ int p2mt_circuit_prove_many(p2mt_circuit_data *const *circuits, size_t n_handles
                             size_t n, uint64_t *proofs_out, size_t proof_stride, int *status_out);
 /* Batched prover: up to `batch` proofs of ONE circuit per pass of the pipeline, the proof index riding in a grid dimension of
  * every launch (a pass costs the ~44 dispatch packets of one proof; the per-proof path above is bound by the device's packet
- * rate when many provers run).  For circuits whose witness table fits LDS -- the reference's MMR-verifier circuits
- * (mmr_plonky2_verifier.rs:148, and the inner prove of mmr_plonky2_verifier_1_recursion.rs:192); P2MT_EINVAL otherwise.
+ * rate when many provers run).  Any circuit p2mt_cb_build accepts: the reference's MMR-verifier circuits
+ * (mmr_plonky2_verifier.rs:148), and both the inner and the outer prove of mmr_plonky2_verifier_1_recursion.rs:192,218.
  * Proofs are bit-identical to p2mt_circuit_prove's.  The prover borrows the circuit handle: one thread at a time, and the
- * circuit must outlive it.  Device memory: ~2 MB per proof of the batch for a 64-row circuit, allocated on the first prove.
+ * circuit must outlive it.  Device memory, allocated on the first prove: per proof of the batch ~2 MB for a 64-row circuit,
+ * ~115 MB for the 2^12-row outer recursion circuit.
  * witnesses[i] -> proofs_out + i * proof_stride for i < n (any n: passes of up to `batch`); every witness must set the same
  * targets in the same order.  status_out[i] (may be NULL) = status of proof i; returns the first non-zero status. */
 typedef struct p2mt_batch_prover p2mt_batch_prover;

@@ -2529,6 +2529,9 @@ static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness
   if (hipHostMalloc((void**)&b->h_pin, pitch * 8 * b->B, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
     b->h_pin = nullptr;
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(b->d_block);  // a later call starts over
+    b->d_block = nullptr;
     return p2mt::fail(P2MT_ENOMEM, "hipHostMalloc(batch prover staging) failed");
   }
   u64* base = reinterpret_cast<u64*>(b->d_block);
@@ -2541,6 +2544,8 @@ static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness
   p.err = reinterpret_cast<int*>(base + o_head + 8 + c->proof_len);
   p.vals = c->lds_bytes ? nullptr : base + o_vals;
   p.set = c->lds_bytes ? nullptr : reinterpret_cast<u32*>(base + o_set);
+  if (p.ch) p2mt::challenger_unwrap(p.ch);  // (left over from an attempt that ran out of memory)
+  p.ch = nullptr;
   P2MT_TRY(p2mt::challenger_wrap(base + o_ch, &p.ch));
   p.h_pin = b->h_pin;
   p.pin_pitch = pitch;
