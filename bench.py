@@ -103,20 +103,45 @@ def cpu_baseline_mmr(host_leaves, gpu_elements_sha256, gpu_root, sample_log=20, 
     el, _ = o.mmr_build_pow2_parallel(host_leaves, best_t, el)  # the pinned spec-form restatement, same array
     dt_spec = time.perf_counter() - t0
     spec_sha = hashlib.sha256(el.tobytes()).hexdigest()
+    # B1'' / B2'': the AVX-512 port (eight permutations per zmm lane set, oracle/poseidon_avx512.c) where the host has AVX-512.
+    # Level order (the add_leaf loop is one hash at a time and cannot feed eight lanes); `el` is already resident (no page faults).
+    simd, simd_1, simd_all = ol.build_avx512_port_native(), None, None
+    if simd is not None:
+        m = 1 << fast_log
+        t0 = time.perf_counter()
+        el_s, _ = ol.avx512_mmr_build_pow2_into(simd, host_leaves[:m], el[:2 * m - 1], 1)
+        dt_s1 = time.perf_counter() - t0
+        assert np.array_equal(el_s[-1], fast_root), "AVX-512 port's root != scalar port's root on the 2^%d sample" % fast_log
+        t0 = time.perf_counter()
+        el, _ = ol.avx512_mmr_build_pow2_into(simd, host_leaves, el, best_t)
+        dt_sa = time.perf_counter() - t0
+        assert hashlib.sha256(el.tobytes()).hexdigest() == spec_sha, "AVX-512 port's 2^24 build != the spec-form port's"
+        simd_1 = {"value": (m - 1) / dt_s1, "cores": 1, "seconds": dt_s1,
+                  "what": "B1'': level-order build of the first 2^%d leaves on the AVX-512 port (oracle/poseidon_avx512.c, eight "
+                          "hashes per permutation call, -O3 -march=native on this host), 1 thread; root == the scalar port's" % fast_log}
+        simd_all = {"value": (n - 1) / dt_sa, "cores": threads, "seconds": dt_sa,
+                    "what": "B2'': the same build of ALL 2^%d leaves, OpenMP; node array SHA-256 == the spec-form port's"
+                            % (n.bit_length() - 1)}
     parity = {"size_log2": n.bit_length() - 1, "root_equal": bool(np.array_equal(cpu_root, gpu_root)),
               "elements_sha256_gpu": gpu_elements_sha256, "elements_sha256_oracle": spec_sha,
               "elements_sha256_equal": spec_sha == gpu_elements_sha256 and cpu_sha == gpu_elements_sha256,
               "oracle": "oracle_mmr_build_pow2_parallel (spec-form port, %d threads, %.1f s) and the tuned port's build" % (threads, dt_spec)}
+    scalar_1 = {"value": ((1 << fast_log) - 1) / dt_fast, "cores": 1, "seconds": dt_fast,
+                "what": "B1': the same add_leaf loop on the tuned scalar port (oracle/poseidon_fast.c: sparse partial "
+                        "rounds, lazy reduction, -O3 -march=native on this host), first 2^%d leaves" % fast_log}
+    scalar_all = {"value": (n - 1) / dt2, "cores": threads, "seconds": dt2,
+                  "what": "B2: level-order OpenMP build of ALL 2^%d leaves with the tuned scalar port (generous, not the "
+                          "reference's algorithm)" % (n.bit_length() - 1)}
+    # port_fast / all_cores = the fastest CPU legs this host can run (the AVX-512 port where available); the scalar legs stay
+    # beside them
+    use_simd = simd_1 is not None and simd_1["value"] > scalar_1["value"]
     return {"value": hashes / dt, "unit": "Poseidon hashes/s", "cores": 1, "kind": "port",
             "sample": "oracle/mmr.c add_leaf loop (B1, faithful: the reference is single-threaded), first 2^%d leaves of the "
                       "bench input, %.1f s; at this rate the full 2^%d-leaf build would take %.0f s"
                       % (sample_log, dt, n.bit_length() - 1, (n - 1) / (hashes / dt)),
-            "port_fast": {"value": ((1 << fast_log) - 1) / dt_fast, "cores": 1, "seconds": dt_fast,
-                          "what": "B1': the same add_leaf loop on the tuned scalar port (oracle/poseidon_fast.c: sparse partial "
-                                  "rounds, lazy reduction, gcc -O3 -march=native on this host), first 2^%d leaves" % fast_log},
-            "all_cores": {"value": (n - 1) / dt2, "cores": threads, "seconds": dt2,
-                          "what": "B2: level-order OpenMP build of ALL 2^%d leaves with the tuned port (generous, not the "
-                                  "reference's algorithm)" % (n.bit_length() - 1)},
+            "port_fast": simd_1 if use_simd else scalar_1,
+            "all_cores": simd_all if use_simd and simd_all["value"] > scalar_all["value"] else scalar_all,
+            "port_fast_scalar": scalar_1, "all_cores_scalar": scalar_all,
             "full_size_parity": parity,
             "_roots": (b1_root, fast_root, sample_log, fast_log)}
 

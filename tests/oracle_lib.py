@@ -44,6 +44,55 @@ def build_fast_port_native():
     return lib
 
 
+def build_avx512_port_native():
+    """oracle/poseidon_avx512.c compiled for THIS machine (-O3 -march=native) into a temp dir, or None when the host has no
+    AVX-512 (the file then compiles to stubs): bench.py's cpu_baseline.port_fast on hosts that have it."""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="p2mt_avx512_port_")
+    so = os.path.join(d, "libavx512port.so")
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    src = os.path.join(ORACLE_DIR, "poseidon_avx512.c")
+    for cc in ([clang] if os.path.exists(clang) else []) + ["gcc"]:
+        try:
+            subprocess.check_call([cc, "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o", so, src, "-I", ORACLE_DIR],
+                                  stderr=subprocess.DEVNULL)
+            break
+        except (subprocess.CalledProcessError, OSError):
+            continue
+    else:
+        return None
+    lib = C.CDLL(so)
+    lib.oracle_avx512_available.restype = C.c_int
+    if not lib.oracle_avx512_available():
+        return None
+    lib.oracle_avx512_permute_batch.argtypes = [_u64p, _u64p, C.c_size_t]
+    lib.oracle_avx512_mmr_build_pow2.argtypes = [_u64p, C.c_size_t, _u64p, C.c_int]
+    lib.oracle_avx512_mmr_build_pow2.restype = C.c_int
+    return lib
+
+
+def avx512_permute_batch(lib, states):
+    a = _arr(states, (-1, 12))
+    out = np.empty_like(a)
+    lib.oracle_avx512_permute_batch(_ptr(a), _ptr(out), a.shape[0])
+    return out
+
+
+def avx512_mmr_build_pow2(lib, leaves, threads=1):
+    a = _arr(leaves)
+    el = np.empty((2 * a.size - 1, 4), np.uint64)
+    used = lib.oracle_avx512_mmr_build_pow2(_ptr(a), a.size, _ptr(el), threads)
+    return el, used
+
+
+def avx512_mmr_build_pow2_into(lib, leaves, el, threads=1):
+    """the same into a caller-owned (already resident) node array"""
+    a = _arr(leaves)
+    assert el.shape == (2 * a.size - 1, 4) and el.dtype == np.uint64 and el.flags.c_contiguous
+    used = lib.oracle_avx512_mmr_build_pow2(_ptr(a), a.size, _ptr(el), threads)
+    return el, used
+
+
 def _bind_fast(lib):
     lib.oracle_fast_poseidon_permute.argtypes = [_u64p]
     lib.oracle_fast_two_to_one_batch.argtypes = [_u64p, _u64p, C.c_size_t]

@@ -300,6 +300,30 @@ def test_fast_port_equals_spec_form(oracle):
     assert np.array_equal(el, oracle.mmr(leaves[:1 << 10]).elements)
 
 
+def test_avx512_port_equals_spec_form(oracle):
+    """oracle/poseidon_avx512.c (bench.py's cpu_baseline.port_fast on hosts with AVX-512: eight permutations per zmm lane set) is
+    the same function as the spec-form restatement: edge values in every lane position, random states, ragged batch sizes, and
+    the level-order MMR build."""
+    import oracle_lib
+    lib = oracle_lib.build_avx512_port_native()
+    if lib is None:
+        pytest.skip("no AVX-512 on this host")
+    rng = np.random.default_rng(29)
+    edge = [np.zeros(12, np.uint64), np.full(12, P - 1, np.uint64), np.full(12, 2**64 - 1, np.uint64), np.full(12, P, np.uint64),
+            np.arange(12, dtype=np.uint64), np.full(12, 2**32 - 1, np.uint64), np.full(12, 2**63, np.uint64)]
+    states = np.stack(edge + [rng.integers(0, 2**64, size=12, dtype=np.uint64) for _ in range(300)])
+    for n in (1, 7, 8, 9, len(states)):
+        got = oracle_lib.avx512_permute_batch(lib, states[:n])
+        for g, s in zip(got, states[:n]):
+            assert np.array_equal(g, oracle.permute(s))
+    leaves = rng.integers(0, 2**64, size=1 << 10, dtype=np.uint64)
+    for threads in (1, 3):
+        el, _ = oracle_lib.avx512_mmr_build_pow2(lib, leaves, threads)
+        assert np.array_equal(el, oracle.mmr(leaves % np.uint64(P)).elements)
+    el, _ = oracle_lib.avx512_mmr_build_pow2(lib, leaves[:4], 1)  # fewer nodes per level than lanes
+    assert np.array_equal(el, oracle.mmr(leaves[:4] % np.uint64(P)).elements)
+
+
 def test_plonky2_digest_layout_restatement(oracle):
     """oracle/merkle_cap.py (plonky2's fill_subtree order + MerkleTree::prove's index formula) agrees with the level-major cap
     tree of the C oracle: same cap, and every Merkle path read through plonky2's indexing equals the level-major walk."""
