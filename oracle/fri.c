@@ -289,13 +289,23 @@ int oracle_fri_prove(const oracle_fri_oracle *oracles, size_t n_oracles, const o
   for (size_t i = 0; i < final_len; ++i) { final_words[2 * i] = coeffs[i].a; final_words[2 * i + 1] = coeffs[i].b; }
   oracle_challenger_observe(ch, final_words, 2 * final_len);
 
-  /* fri_proof_of_work: smallest witness whose response has proof_of_work_bits leading zeros */
+  /* fri_proof_of_work: smallest witness whose response has proof_of_work_bits leading zeros.  The response of a candidate is
+   * `observe(witness); get_challenge()` on a copy of the transcript -- one duplexing: the buffered inputs and the candidate
+   * overwrite the front of the sponge state, one permutation, Vec::pop of the first eight words = word 7.  The grind is ~2^16 of
+   * those, so it runs on the tuned port (oracle/poseidon_fast.c, same function as oracle_poseidon_permute) with the state set
+   * up once; the accepted witness goes through the ordinary challenger below. */
   uint64_t witness = 0;
-  for (;; ++witness) {
-    oracle_challenger t = *ch;
-    oracle_challenger_observe(&t, &witness, 1);
-    const uint64_t resp = oracle_challenger_get(&t);
-    if (p->proof_of_work_bits == 0 || (resp >> (64 - p->proof_of_work_bits)) == 0) break;
+  if (p->proof_of_work_bits && ch->n_in < 8) {
+    uint64_t base[12];
+    memcpy(base, ch->state, sizeof base);
+    for (uint32_t i = 0; i < ch->n_in; ++i) base[i] = ch->in[i];
+    for (;; ++witness) {
+      uint64_t st[12];
+      memcpy(st, base, sizeof st);
+      st[ch->n_in] = witness; /* canonical: the search stays far below p */
+      oracle_fast_poseidon_permute(st);
+      if ((st[7] >> (64 - p->proof_of_work_bits)) == 0) break;
+    }
   }
   oracle_challenger_observe(ch, &witness, 1);
   (void)oracle_challenger_get(ch); /* pow_response */
