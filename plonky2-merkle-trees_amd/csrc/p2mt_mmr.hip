@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
 // ONE inlined permutation.  Pending left siblings (at most one per height) live in a per-lane LDS stack; the control
 // flow is the binary-counter carry chain and is identical in all lanes.  A lane's 2^(LV+1)-1 nodes are a contiguous
 // post-order span, written node by node.  HBM traffic is the same algorithmic minimum as k_mmr_tile.
-template <unsigned LV, int BLK>
+template <unsigned LV, int BLK, int PR = 0>
 __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ leaves, size_t leaf_base,
                                                      u64* __restrict__ elements, size_t block0, size_t n_blocks,
                                                      PermCtx ctx) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
       const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
       store_hash(elements + 4 * (pos - 2), la);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
       store_hash(elements + 4 * (pos - 1), lb);
-      two_to_one_r<IMPL_FAST, 0, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {  // leaf pair: 10 of the 12 first S-boxes are constants
+      two_to_one_r<IMPL_FAST, PR, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {  // leaf pair: 10 of the 12 first S-boxes are constants
         ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
         rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
       });
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
       store_hash(elements + 4 * pos, o);
     } else {  // merge the pending left sibling of height h with cur
       const u64* sp = &stack[h - 1][threadIdx.x * 4];
-      two_to_one_r<IMPL_FAST, 0>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+      two_to_one_r<IMPL_FAST, PR>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
         load_hash(sp, ll);
 #pragma unroll
         for (int k = 0; k < 4; ++k) rr[k] = cur[k];
@@ -536,7 +536,10 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
   hipLaunchKernelGGL((k_mmr_subtree<LVV, BB>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, a >> span_log, \
                      n_blocks, p2mt::perm_ctx())
       if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64); else P2MT_SUB(5, 256); }
-      else { if (sb == 64) P2MT_SUB(4, 64); else if (sb == 128) P2MT_SUB(4, 128); else P2MT_SUB(4, 256); }
+      else if (rt().partial) {  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 1>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
+                           m->elements, a >> span_log, n_blocks, p2mt::perm_ctx());
+      } else { if (sb == 64) P2MT_SUB(4, 64); else if (sb == 128) P2MT_SUB(4, 128); else P2MT_SUB(4, 256); }
 #undef P2MT_SUB
       P2MT_LAUNCH_CHECK();
       p2mt::prof_end(prof_slot);

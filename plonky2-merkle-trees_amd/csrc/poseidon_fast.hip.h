@@ -187,6 +187,60 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
   });
 }
 
+// ------------------------------------------------------------------ sparse partial rounds (SPARSE = true)
+// plonky2's "fast" partial rounds (poseidon.rs partial_first_constant_layer / mds_partial_layer_init / mds_partial_layer_fast):
+//   s += FIRST;  s[1..] = INIT * s[1..]  (11 x 11, once);  22 x { s0 = sbox(s[0]) + K_r;  d = 25 s0 + sum_j W_rj s[j];
+//                                                               s[j] += V_rj s0;  s[0] = d }
+// with full 64-bit constants.  A dense round costs 26 v_mad_u64_u32 per MDS row because the MDS entries are 6-bit numbers; here a
+// term of a dot product costs 6: the constant is split into limbs of 22 + 22 + 20 bits and the state word into its two dwords,
+// so that all six 32 x 22-bit partial products of a term accumulate in 64-bit registers without ever overflowing (12 terms x
+// 2^54 < 2^58) -- no carry handling per product.  The six sums are put together and reduced once per dot product.
+// Table layout behind the round constants (u64 indices from ctx.rc; runtime.hip builds it):
+constexpr int kSpFirst = 370;                  // 12: FAST_PARTIAL_FIRST_ROUND_CONSTANT
+constexpr int kSpK = 382;                      // 22: FAST_PARTIAL_ROUND_CONSTANTS
+constexpr int kSpV = 404;                      // 22 x 11: FAST_PARTIAL_ROUND_VS
+constexpr int kSpW = 646;                      // 22 x 11 x {limb0, limb1, limb2, 0} as u32: FAST_PARTIAL_ROUND_W_HATS
+constexpr int kSpInit = kSpW + 22 * 11 * 2;    // 11 x 11 x {limb0, limb1, limb2, 0}: FAST_PARTIAL_ROUND_INITIAL_MATRIX
+constexpr int kSpTableWords = kSpInit + 121 * 2;
+
+struct Dot {
+  u64 a0l, a0h, a1l, a1h, a2l, a2h;
+};
+// first term: no addend
+GL_DEV void dot_first(Dot& d, u64 x, const u32* __restrict__ w) {
+  const u32 xl = (u32)x, xh = (u32)(x >> 32);
+  d.a0l = (u64)xl * w[0], d.a0h = (u64)xh * w[0];
+  d.a1l = (u64)xl * w[1], d.a1h = (u64)xh * w[1];
+  d.a2l = (u64)xl * w[2], d.a2h = (u64)xh * w[2];
+}
+GL_DEV void dot_term(Dot& d, u64 x, const u32* __restrict__ w) {
+  const u32 xl = (u32)x, xh = (u32)(x >> 32);
+  d.a0l += (u64)xl * w[0], d.a0h += (u64)xh * w[0];
+  d.a1l += (u64)xl * w[1], d.a1h += (u64)xh * w[1];
+  d.a2l += (u64)xl * w[2], d.a2h += (u64)xh * w[2];
+}
+// sum_k (a_kl + a_kh 2^32) 2^(22 k) mod p, every accumulator < 2^59.  Loose result; rare corrections go to `sticky`.
+GL_DEV u64 dot_finish(const Dot& d, u64& sticky) {
+  using u128 = unsigned __int128;
+  // T_k = t + U 2^32 with U = (a_kl >> 32) + a_kh < 2^60; U = ul + uh 2^32  =>  T_k = (t + ul 2^32) + uh (2^32 - 1)  (mod p), < 2^65
+  auto fold = [](u64 al, u64 ah) -> u128 {
+    const u64 U = add32((u32)(al >> 32), ah);
+    const u64 low = ((u64)(u32)U << 32) | (u32)al;
+    const u64 uh = U >> 32;  // < 2^28
+    return (u128)low + (((u64)uh << 32) - uh);
+  };
+  const u128 v = fold(d.a0l, d.a0h) + (fold(d.a1l, d.a1h) << 22) + (fold(d.a2l, d.a2h) << 44);  // < 2^110
+  return reduce128((u64)v, (u64)(v >> 64), sticky);
+}
+// x * k + c (mod p), all three any u64
+GL_DEV u64 mul_add_flag(u64 x, u64 k, u64 c, u64& sticky) {
+  u64 lo, hi;
+  mul_wide(x, k, lo, hi);
+  const u64 l = lo + c;
+  hi += (l < c);  // x k + c < 2^128
+  return reduce128(l, hi, sticky);
+}
+
 // Input: any u64 words.  Output: loose u64 words, valid iff the returned sticky mask is 0 for the whole wave.
 // `rc`: the 360 round constants in GLOBAL memory (kernel argument: base + immediate offsets let the compiler
 // fetch a whole round with wide s_load_dwordx8/x16; the __constant__ symbol would cost a PC-relative address
@@ -199,7 +253,8 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
 // LEAF_PAIR (with CAP_ZERO): the caller additionally guarantees s[1..3] == s[5..7] == 0 -- two_to_one of two leaf digests
 //   [leaf, 0, 0, 0] (hash_or_noop's zero padding, quirk Q1), i.e. half of all hashes of a tree build.  Only words 0 and 4 go
 //   through the first S-box layer; the other ten S-box outputs are the constants (rc[i])^7, read from rc[360 + ..].
-template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false>
+// SPARSE: the 22 partial rounds in the sparse form above (same function; the dense form is the default and the redo path).
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
   u64 sticky = 0;
   auto sbox = [&](u64 x) -> u64 {
@@ -230,16 +285,64 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
     }
     mds_layer<true, 12, EXACT>(s, rc + 12, sticky);
   }
+  static_assert(!(SPARSE && EXACT), "the exact redo path keeps the dense partial rounds");
 #pragma unroll 1
-  for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS; ++r) {
+  for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS - (SPARSE ? 1 : 0); ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
     mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
   }
+  if constexpr (SPARSE) {
+    {  // last full round of the first half: the addend of its MDS layer is FIRST instead of round 4's constants
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+      mds_layer<true, 12, false>(s, rc + kSpFirst, sticky);
+    }
+    {  // s[1..] = INIT * s[1..]
+      u64 t[11];
+      const u32* init = reinterpret_cast<const u32*>(rc + kSpInit);
+#pragma unroll
+      for (int rr = 0; rr < 11; ++rr) {
+        Dot d;
+        dot_first(d, s[1], init + 4 * (11 * rr));
+#pragma unroll
+        for (int c = 1; c < 11; ++c) dot_term(d, s[c + 1], init + 4 * (11 * rr + c));
+        t[rr] = dot_finish(d, sticky);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 11; ++rr) s[rr + 1] = t[rr];
+    }
 #pragma unroll 1
-  for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {
-    s[0] = sbox(s[0]);
-    mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
+    for (int pr = 0; pr < POSEIDON_PARTIAL_ROUNDS; ++pr) {
+      const u64 s0 = gl::add_c(sbox(s[0]), rc[kSpK + pr]);
+      const u32* w = reinterpret_cast<const u32*>(rc + kSpW) + 4 * 11 * pr;
+      const u64* v = rc + kSpV + 11 * pr;
+      Dot d;
+      {  // 25 s0: limb 0 only
+        const u32 xl = (u32)s0, xh = (u32)(s0 >> 32);
+        d.a0l = (u64)xl * 25u, d.a0h = (u64)xh * 25u;
+      }
+      {
+        const u32 xl = (u32)s[1], xh = (u32)(s[1] >> 32);
+        d.a0l += (u64)xl * w[0], d.a0h += (u64)xh * w[0];
+        d.a1l = (u64)xl * w[1], d.a1h = (u64)xh * w[1];
+        d.a2l = (u64)xl * w[2], d.a2h = (u64)xh * w[2];
+      }
+#pragma unroll
+      for (int j = 1; j < 11; ++j) dot_term(d, s[j + 1], w + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 11; ++j) s[j + 1] = mul_add_flag(s0, v[j], s[j + 1], sticky);
+      s[0] = dot_finish(d, sticky);
+    }
+    // the constants of the first full round of the second half (the dense form folds them into the previous MDS layer)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[12 * (POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS) + i]);
+  } else {
+#pragma unroll 1
+    for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {
+      s[0] = sbox(s[0]);
+      mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
+    }
   }
 #pragma unroll 1
   for (int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; r < POSEIDON_ROUNDS - 1; ++r) {

@@ -192,6 +192,7 @@ int verify_fri_queries_host(const p2mt_fri_params& p, const uint64_t* n_polys, s
 
 // Launch KERNEL<mds, partial> for the runtime-selected Poseidon variant on the library stream; the PermCtx is
 // appended as the last kernel argument.  mds 2 = issue-optimised path (default), 0/1 = exact reference variants.
+// (mds 2, partial 1 -- the fast path's sparse partial rounds, an A/B that lost -- exists for the stage-1 MMR kernel only.)
 #define P2MT_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                              \
   do {                                                                                                       \
     hipStream_t st_ = p2mt::rt().stream;                                                                     \

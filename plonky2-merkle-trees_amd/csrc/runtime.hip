@@ -227,8 +227,22 @@ extern "C" int p2mt_init(int device) {
   if (rt().d_rc) (void)hipFree(rt().d_rc);
   {  // 360 round constants + first-round S-box outputs of words that are zero on entry, (rc[i])^7: [360..364) words 8..11 (the
      // capacity of two_to_one), [364..367) words 1..3 and [367..370) words 5..7 (two_to_one of two leaf digests [leaf, 0, 0, 0])
-    uint64_t table[370];
+    // behind them the tables of the sparse partial rounds (poseidon_fast.hip.h kSp*: FIRST, K, V, then W_HAT and INIT as limbs of
+    // 22 + 22 + 20 bits in four u32 per constant)
+    static uint64_t table[1372];
+    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
+    memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
+    memcpy(table + 382, POSEIDON_FAST_K, sizeof(POSEIDON_FAST_K));
+    memcpy(table + 404, POSEIDON_FAST_V, sizeof(POSEIDON_FAST_V));
+    {
+      uint32_t* w = reinterpret_cast<uint32_t*>(table + 646);
+      auto limbs = [](uint64_t c, uint32_t* out) {
+        out[0] = (uint32_t)(c & 0x3FFFFF), out[1] = (uint32_t)((c >> 22) & 0x3FFFFF), out[2] = (uint32_t)(c >> 44), out[3] = 0;
+      };
+      for (int i = 0; i < 242; ++i) limbs(POSEIDON_FAST_W_HAT[i], w + 4 * i);
+      for (int i = 0; i < 121; ++i) limbs(POSEIDON_FAST_INIT[i], w + 4 * (242 + i));
+    }
     const int word_of[10] = {8, 9, 10, 11, 1, 2, 3, 5, 6, 7};
     for (int i = 0; i < 10; ++i) {
       const unsigned __int128 p = 0xFFFFFFFF00000001ULL;

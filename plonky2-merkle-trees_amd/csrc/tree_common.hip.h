@@ -43,8 +43,8 @@ constexpr int IMPL_FAST = 2;  // M == 2: poseidon_fast with exact fallback; M in
 template <int M, int PR, typename Load>
 GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load) {
   load(s);
-  if constexpr (M == IMPL_FAST) {
-    const u64 sticky = poseidon_fast::permute(s, ctx.rc) | ctx.force_fallback;
+  if constexpr (M == IMPL_FAST) {  // PR == 1: sparse partial rounds
+    const u64 sticky = poseidon_fast::permute<false, 12, false, false, PR == 1>(s, ctx.rc) | ctx.force_fallback;
     if (__builtin_expect(sticky != 0, 0)) {
       load(s);
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
@@ -70,7 +70,7 @@ GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr) {
   };
   if constexpr (M == IMPL_FAST) {  // capacity words are zero and only 4 output words are needed
     load(s);
-    const u64 sticky = poseidon_fast::permute<true, 4, false, LEAF_PAIR>(s, ctx.rc) | ctx.force_fallback;
+    const u64 sticky = poseidon_fast::permute<true, 4, false, LEAF_PAIR, PR == 1>(s, ctx.rc) | ctx.force_fallback;
     if (__builtin_expect(sticky != 0, 0)) {  // ~0.5 % of waves.  (Redoing with the exact fast-form instead was
       load(s);                               //  measured 2 % slower overall: bigger kernel, worse allocation.)
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
@@ -98,7 +98,7 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (off + k < len) s[k] = get(off + k);
-      if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute(s, ctx.rc);
+      if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, PR == 1>(s, ctx.rc);
       else if constexpr (M == IMPL_FAST) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
       else poseidon::permute<M, PR>(s);
     }

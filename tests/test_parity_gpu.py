@@ -250,6 +250,25 @@ def test_mmr_tiled_build_ragged(pkg, oracle):
     assert np.array_equal(b.bagging_the_peaks(), om.bagging_the_peaks())
 
 
+def test_stage1_sparse_partial_rounds_variant(pkg, oracle):
+    """Variant (2, 1): the stage-1 MMR kernel with the fast path's SPARSE partial rounds (plonky2's mds_partial_layer_fast in
+    flag-form arithmetic; an A/B that lost by 2.3 %, profiles/r02_sparse_flag_form_ab.txt, kept selectable) is the same function:
+    all nodes equal the oracle's, with and without the forced exact redo."""
+    n = (1 << 16) + 4099
+    leaves = splitmix_leaves(n, 0x5EED0177)
+    om = oracle.mmr(leaves)
+    try:
+        pkg.set_variant(2, 1)
+        a = pkg.MMR.from_leaves(leaves)
+        assert np.array_equal(a.elements, om.elements)
+        pkg.lib().p2mt_debug_force_fallback(1)
+        b = pkg.MMR.from_leaves(leaves[:1 << 12])
+        assert np.array_equal(b.elements, oracle.mmr(leaves[:1 << 12]).elements)
+    finally:
+        pkg.lib().p2mt_debug_force_fallback(0)
+        pkg.set_variant(*DEFAULT_VARIANT)
+
+
 def test_mmr_checkpoint_roundtrip(pkg, oracle, tmp_path):
     """save -> load -> extend continues exactly where the saved MMR stopped; corrupted files are rejected."""
     leaves = splitmix_leaves(3000, 0x5EED0099)
