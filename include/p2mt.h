@@ -414,6 +414,14 @@ int p2mt_circuit_prove(p2mt_circuit_data *c, const p2mt_partial_witness *pw, uin
  * hipSetDeviceFlags(hipDeviceScheduleBlockingSync) before the first HIP call of the process. */
 int p2mt_circuit_prove_many(p2mt_circuit_data *const *circuits, size_t n_handles, const p2mt_partial_witness *const *witnesses,
                             size_t n, uint64_t *proofs_out, size_t proof_stride, int *status_out);
+/* ProofWithPublicInputs::to_bytes() / from_bytes() in plonky2's Buffer order (util/serialization.rs @3b21b87d; SURVEY.md
+ * App. B.5; recalled -- parity unpinned): field elements as 8 little-endian bytes, extension elements as two of them, caps /
+ * openings / evaluations / final polynomial without length prefixes, every MerkleProof as one length byte + its sibling hashes.
+ * = the words of p2mt_circuit_prove plus one byte in front of each of the 28 x (4 + layers) Merkle paths.  Host only.
+ * from_bytes rejects a wrong total length, a path length that does not match the circuit and non-canonical elements. */
+size_t p2mt_proof_bytes_len(const p2mt_circuit_data *c);
+int p2mt_proof_to_bytes(const p2mt_circuit_data *c, const uint64_t *proof, size_t proof_len, uint8_t *bytes_out, size_t bytes_cap);
+int p2mt_proof_from_bytes(const p2mt_circuit_data *c, const uint8_t *bytes, size_t n_bytes, uint64_t *proof_out, size_t proof_cap);
 /* Batched prover: up to `batch` proofs of ONE circuit per pass of the pipeline, the proof index riding in a grid dimension of
  * every launch (a pass costs the ~44 dispatch packets of one proof; the per-proof path above is bound by the device's packet
  * rate when many provers run).  Any circuit p2mt_cb_build accepts: the reference's MMR-verifier circuits

@@ -232,6 +232,20 @@ class CircuitData:
         N.check(N.lib().p2mt_circuit_prove(self._h, pw._h, N.ptr(proof), proof.size))
         return proof
 
+    def proof_to_bytes(self, proof):
+        """ProofWithPublicInputs::to_bytes() in plonky2's Buffer order (one length byte in front of every Merkle path)"""
+        p = N.as_u64(proof).reshape(-1)
+        out = np.zeros(N.lib().p2mt_proof_bytes_len(self._h), np.uint8)
+        N.check(N.lib().p2mt_proof_to_bytes(self._h, N.ptr(p), p.size, out.ctypes.data_as(C.c_void_p), out.size))
+        return out.tobytes()
+
+    def proof_from_bytes(self, data):
+        """ProofWithPublicInputs::from_bytes(bytes, &common_data) -> proof words"""
+        b = np.frombuffer(bytes(data), np.uint8)
+        out = np.zeros(self.info.proof_len, np.uint64)
+        N.check(N.lib().p2mt_proof_from_bytes(self._h, b.ctypes.data_as(C.c_void_p), b.size, N.ptr(out), out.size))
+        return out
+
     def verify(self, proof, with_reason=False):
         """circuit_data.verify(proof): raises P2mtPanic (plonky2 returns Err) unless the proof is accepted; with_reason=True
         returns (accepted, reason) instead (reasons: include/p2mt.h)."""

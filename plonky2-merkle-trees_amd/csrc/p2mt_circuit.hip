@@ -2600,3 +2600,101 @@ extern "C" int p2mt_batch_prover_prove(p2mt_batch_prover* b, const p2mt_partial_
 }
 
 extern "C" size_t p2mt_batch_prover_batch(const p2mt_batch_prover* b) { return b ? b->B : 0; }
+
+// ==================================================================================================== proof bytes
+// ProofWithPublicInputs::to_bytes / from_bytes in plonky2's Buffer order (util/serialization.rs @3b21b87d, absent from the
+// reference tree -- SURVEY.md App. B.5; recalled, parity unpinned): every field element 8 bytes little endian, an extension
+// element as its two coefficients; caps, openings, evaluations and the final polynomial carry no length (CommonCircuitData
+// fixes them); a MerkleProof is ONE length byte (number of siblings) followed by the sibling hashes.  The word form of
+// p2mt_circuit_prove has exactly that order without the length bytes, so the byte form is the words plus one byte in front of
+// each Merkle path: 28 x (4 oracle paths + one per FRI layer).
+namespace {
+struct ProofShape {
+  size_t head_words;                 // 3 caps + openings
+  size_t caps_words;                 // commit-phase caps
+  std::vector<std::pair<size_t, size_t>> per_query;  // (row / evals words, sibling count) per opened tree, in order
+  size_t tail_words;                 // final polynomial + pow witness + public inputs
+  size_t n_queries;
+};
+ProofShape proof_shape(const p2mt_circuit_data* c) {
+  ProofShape sh;
+  const size_t n_open = c->n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
+  const p2mt_fri_params& f = c->fri;
+  const unsigned log_big = f.degree_bits + f.rate_bits;
+  sh.head_words = 3 * 64 + 2 * n_open;
+  sh.caps_words = (size_t)f.num_reductions * ((size_t)4 << f.cap_height);
+  const size_t polys[4] = {c->n_cs, kNumWires, kNumZs, kNumQuot};
+  for (size_t o = 0; o < 4; ++o) sh.per_query.emplace_back(polys[o], (size_t)(log_big - f.cap_height));
+  unsigned log_sz = log_big, arity_total = 0;
+  for (uint32_t l = 0; l < f.num_reductions; ++l) {
+    const unsigned ab = f.reduction_arity_bits[l];
+    sh.per_query.emplace_back((size_t)2 << ab, (size_t)(log_sz - ab - f.cap_height));
+    log_sz -= ab;
+    arity_total += ab;
+  }
+  sh.n_queries = f.num_query_rounds;
+  sh.tail_words = ((size_t)2 << (f.degree_bits - arity_total)) + 1 + c->n_pi;
+  return sh;
+}
+inline void put_le(uint8_t* dst, u64 w) {
+  for (int k = 0; k < 8; ++k) dst[k] = (uint8_t)(w >> (8 * k));
+}
+inline u64 get_le(const uint8_t* src) {
+  u64 w = 0;
+  for (int k = 0; k < 8; ++k) w |= (u64)src[k] << (8 * k);
+  return w;
+}
+}  // namespace
+
+extern "C" size_t p2mt_proof_bytes_len(const p2mt_circuit_data* c) {
+  if (!c) return 0;
+  const ProofShape sh = proof_shape(c);
+  return c->proof_len * 8 + sh.n_queries * sh.per_query.size();
+}
+
+extern "C" int p2mt_proof_to_bytes(const p2mt_circuit_data* c, const uint64_t* proof, size_t proof_len, uint8_t* bytes_out,
+                                   size_t bytes_cap) {
+  if (!c || !proof || !bytes_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (proof_len != c->proof_len) return p2mt::fail(P2MT_EINVAL, "proof_to_bytes: wrong proof length for this circuit");
+  if (bytes_cap < p2mt_proof_bytes_len(c)) return p2mt::fail(P2MT_EINVAL, "proof_to_bytes: output buffer too small (p2mt_proof_bytes_len)");
+  const ProofShape sh = proof_shape(c);
+  const uint64_t* w = proof;
+  uint8_t* b = bytes_out;
+  auto words = [&](size_t n) {
+    for (size_t i = 0; i < n; ++i, b += 8) put_le(b, *w++);
+  };
+  words(sh.head_words + sh.caps_words);
+  for (size_t q = 0; q < sh.n_queries; ++q)
+    for (const auto& t : sh.per_query) {
+      words(t.first);
+      *b++ = (uint8_t)t.second;  // MerkleProof: siblings.len() as one byte
+      words(4 * t.second);
+    }
+  words(sh.tail_words);
+  if ((size_t)(w - proof) != proof_len) return p2mt::fail(P2MT_EHIP, "proof_to_bytes: internal layout mismatch");
+  return P2MT_OK;
+}
+
+extern "C" int p2mt_proof_from_bytes(const p2mt_circuit_data* c, const uint8_t* bytes, size_t n_bytes, uint64_t* proof_out,
+                                     size_t proof_cap) {
+  if (!c || !bytes || !proof_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (proof_cap < c->proof_len) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: proof buffer too small");
+  if (n_bytes != p2mt_proof_bytes_len(c)) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: wrong length for this circuit");
+  const ProofShape sh = proof_shape(c);
+  const uint8_t* b = bytes;
+  uint64_t* w = proof_out;
+  auto words = [&](size_t n) {
+    for (size_t i = 0; i < n; ++i, b += 8) *w++ = get_le(b);
+  };
+  words(sh.head_words + sh.caps_words);
+  for (size_t q = 0; q < sh.n_queries; ++q)
+    for (const auto& t : sh.per_query) {
+      words(t.first);
+      if (*b++ != (uint8_t)t.second) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: Merkle path length does not match the circuit");
+      words(4 * t.second);
+    }
+  words(sh.tail_words);
+  for (size_t i = 0; i < c->proof_len; ++i)  // plonky2's read_field rejects non-canonical encodings
+    if (proof_out[i] >= gl::P) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: non-canonical field element");
+  return P2MT_OK;
+}

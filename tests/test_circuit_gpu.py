@@ -482,6 +482,37 @@ def test_prove_many(pkg, oracle):
         pkg.prove_many([handles[0][0], handles[0][0]], pws[:2])  # the same handle twice
 
 
+def test_proof_bytes_roundtrip(pkg, oracle):
+    """ProofWithPublicInputs::to_bytes / from_bytes in plonky2's Buffer order (SURVEY App. B.5): the words plus one length byte in
+    front of each of the 28 x (4 + layers) Merkle paths; from_bytes restores the words, verify accepts them, and malformed byte
+    strings (length, path-length byte, non-canonical element) are rejected."""
+    cd, pw, _, _ = build_both(pkg, oracle, synthetic_case(oracle, 20, 321))
+    proof = cd.prove(pw)
+    data = cd.proof_to_bytes(proof)
+    n_pi, layers = cd.info.num_public_inputs, 1  # degree 2^6: one arity-16 reduction
+    assert len(data) == 8 * proof.size + 28 * (4 + layers)
+    assert np.array_equal(np.frombuffer(data[:64 * 8], "<u8"), proof[:64])              # the wires cap, little endian
+    assert np.array_equal(np.frombuffer(data[-8 * n_pi:], "<u8"), proof[-n_pi:])        # public inputs close the byte string
+    n_cs = cd.info.num_selectors + 2 + 80                                               # constants_sigmas polynomials
+    n_open = n_cs + 135 + 2 * 2 + 2 * 9 + 16
+    first_len = 8 * (3 * 64 + 2 * n_open + layers * 64 + n_cs)                          # behind the first opened leaf row
+    assert data[first_len] == 9 - 4                                                    # 2^9 leaves, 2^4 cap: 5 siblings
+    assert np.array_equal(np.frombuffer(data[first_len + 1:first_len + 1 + 32], "<u8"),
+                          proof[3 * 64 + 2 * n_open + layers * 64 + n_cs:][:4])
+    back = cd.proof_from_bytes(data)
+    assert np.array_equal(back, proof) and cd.verify(back)
+    with pytest.raises(pkg.P2mtPanic):
+        cd.proof_from_bytes(data[:-1])
+    bad = bytearray(data)
+    bad[24:32] = b"\xff" * 8  # word 3 := 2^64 - 1: not canonical
+    with pytest.raises(pkg.P2mtPanic, match="canonical"):
+        cd.proof_from_bytes(bytes(bad))
+    bad = bytearray(data)
+    bad[first_len] = 6
+    with pytest.raises(pkg.P2mtPanic, match="path length"):
+        cd.proof_from_bytes(bytes(bad))
+
+
 def test_lds_limit_is_only_raised(pkg, oracle):
     """The dynamic-LDS limit of the witness kernel is a property of the kernel: building a smaller circuit after a larger
     one must not lower it under the larger one's feet (200 path elements -> ~90 KB table, then 100 -> ~70 KB, then prove both)."""
