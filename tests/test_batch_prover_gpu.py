@@ -163,3 +163,36 @@ def test_batch_of_recursion_proofs(pkg, oracle):
     for g, w in zip(outer_got, outer_want):
         assert np.array_equal(g, w)
     assert outer.verify(outer_got[-1])
+
+
+def test_batch_provers_on_two_threads(pkg, oracle):
+    """Two host threads, each with its own stream, circuit handle and batch prover (the shape bench.py's throughput leg uses): the
+    per-thread batch context and scratch keep the passes apart; all proofs equal the sequential ones."""
+    import threading
+    seeds = [range(600, 612), range(620, 632)]
+    want, got, errs = [None, None], [None, None], []
+    for i, sd in enumerate(seeds):
+        cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, sd)
+        want[i] = [cd.prove(pw) for pw in pws]
+
+    def worker(i):
+        try:
+            pkg._native.check(pkg.lib().p2mt_thread_stream_create())
+            cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, seeds[i])
+            bp = pkg.BatchProver(cd, 8)
+            for _ in range(3):
+                got[i] = bp.prove(pws)
+            del bp, cd, pws
+            pkg._native.check(pkg.lib().p2mt_thread_stream_destroy())
+        except Exception as e:  # surfaced below
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for g, w in zip(got[i], want[i]):
+            assert np.array_equal(g, w)
