@@ -503,6 +503,15 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
     for _ in range(args.steps):
         Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
     out["verify_ms"] = (time.perf_counter() - t0) * 1e3 / args.steps
+    # batched verify: 256 proofs per pass (transcripts and Merkle paths with the proof index in grid z, field arithmetic on host threads)
+    many = np.ascontiguousarray(np.tile(proof, (256, 1)))
+    accs, reasons = (C.c_int * 256)(), (C.c_int * 256)()
+    Nn.check(lib.p2mt_circuit_verify_batch(cd._h, Nn.ptr(many), 256, many.shape[1], accs, reasons))
+    assert all(accs), "batched verify rejects the product's proof"
+    t0 = time.perf_counter()
+    for _ in range(5):
+        Nn.check(lib.p2mt_circuit_verify_batch(cd._h, Nn.ptr(many), 256, many.shape[1], accs, reasons))
+    out["verify_batch_proofs_per_s"] = 5 * 256 / (time.perf_counter() - t0)
     if args.threads > 1:
         # throughput: one prover per host thread (own stream, circuit handle, witness), in a separate process so that it can
         # run with blocking synchronisation (a device flag that must precede the HIP context; it frees the host cores the

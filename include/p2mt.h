@@ -443,6 +443,10 @@ size_t p2mt_batch_prover_batch(const p2mt_batch_prover *b);
  * be NULL): 0 ok, 10 malformed (length / non-canonical word), 11 vanishing polynomial != Z_H * quotient at zeta, 1 proof of
  * work, 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 inconsistent layer value, 5 final polynomial. */
 int p2mt_circuit_verify(p2mt_circuit_data *c, const uint64_t *proof, size_t proof_len, int *accepted, int *reason);
+/* circuit_data.verify for n proofs of this circuit (proofs[i] at proofs + i * proof_stride words): passes of up to 256 proofs with
+ * the proof index in a grid dimension of every launch -- one transcript replay and one Merkle-path launch per pass -- and the
+ * field arithmetic of each proof on a few host threads.  accepted[i] / reason[i] as p2mt_circuit_verify. */
+int p2mt_circuit_verify_batch(p2mt_circuit_data *c, const uint64_t *proofs, size_t n, size_t proof_stride, int *accepted, int *reason);
 /* ---- the outer circuit of the recursion (mmr_plonky2_verifier_1_recursion.rs:84-140): plonky2's in-circuit verifier.
  * `inner` stands for `inner_circuit_data.common` (and `.verifier_only` for the witness): the built inner circuit.
  * A ProofWithPublicInputsTarget is a flat array of proof_len targets (the inner circuit's p2mt_circuit_info), one per word of the proof

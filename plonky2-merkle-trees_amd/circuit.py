@@ -258,6 +258,14 @@ class CircuitData:
             raise N.P2mtPanic(N.P2MT_EINVAL, "proof rejected (reason %d)" % reason.value)
         return True
 
+    def verify_batch(self, proofs):
+        """circuit_data.verify for many proofs in passes of up to 256 (p2mt_circuit_verify_batch) -> (accepted, reasons) lists"""
+        p = np.ascontiguousarray(N.as_u64(proofs).reshape(-1, self.info.proof_len))
+        n = p.shape[0]
+        acc, reason = (C.c_int * n)(), (C.c_int * n)()
+        N.check(N.lib().p2mt_circuit_verify_batch(self._h, N.ptr(p), n, p.shape[1], acc, reason))
+        return [bool(a) for a in acc], list(reason)
+
     def prove_trace(self):
         n = 1 << self.degree_bits
         out = {}

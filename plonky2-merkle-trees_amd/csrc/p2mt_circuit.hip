@@ -91,6 +91,10 @@ struct p2mt_circuit_data {
   p2mt_challenger* ch = nullptr;
   // verifier scratch (allocated on the first p2mt_circuit_verify)
   u64* d_verify = nullptr;
+  // batched verifier (p2mt_circuit_verify_batch): one block of the same layout per proof, a challenger state behind each
+  char* d_vbatch = nullptr;
+  size_t vbatch_cap = 0, vbatch_stride = 0;
+  p2mt_challenger* vbch = nullptr;
   // pinned host staging: [0..2) zeta, [2..4) err flags, [8..8+proof_len) proof, then the witness assignments (H2D)
   u64* h_pin = nullptr;
   size_t pin_pairs_off = 0;
@@ -1202,7 +1206,9 @@ __global__ __launch_bounds__(kBlock) void k_opening_set(const u64* __restrict__ 
 }
 
 // inverse of k_opening_set: the order the challenger observes (FriOpenings) from the proof's OpeningSet order
-__global__ __launch_bounds__(kBlock) void k_opening_unset(const u64* __restrict__ set_order, u64* __restrict__ out, u32 n_cs) {
+__global__ __launch_bounds__(kBlock) void k_opening_unset(const u64* __restrict__ set_order, u64* __restrict__ out, u32 n_cs, BatchArg ba) {
+  set_order = bp(set_order, ba);
+  out = bp(out, ba);
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
   const u32 a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot), total = a + 2 * kNumCh + tail;
   if (t >= total) return;
@@ -1219,7 +1225,10 @@ struct VItem {
   u32 leaf_off, width, index, sib_off, n_sib, cap_off;
 };
 __global__ __launch_bounds__(kBlock) void k_verify_merkle(const u64* __restrict__ words, const VItem* __restrict__ items, u32 n_items,
-                                                          int* bad, PermCtx ctx) {
+                                                          int* bad, BatchArg ba, PermCtx ctx) {
+  words = bp(words, ba);
+  items = bp(items, ba);
+  bad = bp(bad, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   const u32 item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -1727,6 +1736,8 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (c->ch) p2mt_challenger_destroy(c->ch);
   if (c->vch) p2mt_challenger_destroy(c->vch);
   if (c->d_verify) (void)hipFree(c->d_verify);
+  if (c->vbch) p2mt::challenger_unwrap(c->vbch);
+  if (c->d_vbatch) (void)hipFree(c->d_vbatch);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->d_base) {
     (void)hipStreamSynchronize(rt().stream);
@@ -2254,6 +2265,186 @@ extern "C" int p2mt_circuit_prove_trace(const p2mt_circuit_data* c, int what, ui
 // two small copies), the field arithmetic on the host (p2mt_verify_host.hip).  *accepted = 1/0; *reason: 0 ok, 10 malformed
 // (length, non-canonical word), 11 vanishing polynomial != Z_H * quotient at zeta (or zeta in the subgroup), 1 proof of work,
 // 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 layer value inconsistent, 5 final polynomial.
+namespace {
+// device layout of one proof under verification: digest | pi_hash | proof | cs_cap | openings in transcript order | challenges |
+// flag | Merkle items
+struct VLayout {
+  size_t n_open, off_open, off_fri, off_pi, off_final, final_len, nq, max_items;
+  size_t o_proof, o_cscap, o_fo, o_out, n_out, o_flag, o_items, words;
+  u32 nred;
+};
+VLayout verify_layout(const p2mt_circuit_data* c) {
+  VLayout L;
+  L.nred = c->fri.num_reductions;
+  L.n_open = c->n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
+  L.off_open = 192, L.off_fri = L.off_open + 2 * L.n_open, L.off_pi = c->proof_len - c->n_pi;
+  unsigned total_arity = 0;
+  for (u32 l = 0; l < L.nred; ++l) total_arity += c->fri.reduction_arity_bits[l];
+  L.final_len = (size_t)1 << (c->degree_bits - total_arity), L.nq = c->fri.num_query_rounds;
+  L.off_final = L.off_fri + c->fri_len - 1 - 2 * L.final_len;
+  L.max_items = L.nq * (4 + L.nred);
+  L.o_proof = 8, L.o_cscap = L.o_proof + c->proof_len, L.o_fo = L.o_cscap + 64, L.o_out = L.o_fo + 2 * L.n_open;
+  L.n_out = 8 + 2 + 2 * 8 + 1 + L.nq, L.o_flag = L.o_out + L.n_out + 1, L.o_items = L.o_flag + 1;
+  L.words = L.o_items + (L.max_items * sizeof(VItem) + 7) / 8 + 1;
+  return L;
+}
+constexpr int kFlagClear = 0x7F7F7F7F;  // "no failing Merkle path" (the kernel keeps the smallest failing item + 1)
+
+// One pass over B proofs (B = 1: dv is the circuit's own block and no batch context is active; B > 1: dv is block 0 of B blocks
+// `stride` bytes apart and the calling thread's batch context is set).  Everything that depends only on the proof -- the whole
+// transcript and every Merkle path -- runs on the device with the proofs in grid z; the field arithmetic runs on host threads.
+int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t stride, const uint64_t* proofs, size_t proof_stride,
+                unsigned B, int* accepted, int* reason) {
+  const VLayout L = verify_layout(c);
+  const u32 n_cs = c->n_cs, log_n = c->degree_bits, log_big = log_n + kRateBits, nred = L.nred;
+  const size_t nq = L.nq;
+  hipStream_t st = rt().stream;
+  std::vector<char> live(B, 1);
+  for (unsigned b = 0; b < B; ++b) {
+    accepted[b] = 0;
+    reason[b] = 10;
+    const uint64_t* pr = proofs + (size_t)b * proof_stride;
+    for (size_t k = 0; k < c->proof_len; ++k)
+      if (pr[k] >= gl::P) {
+        live[b] = 0;
+        break;
+      }
+  }
+  P2MT_HIP(hipMemcpyAsync(dv, c->digest, 32, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(dv + L.o_cscap, c->cs_cap, sizeof c->cs_cap, hipMemcpyHostToDevice, st));
+  if (B > 1) {
+    P2MT_TRY(p2mt::batch_broadcast(dv, 32));
+    P2MT_TRY(p2mt::batch_broadcast(dv + L.o_cscap, sizeof c->cs_cap));
+    P2MT_HIP(hipMemcpy2DAsync(dv + L.o_proof, stride, proofs, proof_stride * 8, c->proof_len * 8, B, hipMemcpyHostToDevice, st));
+  } else {
+    P2MT_HIP(hipMemcpyAsync(dv + L.o_proof, proofs, c->proof_len * 8, hipMemcpyHostToDevice, st));
+  }
+  if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(dv + L.o_proof + L.off_pi, 1, c->n_pi, 0, dv + 4));
+  else P2MT_TRY(p2mt::batch_fill(dv + 4, 0, 32));
+  // the whole transcript depends only on the proof: enqueue it in one go
+  u64* d_out = dv + L.o_out;
+  P2MT_TRY(p2mt_challenger_restart_duplex_dev(ch, dv, 8 + 64, d_out, 2 * kNumCh));                          // betas, gammas
+  P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + 64, 64, d_out + 2 * kNumCh, kNumCh));           // alphas
+  P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + 128, 64, d_out + 3 * kNumCh, 2));                // zeta
+  hipLaunchKernelGGL(k_opening_unset, bgrid(grid_for(2 * L.n_open)), dim3(kBlock), 0, st, (const u64*)(dv + L.o_proof + L.off_open),
+                     dv + L.o_fo, n_cs, barg());
+  P2MT_LAUNCH_CHECK();
+  P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_fo, 2 * L.n_open, d_out + 8, 2));                       // FRI alpha
+  for (u32 l = 0; l < nred; ++l)
+    P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + L.off_fri + 64 * l, 64, d_out + 10 + 2 * l, 2));  // FRI betas
+  P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + L.off_final, 2 * L.final_len + 1, d_out + 26, 1));    // PoW response
+  P2MT_TRY(p2mt_challenger_get_challenges_dev(ch, nq, d_out + 27));                                           // query indices
+  std::vector<u64> out((size_t)B * L.n_out), pi_hash((size_t)B * 4);
+  if (B > 1) {
+    P2MT_HIP(hipMemcpy2DAsync(out.data(), L.n_out * 8, d_out, stride, L.n_out * 8, B, hipMemcpyDeviceToHost, st));
+    P2MT_HIP(hipMemcpy2DAsync(pi_hash.data(), 32, dv + 4, stride, 32, B, hipMemcpyDeviceToHost, st));
+  } else {
+    P2MT_HIP(hipMemcpyAsync(out.data(), d_out, L.n_out * 8, hipMemcpyDeviceToHost, st));
+    P2MT_HIP(hipMemcpyAsync(pi_hash.data(), dv + 4, 32, hipMemcpyDeviceToHost, st));
+  }
+  P2MT_HIP(hipStreamSynchronize(st));
+
+  p2mt::VerifyDesc vd{};
+  vd.degree_bits = log_n, vd.num_wires = kNumWires, vd.num_routed = kNumRouted, vd.num_constants = kNumConsts;
+  vd.num_selectors = c->num_selectors, vd.num_challenges = kNumCh, vd.quotient_degree_factor = kQF, vd.n_kinds = c->n_kinds;
+  for (u32 g = 0; g < kMaxGateTypes; ++g) vd.kind[g] = c->kind[g], vd.sel[g] = c->sel[g], vd.gs[g] = c->gs[g], vd.ge[g] = c->ge[g];
+  const size_t big = (size_t)1 << log_big;
+  const uint64_t n_polys[4] = {n_cs, kNumWires, kNumZs, kNumQuot};
+  const u32 cap_off[4] = {(u32)L.o_cscap, (u32)L.o_proof, (u32)L.o_proof + 64, (u32)L.o_proof + 128};
+  const size_t n_items = L.max_items;
+  std::vector<VItem> items((size_t)B * n_items);
+  std::vector<u64> x_indices((size_t)B * nq);
+  std::vector<char> is_layer(n_items);
+  // host arithmetic, one proof per task; the tasks are independent and pure, so a batch spreads them over a few threads
+  auto for_each_proof = [&](auto&& fn) {
+    const unsigned T = B > 1 ? std::min<unsigned>(B, std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+    if (T <= 1) {
+      for (unsigned b = 0; b < B; ++b) fn(b);
+      return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t)
+      pool.emplace_back([&, t] {
+        for (unsigned b = t; b < B; b += T) fn(b);
+      });
+    for (auto& th : pool) th.join();
+  };
+  for_each_proof([&](unsigned b) {
+    const uint64_t* proof = proofs + (size_t)b * proof_stride;
+    const u64* o = &out[(size_t)b * L.n_out];
+    if (live[b]) {
+      reason[b] = 11;
+      if (!p2mt::verify_openings_host(vd, c->k_is, o + 3 * kNumCh, proof + L.off_open, &pi_hash[(size_t)b * 4], o, o + kNumCh, o + 2 * kNumCh)) live[b] = 0;
+    }
+    if (live[b]) {
+      reason[b] = 1;
+      if (c->fri.proof_of_work_bits && (o[26] >> (64 - c->fri.proof_of_work_bits)) != 0) live[b] = 0;
+    }
+    // Merkle paths of every query: oracle rows against the four caps, layer cosets against the layer caps
+    VItem* it = &items[(size_t)b * n_items];
+    size_t k = 0, w = L.o_proof + L.off_fri + (size_t)nred * 64;
+    for (size_t q = 0; q < nq; ++q) {
+      size_t x_index = (size_t)(o[27 + q] % big);
+      x_indices[(size_t)b * nq + q] = x_index;
+      for (u32 tr = 0; tr < 4; ++tr) {
+        it[k] = VItem{(u32)w, (u32)n_polys[tr], (u32)x_index, (u32)(w + n_polys[tr]), log_big - kCapHeight, cap_off[tr]};
+        if (b == 0) is_layer[k] = 0;
+        ++k;
+        w += n_polys[tr] + 4 * (size_t)(log_big - kCapHeight);
+      }
+      unsigned log_sz = log_big;
+      for (u32 l = 0; l < nred; ++l) {
+        const unsigned ab = c->fri.reduction_arity_bits[l];
+        const size_t arity = (size_t)1 << ab;
+        x_index >>= ab;
+        const u32 n_sib = log_sz - ab - kCapHeight;
+        it[k] = VItem{(u32)w, (u32)(2 * arity), (u32)x_index, (u32)(w + 2 * arity), n_sib, (u32)(L.o_proof + L.off_fri + 64 * l)};
+        if (b == 0) is_layer[k] = 1;
+        ++k;
+        w += 2 * arity + 4 * (size_t)n_sib;
+        log_sz -= ab;
+      }
+    }
+  });
+  int* d_flag = reinterpret_cast<int*>(dv + L.o_flag);
+  VItem* d_items = reinterpret_cast<VItem*>(dv + L.o_items);
+  P2MT_TRY(p2mt::batch_fill(d_flag, 0x7F, 8));
+  if (B > 1) {
+    P2MT_HIP(hipMemcpy2DAsync(d_items, stride, items.data(), n_items * sizeof(VItem), n_items * sizeof(VItem), B, hipMemcpyHostToDevice, st));
+  } else {
+    P2MT_HIP(hipMemcpyAsync(d_items, items.data(), n_items * sizeof(VItem), hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(k_verify_merkle, bgrid((unsigned)((n_items + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
+                     (const u64*)dv, (const VItem*)d_items, (u32)n_items, d_flag, barg(), p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  std::vector<int> flags(B, 0);
+  if (B > 1) P2MT_HIP(hipMemcpy2DAsync(flags.data(), sizeof(int), d_flag, stride, sizeof(int), B, hipMemcpyDeviceToHost, st));
+  else P2MT_HIP(hipMemcpyAsync(flags.data(), d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  for_each_proof([&](unsigned b) {
+    if (!live[b]) return;
+    if (flags[b] != kFlagClear) {
+      reason[b] = is_layer[(size_t)flags[b] - 1] ? 4 : 2;
+      return;
+    }
+    const uint64_t* proof = proofs + (size_t)b * proof_stride;
+    const u64* o = &out[(size_t)b * L.n_out];
+    // openings in transcript order for the FRI arithmetic (host reorder of the OpeningSet)
+    std::vector<u64> fo(2 * L.n_open);
+    const u64* so = proof + L.off_open;
+    const size_t a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot);
+    std::copy(so, so + a, fo.begin());
+    std::copy(so + a + 2 * kNumCh, so + a + 2 * kNumCh + tail, fo.begin() + a);
+    std::copy(so + a, so + a + 2 * kNumCh, fo.begin() + a + tail);
+    const int r = p2mt::verify_fri_queries_host(c->fri, n_polys, 4, kNumCh, o + 3 * kNumCh, fo.data(), o + 8, o + 10, proof + L.off_fri,
+                                                c->fri_len, &x_indices[(size_t)b * nq]);
+    reason[b] = r;
+    accepted[b] = r == 0;
+  });
+  return P2MT_OK;
+}
+}  // namespace
+
 extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, size_t proof_len, int* accepted, int* reason) {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !proof || !accepted) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -2262,115 +2453,59 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
   *accepted = 0;
   *reason = 10;
   if (proof_len != c->proof_len) return P2MT_OK;
-  for (size_t k = 0; k < proof_len; ++k)
-    if (proof[k] >= gl::P) return P2MT_OK;
-  const u32 n_cs = c->n_cs, log_n = c->degree_bits, log_big = log_n + kRateBits, nred = c->fri.num_reductions;
-  const size_t n_open = n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot;
-  const size_t off_open = 192, off_fri = off_open + 2 * n_open, off_pi = c->proof_len - c->n_pi;
-  unsigned total_arity = 0;
-  for (u32 l = 0; l < nred; ++l) total_arity += c->fri.reduction_arity_bits[l];
-  const size_t final_len = (size_t)1 << (log_n - total_arity), nq = c->fri.num_query_rounds;
-  const size_t off_final = off_fri + c->fri_len - 1 - 2 * final_len;
-  // device layout: digest | pi_hash | proof | cs_cap | openings in transcript order | challenges | flag | items
-  const size_t max_items = nq * (4 + nred);
-  const size_t o_proof = 8, o_cscap = o_proof + c->proof_len, o_fo = o_cscap + 64, o_out = o_fo + 2 * n_open;
-  const size_t n_out = 8 + 2 + 2 * 8 + 1 + nq, o_flag = o_out + n_out + 1, o_items = o_flag + 1;
-  const size_t words = o_items + (max_items * sizeof(VItem) + 7) / 8 + 1;
-  hipStream_t st = rt().stream;
+  if (p2mt::batch_B() != 1) return p2mt::fail(P2MT_EINVAL, "verify: called inside a batched pass");
   if (!c->d_verify) {
-    if (hipMalloc((void**)&c->d_verify, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(verify) failed");
+    if (hipMalloc((void**)&c->d_verify, verify_layout(c).words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(verify) failed");
     P2MT_TRY(p2mt_challenger_create(&c->vch));
   }
-  u64* dv = c->d_verify;
-  P2MT_HIP(hipMemcpyAsync(dv, c->digest, 32, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(dv + o_proof, proof, c->proof_len * 8, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(dv + o_cscap, c->cs_cap, sizeof c->cs_cap, hipMemcpyHostToDevice, st));
-  if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(dv + o_proof + off_pi, 1, c->n_pi, 0, dv + 4));
-  else P2MT_HIP(hipMemsetAsync(dv + 4, 0, 32, st));
-  // the whole transcript depends only on the proof: enqueue it in one go
-  u64* d_out = dv + o_out;
-  P2MT_TRY(p2mt_challenger_restart_duplex_dev(c->vch, dv, 8 + 64, d_out, 2 * kNumCh));               // betas, gammas
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + 64, 64, d_out + 2 * kNumCh, kNumCh));    // alphas
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + 128, 64, d_out + 3 * kNumCh, 2));         // zeta
-  hipLaunchKernelGGL(k_opening_unset, dim3(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)(dv + o_proof + off_open),
-                     dv + o_fo, n_cs);
-  P2MT_LAUNCH_CHECK();
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_fo, 2 * n_open, d_out + 8, 2));                    // FRI alpha
-  for (u32 l = 0; l < nred; ++l)
-    P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + off_fri + 64 * l, 64, d_out + 10 + 2 * l, 2));  // FRI betas
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->vch, dv + o_proof + off_final, 2 * final_len + 1, d_out + 26, 1));    // PoW response
-  P2MT_TRY(p2mt_challenger_get_challenges_dev(c->vch, nq, d_out + 27));                                      // query indices
-  std::vector<u64> out(n_out), pi_hash(4);
-  P2MT_HIP(hipMemcpyAsync(out.data(), d_out, n_out * 8, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipMemcpyAsync(pi_hash.data(), dv + 4, 32, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipStreamSynchronize(st));
-  const u64 *betas = &out[0], *gammas = &out[kNumCh], *alphas = &out[2 * kNumCh], *zeta = &out[3 * kNumCh];
+  return verify_pass(c, c->d_verify, c->vch, 0, proof, proof_len, 1, accepted, reason);
+}
 
-  p2mt::VerifyDesc vd{};
-  vd.degree_bits = log_n, vd.num_wires = kNumWires, vd.num_routed = kNumRouted, vd.num_constants = kNumConsts;
-  vd.num_selectors = c->num_selectors, vd.num_challenges = kNumCh, vd.quotient_degree_factor = kQF, vd.n_kinds = c->n_kinds;
-  for (u32 g = 0; g < kMaxGateTypes; ++g) vd.kind[g] = c->kind[g], vd.sel[g] = c->sel[g], vd.gs[g] = c->gs[g], vd.ge[g] = c->ge[g];
-  *reason = 11;
-  if (!p2mt::verify_openings_host(vd, c->k_is, zeta, proof + off_open, pi_hash.data(), betas, gammas, alphas)) return P2MT_OK;
-  *reason = 1;
-  if (c->fri.proof_of_work_bits && (out[26] >> (64 - c->fri.proof_of_work_bits)) != 0) return P2MT_OK;
-
-  // Merkle paths of every query: oracle rows against the four caps, layer cosets against the layer caps
-  const size_t big = (size_t)1 << log_big;
-  const uint64_t n_polys[4] = {n_cs, kNumWires, kNumZs, kNumQuot};
-  const u32 cap_off[4] = {(u32)o_cscap, (u32)o_proof, (u32)o_proof + 64, (u32)o_proof + 128};
-  std::vector<VItem> items;
-  std::vector<u64> x_indices(nq);
-  std::vector<char> is_layer;
-  size_t w = o_proof + off_fri + (size_t)nred * 64;
-  for (size_t q = 0; q < nq; ++q) {
-    size_t x_index = (size_t)(out[27 + q] % big);
-    x_indices[q] = x_index;
-    for (u32 o = 0; o < 4; ++o) {
-      items.push_back(VItem{(u32)w, (u32)n_polys[o], (u32)x_index, (u32)(w + n_polys[o]), log_big - kCapHeight, cap_off[o]});
-      is_layer.push_back(0);
-      w += n_polys[o] + 4 * (size_t)(log_big - kCapHeight);
+// circuit_data.verify for n proofs of this circuit, proofs[i] at proofs + i * proof_stride words: passes of up to 256 proofs with
+// the proof index in a grid dimension of every launch (one transcript replay and one Merkle-path launch per pass), the field
+// arithmetic of each proof on a few host threads.  accepted[i] / reason[i] as p2mt_circuit_verify.
+extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* proofs, size_t n, size_t proof_stride, int* accepted,
+                                         int* reason) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!c || !proofs || !accepted || !reason) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (proof_stride < c->proof_len) return p2mt::fail(P2MT_EINVAL, "verify_batch: proof_stride < proof_len");
+  if (p2mt::batch_B() != 1) return p2mt::fail(P2MT_EINVAL, "verify_batch: called inside a batched pass");
+  if (n == 0) return P2MT_OK;
+  constexpr size_t kMaxPass = 256;
+  const VLayout L = verify_layout(c);
+  const size_t want = std::min(n, kMaxPass);
+  const size_t stride = ((L.words * 8 + p2mt::kChallengerStateBytes + 8) + 255) & ~(size_t)255;
+  if (c->vbatch_cap < want) {
+    if (c->d_vbatch) {
+      (void)hipStreamSynchronize(rt().stream);
+      (void)hipFree(c->d_vbatch);
+      c->d_vbatch = nullptr;
+      c->vbatch_cap = 0;
     }
-    unsigned log_sz = log_big;
-    for (u32 l = 0; l < nred; ++l) {
-      const unsigned ab = c->fri.reduction_arity_bits[l];
-      const size_t arity = (size_t)1 << ab;
-      x_index >>= ab;
-      const u32 n_sib = log_sz - ab - kCapHeight;
-      items.push_back(VItem{(u32)w, (u32)(2 * arity), (u32)x_index, (u32)(w + 2 * arity), n_sib, (u32)(o_proof + off_fri + 64 * l)});
-      is_layer.push_back(1);
-      w += 2 * arity + 4 * (size_t)n_sib;
-      log_sz -= ab;
+    if (hipMalloc((void**)&c->d_vbatch, stride * want) != hipSuccess) {
+      (void)hipGetLastError();
+      c->d_vbatch = nullptr;
+      return p2mt::fail(P2MT_ENOMEM, "hipMalloc(verify batch) failed");
     }
+    c->vbatch_cap = want, c->vbatch_stride = stride;
+    if (c->vbch) p2mt::challenger_unwrap(c->vbch);
+    c->vbch = nullptr;
+    P2MT_TRY(p2mt::challenger_wrap(c->d_vbatch + ((L.words * 8 + 7) & ~(size_t)7), &c->vbch));
   }
-  int* d_flag = reinterpret_cast<int*>(dv + o_flag);
-  VItem* d_items = reinterpret_cast<VItem*>(dv + o_items);
-  const int big_flag = 0x7FFFFFFF;
-  P2MT_HIP(hipMemcpyAsync(d_flag, &big_flag, sizeof big_flag, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(VItem), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_verify_merkle, dim3((unsigned)((items.size() + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
-                     (const u64*)dv, (const VItem*)d_items, (u32)items.size(), d_flag, p2mt::perm_ctx());
-  P2MT_LAUNCH_CHECK();
-  int flag = 0;
-  P2MT_HIP(hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipStreamSynchronize(st));
-  if (flag != big_flag) {
-    *reason = is_layer[(size_t)flag - 1] ? 4 : 2;
-    return P2MT_OK;
+  struct Scope {
+    ~Scope() { p2mt::batch() = p2mt::BatchCtx{}; }
+  } scope;
+  for (size_t at = 0; at < n; at += kMaxPass) {
+    const unsigned cnt = (unsigned)std::min(kMaxPass, n - at);
+    p2mt::BatchCtx& ctx = p2mt::batch();
+    ctx = p2mt::BatchCtx{};
+    if (cnt > 1) {
+      ctx.B = cnt;
+      ctx.arg = p2mt::BatchArg{(uint64_t)c->d_vbatch, (uint64_t)c->vbatch_stride, (uint64_t)c->vbatch_stride};
+    }
+    P2MT_TRY(verify_pass(c, reinterpret_cast<u64*>(c->d_vbatch), c->vbch, c->vbatch_stride, proofs + at * proof_stride, proof_stride, cnt,
+                         accepted + at, reason + at));
   }
-  // openings in transcript order for the FRI arithmetic (host reorder of the OpeningSet)
-  std::vector<u64> fo(2 * n_open);
-  {
-    const u64* so = proof + off_open;
-    const size_t a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot);
-    std::copy(so, so + a, fo.begin());
-    std::copy(so + a + 2 * kNumCh, so + a + 2 * kNumCh + tail, fo.begin() + a);
-    std::copy(so + a, so + a + 2 * kNumCh, fo.begin() + a + tail);
-  }
-  const int r = p2mt::verify_fri_queries_host(c->fri, n_polys, 4, kNumCh, zeta, fo.data(), &out[8], &out[10], proof + off_fri,
-                                              c->fri_len, x_indices.data());
-  *reason = r;
-  *accepted = r == 0;
   return P2MT_OK;
 }
 

@@ -797,13 +797,12 @@ __global__ __launch_bounds__(kBlock) void k_digests_to_plonky2(const u64* __rest
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= total) return;
   // level of record t: levels have n, n/2, ... entries
-  size_t off = 0, g = t;
+  size_t g = t;
   unsigned lvl = 0;
   for (; lvl + cap_height < log_n; ++lvl) {
     const size_t cnt = (size_t)1 << (log_n - lvl);
     if (g < cnt) break;
     g -= cnt;
-    off += cnt;
   }
   const unsigned sub_log = log_n - cap_height;                    // log2(leaves per cap subtree)
   const size_t per_sub = ((size_t)2 << sub_log) - 2;              // digests per cap subtree

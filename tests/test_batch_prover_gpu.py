@@ -196,3 +196,38 @@ def test_batch_provers_on_two_threads(pkg, oracle):
     for i in range(2):
         for g, w in zip(got[i], want[i]):
             assert np.array_equal(g, w)
+
+
+def test_verify_batch_matches_single_verify(pkg, oracle):
+    """p2mt_circuit_verify_batch: accepted / reason per proof equal circuit_data.verify's, for good proofs and for every way of
+    breaking one (non-canonical word, opening, proof-of-work witness, oracle Merkle path, layer Merkle path, final polynomial);
+    more proofs than one pass holds (256) go through several passes."""
+    cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, range(640, 652))
+    proofs = pkg.BatchProver(cd, 12).prove(pws)
+    acc, why = cd.verify_batch(proofs)
+    assert acc == [True] * 12 and why == [0] * 12
+    info, plen = cd.info, cd.info.proof_len
+    n_cs = info.num_selectors + 2 + 80
+    n_open = n_cs + 135 + 2 * 2 + 2 * 9 + 16
+    off_fri = 192 + 2 * n_open
+    first_row = off_fri + 64          # one reduction at degree 2^6: the first query's constants_sigmas row
+    bad = proofs.copy()
+    bad[1, 5] = 0xFFFFFFFFFFFFFFFF                            # not canonical
+    bad[2, 192 + 7] ^= 1                                      # an opening
+    bad[3, plen - info.num_public_inputs - 1] ^= 1            # the proof-of-work witness
+    bad[4, first_row + n_cs + 2] ^= 1                         # a sibling of an oracle row's Merkle path
+    bad[5, plen - info.num_public_inputs - 3] ^= 1            # a coefficient of the final polynomial
+    bad[6, first_row + 3] ^= 1                                # an opened oracle value
+    acc, why = cd.verify_batch(bad)
+    for i in range(12):
+        a, r = cd.verify(bad[i], with_reason=True)
+        assert (acc[i], why[i]) == (a, r), (i, acc[i], why[i], a, r)
+    assert acc[0] and not any(acc[1:7]) and all(acc[7:])
+    assert why[1] == 10 and why[2] == 11 and why[4] == 2
+    # several passes, a single proof, an empty batch
+    many = np.tile(proofs, (25, 1))[:290]
+    many[277] = bad[2]
+    acc, why = cd.verify_batch(many)
+    assert acc == [i != 277 for i in range(290)] and why[277] == 11
+    assert cd.verify_batch(proofs[:1]) == ([True], [0])
+    assert cd.verify_batch(np.zeros((0, plen), np.uint64)) == ([], [])
