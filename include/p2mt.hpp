@@ -397,6 +397,31 @@ class CircuitData {  // CircuitData<GoldilocksField, PoseidonGoldilocksConfig, 2
     check(p2mt_circuit_verify(h_, proof.words.data(), proof.words.size(), &accepted, &reason));
     if (!accepted) throw panic(P2MT_EINVAL, "proof rejected (reason " + std::to_string(reason) + ")");
   }
+  // circuit_data.verify for many proofs in passes of up to 256 (p2mt_circuit_verify_batch): accepted[i] per proof
+  std::vector<bool> verify_batch(const std::vector<ProofWithPublicInputs>& proofs) {
+    const std::size_t n = proofs.size(), len = info.proof_len;
+    std::vector<uint64_t> words(n * len);
+    for (std::size_t i = 0; i < n; ++i) {
+      if (proofs[i].words.size() != len) throw panic(P2MT_EINVAL, "proof does not belong to this circuit");
+      std::copy(proofs[i].words.begin(), proofs[i].words.end(), words.begin() + i * len);
+    }
+    std::vector<int> acc(n), reason(n);
+    check(p2mt_circuit_verify_batch(h_, words.data(), n, len, acc.data(), reason.data()));
+    return std::vector<bool>(acc.begin(), acc.end());
+  }
+  // ProofWithPublicInputs::to_bytes / from_bytes in plonky2's Buffer order
+  std::vector<uint8_t> to_bytes(const ProofWithPublicInputs& proof) const {
+    std::vector<uint8_t> out(p2mt_proof_bytes_len(h_));
+    check(p2mt_proof_to_bytes(h_, proof.words.data(), proof.words.size(), out.data(), out.size()));
+    return out;
+  }
+  ProofWithPublicInputs from_bytes(const std::vector<uint8_t>& bytes) const {
+    ProofWithPublicInputs p;
+    p.words.resize(info.proof_len);
+    check(p2mt_proof_from_bytes(h_, bytes.data(), bytes.size(), p.words.data(), p.words.size()));
+    p.public_inputs.assign(p.words.end() - info.num_public_inputs, p.words.end());
+    return p;
+  }
   HashOut circuit_digest() const {
     HashOut d;
     check(p2mt_circuit_constants_sigmas(h_, nullptr, nullptr, d.elements.data()));

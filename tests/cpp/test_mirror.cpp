@@ -234,6 +234,14 @@ static void test_inner_merkle_proof_3leaves() {
   REQUIRE(many.size() == 3);
   for (const auto& p : many) REQUIRE(p.words == proof.words);
   REQUIRE(c.data.prove(pw).words == proof.words);  // the circuit handle is its own again
+  // batched verify and the byte form of the proof
+  ProofWithPublicInputs broken = proof;
+  broken.words[200] ^= 1;
+  const std::vector<bool> verdicts = c.data.verify_batch({proof, broken, proof});
+  REQUIRE(verdicts.size() == 3 && verdicts[0] && !verdicts[1] && verdicts[2]);
+  const std::vector<uint8_t> bytes = c.data.to_bytes(proof);
+  REQUIRE(bytes.size() > 8 * proof.words.size());
+  REQUIRE(c.data.from_bytes(bytes).words == proof.words);
 }
 
 // mmr_plonky2_verifier_1_recursion.rs:152-221 test_complete_verification_circuit_with_inner_proof, leaves (1..7), leaf index 5
