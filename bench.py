@@ -556,6 +556,63 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
     return out
 
 
+def run_prove_replicas(args, torch, pkg, lib, rank, world, dist):
+    """--workload prove on N > 1 GPUs: the prover does not shard (one proof is a dependent chain on one device: "replicas only",
+    DESIGN.md 6), so every rank runs its own batched prover (p2mt_batch_prover, 128 different statements per pass) on its own
+    GPU; a step = one pass per rank; value = all ranks' proofs / the slowest rank's time (barrier on both sides)."""
+    Nn = pkg._native
+    B = 128
+    P = pkg.GOLDILOCKS_FIELD_ORDER
+    cd, leaf_t, proof_ts, peak_ts = pkg.verify_mmr_proof_circuit(20, 1)
+    pws = []
+    for k in range(B):
+        rng = np.random.default_rng(7000 + 1000 * rank + k)
+        leaf = int(rng.integers(0, P, dtype=np.uint64))
+        siblings = rng.integers(0, P, size=(20, 4), dtype=np.uint64)
+        lefts = rng.integers(0, 2, size=20).astype(np.uint8)
+        cur = np.array([leaf, 0, 0, 0], np.uint64)
+        for sb, l in zip(siblings, lefts):
+            cur = pkg.two_to_one(sb, cur) if l else pkg.two_to_one(cur, sb)
+        pw = pkg.PartialWitness()
+        pkg.synthetic.assign_mmr_proof(leaf_t, proof_ts, peak_ts, cd.prover_only.public_inputs,
+                                       (leaf, siblings, lefts, cur.reshape(1, 4), cur.copy()), pw.set_target)
+        pws.append(pw)
+    bp = pkg.BatchProver(cd, B)
+    warr = (C.c_void_p * B)(*[w._h for w in pws])
+    out = np.zeros((B, cd.info.proof_len), np.uint64)
+
+    def step():
+        Nn.check(lib.p2mt_batch_prover_prove(bp._h, warr, B, Nn.ptr(out), cd.info.proof_len, None))
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    assert np.array_equal(out[0], cd.prove(pws[0])) and cd.verify(out[B - 1])  # batch == one at a time; accepted
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * args.steps / dt
+    return {"metric": "proofs/s mmr_plonky2_verifier (batched prover, one replica per GPU)", "value": value, "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks + quadratic extension)",
+            "data": "synthetic",
+            "config": {"workload": "mmr_plonky2_verifier circuit_data.prove through p2mt_batch_prover, %d different statements per "
+                                   "pass and rank (20 path elements + 1 peak, degree 2^%d), replicas only: no data-path collective"
+                                   % (B, cd.degree_bits), "proofs_per_step": world * B}}
+
+
 def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
     """BASELINE.json config 4 / the second half of its metric: ms/proof of mmr_plonky2_verifier_1_recursion -- inner prove + outer
     prove (/root/reference/src/mmr/mmr_plonky2_verifier_1_recursion.rs:191-192 and :217-218) for one leaf of a 2^20-leaf MMR.
@@ -734,6 +791,8 @@ def main():
         out = run_commit(args, torch, pkg, lib) if rank == 0 else None
     elif args.workload == "fri":
         out = run_fri(args, torch, pkg, lib) if rank == 0 else None
+    elif args.workload == "prove" and world > 1:
+        out = run_prove_replicas(args, torch, pkg, lib, rank, world, dist)
     elif args.workload == "prove":
         out = run_prove(args, torch, pkg, lib) if rank == 0 else None
     elif args.workload == "recursion":

@@ -200,3 +200,17 @@ def test_bench_two_ranks_on_one_device(pkg, oracle, scaling, log_leaves):
     leaves = np.concatenate([pkg.synthetic.bench_leaves(local_log, r) for r in range(2)])
     assert [int(x) for x in oracle.mmr(leaves).bagging_the_peaks()] == out["root"]
     assert out["config"]["hashes_per_step"] == 2 * ((1 << local_log) - 1) + 1
+
+
+def test_bench_prove_replicas_on_one_device(pkg):
+    """bench.py --workload prove --gpus 2: the prover does not shard, so every rank runs its own batched prover (replicas only);
+    launched as the driver would (two child processes, both on GPU 0 here, gloo for the barrier)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--workload", "prove"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "proofs/s"
+    assert out["config"]["proofs_per_step"] == 256 and out["value"] > 1000
