@@ -694,13 +694,14 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
                         "note": "dependency chains (witness levels, transcript, Merkle levels), not bandwidth: per-kernel split in "
                                 "profiles/r02_prove_timeline_recursion.txt"}}
     if getattr(args, "workload", "") == "recursion":
-        # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks at B = 32)
+        # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks per thread at B = 32; two threads so
+        # that one pass's one-workgroup witness interpreter overlaps the other's hashing)
         import subprocess
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", "4"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", "4", "2"],
                            capture_output=True, text=True, timeout=300)
         try:
             out["throughput"] = json.loads(r.stdout.strip().splitlines()[-1])
-            out["throughput"]["note"] = ("p2mt_batch_prover on the inner and on the outer circuit, one host thread; proofs "
+            out["throughput"]["note"] = ("p2mt_batch_prover on the inner and on the outer circuit, two host threads; proofs "
                                          "bit-identical to the one-at-a-time path's; `value` above stays the single-proof latency")
         except Exception:
             out["throughput"] = {"error": (r.stdout + r.stderr)[-400:]}
