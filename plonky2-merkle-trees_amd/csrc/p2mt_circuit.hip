@@ -633,7 +633,7 @@ GL_DEV u32 poseidon_fresh_mask(u32 kind, u32 c) { return (kind & kFreshOutputs) 
 // copy-constrained, so they have no value slot and are not computed here at all: the level loop is a dependency chain, and
 // recording them costs ~40 % on top of every chained permutation.  k_poseidon_rows recomputes every row in parallel, with
 // the recording hook, once the wire matrix holds the rows' inputs.
-template <typename Mem>
+template <typename Mem, u32 BLK = kBlock>
 GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
                        const u32* __restrict__ pslots, const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
                        const PermCtx& ctx) {
@@ -644,10 +644,10 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
   constexpr u32 kLvlLds = 1024, kChunk = 512;
   __shared__ u32 lvl_lds[2 * kLvlLds + 1];
   __shared__ WOp ops_lds[kChunk];
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = kBlock / 64;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = BLK / 64;
   const u32* L = lvl;
   if (n_levels <= kLvlLds) {
-    for (u32 k = tid; k < 2 * n_levels + 1; k += kBlock) lvl_lds[k] = lvl[k];
+    for (u32 k = tid; k < 2 * n_levels + 1; k += BLK) lvl_lds[k] = lvl[k];
     __syncthreads();
     L = lvl_lds;
   }
@@ -661,7 +661,7 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
     u32 last = l;
     while (last + 1 < n_levels && L[2 * (last + 2)] - s <= kChunk) ++last;
     const u32 end = L[2 * (last + 1)];
-    for (u32 k = tid; k < end - s; k += kBlock) ops_lds[k] = ops[s + k];
+    for (u32 k = tid; k < end - s; k += BLK) ops_lds[k] = ops[s + k];
     __syncthreads();
     ch_begin = s;
     ch_end = end;
@@ -687,7 +687,7 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
       if (o != s + wave) ps = lane < 25 ? pslots[(size_t)po.b * 32 + lane] : 0;  // more PoseidonGate rows in this level than wavefronts
       run_poseidon_generator<false>(m, ps, lane, o, poseidon_fresh_mask(po.kind, po.c), err, ctx);
     }
-    for (u32 o = s + np + tid; o < e; o += kBlock) run_lane_generator(m, OP(o), o, tab, args, err);
+    for (u32 o = s + np + tid; o < e; o += BLK) run_lane_generator(m, OP(o), o, tab, args, err);
     m.sync();
     if (l + 1 < n_levels) {
       if (L[2 * (l + 1) + 2] <= ch_end) {
@@ -700,16 +700,19 @@ GL_DEV void run_levels(const Mem& m, const WOp* __restrict__ ops, const u32* __r
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
-                                                        u64* vals, u32* set, const u32* __restrict__ pslots,
-                                                        const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
-                                                        BatchArg ba, PermCtx ctx) {
+// BLK = 256: the fallback of a single proof; BLK = 1024 (16 wavefronts: 16 PoseidonGate rows of a level at a time) for the proofs
+// of a batch, which get one workgroup each.
+template <u32 BLK>
+__global__ __launch_bounds__(BLK) void k_witness_run(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
+                                                     u64* vals, u32* set, const u32* __restrict__ pslots,
+                                                     const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
+                                                     BatchArg ba, PermCtx ctx) {
   vals = bp(vals, ba);
   set = bp(set, ba);
   err = bp(err, ba);
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
-  run_levels(GMem{vals, set}, ops, lvl, n_levels, pslots, tab, args, err, ctx);
+  run_levels<GMem, BLK>(GMem{vals, set}, ops, lvl, n_levels, pslots, tab, args, err, ctx);
 }
 
 // The same interpreter spread over the whole grid, for circuits with wide levels (the recursion's outer circuit: 28 FRI query
@@ -1605,9 +1608,15 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
                        c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
                        c->d_sync, p2mt::perm_ctx());
   } else {
-    hipLaunchKernelGGL(k_witness_run, bgrid(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels, c->d_vals,
-                       c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err, barg(),
-                       p2mt::perm_ctx());
+    if (B > 1) {
+      hipLaunchKernelGGL(k_witness_run<1024>, bgrid(1), dim3(1024), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
+                         c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err, barg(),
+                         p2mt::perm_ctx());
+    } else {
+      hipLaunchKernelGGL(k_witness_run<256>, bgrid(1), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
+                         c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err, barg(),
+                         p2mt::perm_ctx());
+    }
   }
   P2MT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_witness_scatter, bgrid(grid_for(std::max<size_t>(c->n_act, c->n_pi))), dim3(kBlock), 0, st,
