@@ -1058,7 +1058,6 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
       P2MT_HIP(hipStreamSynchronize(st));
       return P2MT_OK;
     }
-    (void)d_saved;
     unsigned long long found = ~0ull;
     for (u64 base = 0;; base += chunk) {
       if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
