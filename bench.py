@@ -527,9 +527,9 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
                                                  "device's dispatch-packet rate)")
         except Exception:
             out["throughput_threads"] = {"error": (r.stdout + r.stderr)[-400:]}
-        # the batched prover (p2mt_batch_prover_*): 128 different statements per pass, the proof index in a grid dimension of
-        # every launch; two host threads so that one pass's latency-bound transcript overlaps the other's grind
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_batch_probe.py"), "4", "2", "128", "3"],
+        # the batched prover (p2mt_batch_prover_*): 256 statements per pass, the proof index in a grid dimension of every launch;
+        # three host threads so that one pass's latency-bound transcript overlaps the others' grind (2 x 128: 18.8 k, 3 x 256: 22.4 k)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_batch_probe.py"), "4", "3", "256", "3"],
                            capture_output=True, text=True, env=dict(os.environ), timeout=300)
         try:
             out["throughput"] = json.loads(r.stdout.strip().splitlines()[-1])
