@@ -77,6 +77,9 @@ int p2mt_debug_force_fallback(int on);
 /* Test hook: the next `n` device allocations made while growing an MMR handle report P2MT_ENOMEM (fault injection: a failed
  * flush / extend must leave len(), num_leaves() and every later root or proof consistent, and must be retryable). */
 int p2mt_debug_fail_allocs(int n);
+/* debug: per-generator completion ticks (100 MHz) of the dataflow witness interpreter; see csrc/p2mt_circuit.hip */
+struct p2mt_circuit_data;
+int p2mt_debug_witness_trace(struct p2mt_circuit_data *c, int enable, uint64_t *out, size_t cap, size_t *n_out);
 /* Test hook: run one Goldilocks primitive of the device code on caller-supplied operands (host pointers).
  * op 0: exact reduce of the 128-bit value a[i] + b[i]*2^64;  op 1: exact fold of (b[i] & 0x3FF)*2^64 + a[i];
  * op 2: flag-form reduce (poseidon_fast::reduce128): out = value, flag_out[i] = 1 if the lane raised the sticky flag

@@ -161,6 +161,7 @@ SIGNATURES = {
     "p2mt_circuit_prove_trace": (C.c_int, [voidp, C.c_int, voidp]),
     "p2mt_circuit_verify": (C.c_int, [voidp, voidp, C.c_size_t, intp, intp]),
     "p2mt_circuit_prove_many": (C.c_int, [voidp, C.c_size_t, voidp, C.c_size_t, voidp, C.c_size_t, voidp]),
+    "p2mt_debug_witness_trace": (C.c_int, [voidp, C.c_int, voidp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "p2mt_circuit_verify_batch": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp]),
     "p2mt_proof_bytes_len": (C.c_size_t, [voidp]),
     "p2mt_proof_to_bytes": (C.c_int, [voidp, voidp, C.c_size_t, voidp, C.c_size_t]),

@@ -27,6 +27,7 @@
 #include <new>
 #include <thread>
 #include <tuple>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -92,6 +93,7 @@ struct p2mt_circuit_data {
   // verifier scratch (allocated on the first p2mt_circuit_verify)
   u64* d_verify = nullptr;
   // batched verifier (p2mt_circuit_verify_batch): one block of the same layout per proof, a challenger state behind each
+  u64* d_trace = nullptr;  // debug (p2mt_debug_witness_trace): completion tick of every generator of the dataflow interpreter
   char* d_vbatch = nullptr;
   size_t vbatch_cap = 0, vbatch_stride = 0;
   p2mt_challenger* vbch = nullptr;
@@ -380,6 +382,16 @@ struct FMem {
     }
     return v;
   }
+  // N operands at once: all N loads are in flight together (a get() per operand is one exposed ~1.2 us round trip each -- a
+  // ReducingExtensionGate generator reads 68 operands); the slots that are not written yet fall back to the waiting get()
+  template <int N>
+  GL_DEV void get_many(const u32 (&sl)[N], u64 (&v)[N]) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = ld64(vals + sl[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (v[i] == kUnsetValue) v[i] = get(sl[i]);
+  }
   GL_DEV bool is_set(u32 s) const {  // a generator that re-derives an already written slot waits for its first writer, then compares
     (void)get(s);
     return true;
@@ -390,6 +402,16 @@ struct FMem {
   }
   GL_DEV void sync() const {}
 };
+// the same for the tables that need no waiting (LMem, GMem)
+template <typename Mem, int N>
+GL_DEV void get_many(const Mem& m, const u32 (&sl)[N], u64 (&v)[N]) {
+  if constexpr (std::is_same<Mem, FMem>::value) {
+    m.template get_many<N>(sl, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = m.get(sl[i]);
+  }
+}
 
 // PartitionWitness::set_target: a slot already holding a value must agree (plonky2 panics otherwise)
 template <typename Mem>
@@ -420,6 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_init(const u64* __restrict__
 // common case).  Otherwise one bit per output, in the order gen_targets() lists them: ArithmeticBase / Equality in bits 9-10 of
 // kind; every other generator in the 96 bits (c, out, out2), which those kinds do not use otherwise.
 constexpr u32 kFreshOutputs = 0x100, kFreshBit0 = 0x200, kFreshBit1 = 0x400;
+constexpr u32 kGenNop = 0xFF;  // padding record of the schedule: no generator
 struct Fresh {
   bool all;
   u32 m[3];
@@ -449,7 +472,6 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
   const Fresh fr = fresh_of(op);
   const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
   auto G = [&](u32 col) { return m.get(S[col]); };
-  auto GE = [&](u32 col) { return DE{m.get(S[col]), m.get(S[col + 1])}; };
   auto PE = [&](u32 col, DE v, u32 ord) {  // ord: ordinal of the pair's first word among the generator's outputs
     put_out(m, S[col], v.a, fr.at(ord), err, o);
     put_out(m, S[col + 1], v.b, fr.at(ord + 1), err, o);
@@ -457,12 +479,22 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
   switch (op.kind & 0xFF) {
     case GEN_ARITH_EXT: {
       const u32 at = 8 * op.b;
-      PE(at + 6, de_add(de_scale(de_mul(GE(at), GE(at + 2)), op.c0), de_scale(GE(at + 4), op.c1)), 0);
+      u32 sl[6];
+      u64 in[6];
+#pragma unroll
+      for (u32 i = 0; i < 6; ++i) sl[i] = S[at + i];
+      get_many(m, sl, in);
+      PE(at + 6, de_add(de_scale(de_mul(DE{in[0], in[1]}, DE{in[2], in[3]}), op.c0), de_scale(DE{in[4], in[5]}, op.c1)), 0);
       break;
     }
     case GEN_MUL_EXT: {
       const u32 at = 6 * op.b;
-      PE(at + 4, de_scale(de_mul(GE(at), GE(at + 2)), op.c0), 0);
+      u32 sl[4];
+      u64 in[4];
+#pragma unroll
+      for (u32 i = 0; i < 4; ++i) sl[i] = S[at + i];
+      get_many(m, sl, in);
+      PE(at + 4, de_scale(de_mul(DE{in[0], in[1]}, DE{in[2], in[3]}), op.c0), 0);
       break;
     }
     case GEN_QUOTIENT_EXT: {
@@ -473,32 +505,79 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       put_out(m, A[5], q.b, fr.at(1), err, o);
       break;
     }
+    // ReducingGate / ReducingExtensionGate: a Horner chain whose every intermediate accumulator is a wire.  The chain is a loop
+    // over chunks of 8 coefficient words (fully unrolled it is ~100 KB of straight-line code per generator kind -- more than the
+    // instruction cache, and the steps ran at instruction-fetch speed, ~1 us each); a chunk's operands are loaded together, the
+    // next chunk's while this one computes.
     case GEN_REDUCING: {
-      u64 coeff[kReducingCoeffs];
+      constexpr u32 kChunk = 8;
+      u32 sl[4];
+      u64 in[4];
 #pragma unroll
-      for (u32 i = 0; i < kReducingCoeffs; ++i) coeff[i] = G(6 + i);
-      const DE alpha = GE(2);
-      DE acc = GE(4);
+      for (u32 i = 0; i < 4; ++i) sl[i] = S[2 + i];
+      get_many(m, sl, in);
+      const DE alpha{in[0], in[1]};
+      DE acc{in[2], in[3]};
+      u32 cs[kChunk];
+      u64 cur[kChunk], nxt[kChunk];
+      auto load = [&](u32 base, u64 (&dst)[kChunk]) {
 #pragma unroll
-      for (u32 i = 0; i < kReducingCoeffs; ++i) {
-        acc = de_mul(acc, alpha);
-        acc.a = gl::add(acc.a, coeff[i]);
-        if (i == kReducingCoeffs - 1) PE(0, acc, 0);
-        else PE(6 + kReducingCoeffs + 2 * i, acc, 2 + 2 * i);
+        for (u32 j = 0; j < kChunk; ++j) cs[j] = S[6 + (base + j < kReducingCoeffs ? base + j : kReducingCoeffs - 1)];
+        get_many(m, cs, dst);
+      };
+      load(0, cur);
+#pragma unroll 1
+      for (u32 base = 0; base < kReducingCoeffs; base += kChunk) {
+        if (base + kChunk < kReducingCoeffs) load(base + kChunk, nxt);
+#pragma unroll
+        for (u32 j = 0; j < kChunk; ++j) {
+          const u32 i = base + j;
+          if (i < kReducingCoeffs) {
+            acc = de_mul(acc, alpha);
+            acc.a = gl::add(acc.a, cur[j]);
+            if (i == kReducingCoeffs - 1) PE(0, acc, 0);
+            else PE(6 + kReducingCoeffs + 2 * i, acc, 2 + 2 * i);
+          }
+        }
+#pragma unroll
+        for (u32 j = 0; j < kChunk; ++j) cur[j] = nxt[j];
       }
       break;
     }
     case GEN_REDUCING_EXT: {
-      DE coeff[kReducingExtCoeffs];
+      constexpr u32 kChunk = 4;  // extension coefficients per chunk
+      u32 sl[4];
+      u64 in[4];
 #pragma unroll
-      for (u32 i = 0; i < kReducingExtCoeffs; ++i) coeff[i] = GE(6 + 2 * i);
-      const DE alpha = GE(2);
-      DE acc = GE(4);
+      for (u32 i = 0; i < 4; ++i) sl[i] = S[2 + i];
+      get_many(m, sl, in);
+      const DE alpha{in[0], in[1]};
+      DE acc{in[2], in[3]};
+      u32 cs[2 * kChunk];
+      u64 cur[2 * kChunk], nxt[2 * kChunk];
+      auto load = [&](u32 base, u64 (&dst)[2 * kChunk]) {
 #pragma unroll
-      for (u32 i = 0; i < kReducingExtCoeffs; ++i) {
-        acc = de_add(de_mul(acc, alpha), coeff[i]);
-        if (i == kReducingExtCoeffs - 1) PE(0, acc, 0);
-        else PE(6 + 2 * kReducingExtCoeffs + 2 * i, acc, 2 + 2 * i);
+        for (u32 j = 0; j < 2 * kChunk; ++j) {
+          const u32 w = 2 * base + j;
+          cs[j] = S[6 + (w < 2 * kReducingExtCoeffs ? w : 2 * kReducingExtCoeffs - 1)];
+        }
+        get_many(m, cs, dst);
+      };
+      load(0, cur);
+#pragma unroll 1
+      for (u32 base = 0; base < kReducingExtCoeffs; base += kChunk) {
+        if (base + kChunk < kReducingExtCoeffs) load(base + kChunk, nxt);
+#pragma unroll
+        for (u32 j = 0; j < kChunk; ++j) {
+          const u32 i = base + j;
+          if (i < kReducingExtCoeffs) {
+            acc = de_add(de_mul(acc, alpha), DE{cur[2 * j], cur[2 * j + 1]});
+            if (i == kReducingExtCoeffs - 1) PE(0, acc, 0);
+            else PE(6 + 2 * kReducingExtCoeffs + 2 * i, acc, 2 + 2 * i);
+          }
+        }
+#pragma unroll
+        for (u32 j = 0; j < 2 * kChunk; ++j) cur[j] = nxt[j];
       }
       break;
     }
@@ -531,11 +610,16 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       break;
     }
     case GEN_INTERPOLATION: {
+      u32 sl[35];
+      u64 in[35];  // shift, 16 values, evaluation point: wires 0 .. 34
+#pragma unroll
+      for (u32 i = 0; i < 35; ++i) sl[i] = S[i];
+      get_many(m, sl, in);
       DE vals[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) vals[i] = GE(1 + 2 * i);
-      const DE point = GE(33);
-      const DE x = de_scale(point, gl_inv(gl::canon(G(0))));  // shifted_evaluation_point = evaluation_point / shift
+      for (int i = 0; i < 16; ++i) vals[i] = DE{in[1 + 2 * i], in[2 + 2 * i]};
+      const DE point{in[33], in[34]};
+      const DE x = de_scale(point, gl_inv(gl::canon(in[0])));  // shifted_evaluation_point = evaluation_point / shift
       PE(45, x, 10);
       DE ev{0, 0}, pr{1, 0};
       auto step = [&](int i) {
@@ -558,9 +642,14 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       break;
     }
     case GEN_POSEIDON_MDS: {
+      u32 sl[24];
+      u64 in[24];
+#pragma unroll
+      for (u32 i = 0; i < 24; ++i) sl[i] = S[i];
+      get_many(m, sl, in);
       DE st[12];
 #pragma unroll
-      for (u32 i = 0; i < 12; ++i) st[i] = GE(2 * i);
+      for (u32 i = 0; i < 12; ++i) st[i] = DE{in[2 * i], in[2 * i + 1]};
 #pragma unroll
       for (u32 r = 0; r < 12; ++r) {
         DE acc = r == 0 ? de_scale(st[0], 8) : DE{0, 0};
@@ -776,7 +865,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__
 __global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__ ops, const u32* __restrict__ lvl, u32 n_levels,
                                                          u64* vals, u32* set, const u32* __restrict__ pslots,
                                                          const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
-                                                         PermCtx ctx) {
+                                                         u64* __restrict__ trace, PermCtx ctx) {
   __shared__ u64 rc_lds[360];
   ctx = stage_round_constants(rc_lds, ctx);
   const FMem m{vals, set, err};
@@ -795,13 +884,17 @@ __global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__
         const u32 pb = ops[o].b, pk = ops[o].kind, pc = ops[o].c;
         const u32 ps = lane < 25 ? pslots[(size_t)pb * 32 + lane] : 0;
         run_poseidon_generator<true>(m, ps, lane, o, poseidon_fresh_mask(pk, pc), err, ctx, &prev_slot, &prev_val);
+        if (trace && lane == 0) trace[o] = wall_clock64();  // (debug: completion time of every generator, 100 MHz ticks)
       }
     }
   } else {
     const u32 lt = (gwave - n_pw) * 64 + lane, n_lt = (n_gwaves - n_pw) * 64;
     for (u32 l = 0; l < n_levels; ++l) {
       const u32 s = lvl[2 * l], np = lvl[2 * l + 1], e = lvl[2 * l + 2];
-      for (u32 o = s + np + lt; o < e; o += n_lt) run_lane_generator(m, ops[o], o, tab, args, err);
+      for (u32 o = s + np + lt; o < e; o += n_lt) {
+        run_lane_generator(m, ops[o], o, tab, args, err);
+        if (trace) trace[o] = wall_clock64();
+      }
     }
   }
 }
@@ -1460,19 +1553,61 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
     return a.level != b.level ? a.level < b.level : ((a.op.kind & 0xFF) == GEN_POSEIDON) > ((b.op.kind & 0xFF) == GEN_POSEIDON);
   });
-  std::vector<WOp> ops(items.size());
-  std::vector<u32> lvl;
-  int cur = -1;
-  for (size_t k = 0; k < items.size(); ++k) {
-    ops[k] = items[k].op;
-    if (items[k].level != cur) {
-      cur = items[k].level;
-      lvl.push_back((u32)k);
-      lvl.push_back(0);
+  // Emit level by level: the PoseidonGate rows first (one per wavefront), then the lane generators.  In the dataflow interpreter a
+  // wavefront executes the code paths of ALL the generator kinds its 64 lanes hold, one after the other; the long single-lane
+  // generators (a ReducingExtensionGate's 32-step Horner chain, a CosetInterpolationGate, an extension inversion: 25-35 us each)
+  // would add up inside one wavefront.  So each of those kinds starts at a multiple of 64 lanes (padding with no-op records):
+  // different kinds of a level run on different wavefronts, side by side.  (Tables in LDS are walked by one workgroup: no padding.)
+  auto weight_class = [](u32 kind) -> int {
+    switch (kind & 0xFF) {
+      case GEN_REDUCING: return 1;
+      case GEN_REDUCING_EXT: return 2;
+      case GEN_INTERPOLATION: return 3;
+      case GEN_QUOTIENT_EXT: return 4;
+      case GEN_POSEIDON_MDS: return 5;
+      case GEN_BASE_SPLIT: return 6;
+      case GEN_WIRE_SPLIT: return 7;
+      case GEN_RANDOM_ACCESS: return 8;
+      default: return 0;
     }
-    if ((items[k].op.kind & 0xFF) == GEN_POSEIDON) ++lvl.back();
+  };
+  std::vector<WOp> ops;
+  std::vector<u32> lvl;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool pad = pass == 0 && !c->lds_bytes && c->has_recursion_gates;
+    ops.clear();
+    lvl.clear();
+    size_t k = 0;
+    while (k < items.size()) {
+      size_t k2 = k;
+      u32 np = 0;
+      while (k2 < items.size() && items[k2].level == items[k].level) {
+        np += (items[k2].op.kind & 0xFF) == GEN_POSEIDON;
+        ++k2;
+      }
+      lvl.push_back((u32)ops.size());
+      lvl.push_back(np);
+      for (size_t j = k; j < k + np; ++j) ops.push_back(items[j].op);
+      const size_t base = ops.size();
+      for (int cls = 0; cls <= 8; ++cls) {
+        bool first = true;
+        for (size_t j = k + np; j < k2; ++j) {
+          if (weight_class(items[j].op.kind) != cls) continue;
+          if (first && pad && ops.size() != base) {
+            WOp nop{};
+            nop.kind = kGenNop;
+            while ((ops.size() - base) % 64) ops.push_back(nop);
+          }
+          first = false;
+          ops.push_back(items[j].op);
+        }
+      }
+      k = k2;
+    }
+    lvl.push_back((u32)ops.size());
+    if (ops.size() <= c->ops_cap) break;  // (the padded table did not fit: emit it dense)
   }
-  lvl.push_back((u32)items.size());
+  if (ops.size() > c->ops_cap) return p2mt::fail(P2MT_EINVAL, "internal: generator table overflow");
   c->n_levels = (u32)(lvl.size() / 2);
   if (args.size() > c->args_cap) return p2mt::fail(P2MT_EINVAL, "internal: generator argument table overflow");
   hipStream_t st = rt().stream;
@@ -1601,7 +1736,7 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
   if (mode == 2) {
     hipLaunchKernelGGL(k_witness_flow, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
                        c->d_vals, c->d_set, (const u32*)c->d_pslots, (const u32*)c->d_slot_tab, (const u32*)c->d_args, c->d_err,
-                       p2mt::perm_ctx());
+                       c->d_trace, p2mt::perm_ctx());
   } else if (mode == 1) {
     P2MT_HIP(hipMemsetAsync(c->d_sync, 0, 8, st));
     hipLaunchKernelGGL(k_witness_grid, dim3(kGridBlocks), dim3(kBlock), 0, st, (const WOp*)c->d_ops, (const u32*)c->d_lvl, c->n_levels,
@@ -1745,6 +1880,7 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (c->ch) p2mt_challenger_destroy(c->ch);
   if (c->vch) p2mt_challenger_destroy(c->vch);
   if (c->d_verify) (void)hipFree(c->d_verify);
+  if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->vbch) p2mt::challenger_unwrap(c->vbch);
   if (c->d_vbatch) (void)hipFree(c->d_vbatch);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1968,7 +2104,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   c->init_cap = c->const_inits.size() + n_targets;
   const size_t o_init = carve(2 * c->init_cap);
   const size_t o_wslot = carve(n * kNumWires + 1), o_pislot = carve((c->n_pi + 2) / 2);
-  c->ops_cap = c->gens.size();
+  c->ops_cap = c->gens.size() + (c->has_recursion_gates ? 3 * c->gens.size() + 8192 : 0);  // room for the schedule's padding records
   const size_t o_ops = carve((c->ops_cap + 1) * sizeof(WOp) / 8 + 1), o_lvl = carve(c->ops_cap + 2);
   const size_t o_pslots = carve((size_t)c->counts[G_POSEIDON] * 16 + 16), o_prows = carve(c->counts[G_POSEIDON] / 2 + 1);
   c->args_cap = 0;
@@ -2840,5 +2976,33 @@ extern "C" int p2mt_proof_from_bytes(const p2mt_circuit_data* c, const uint8_t* 
   words(sh.tail_words);
   for (size_t i = 0; i < c->proof_len; ++i)  // plonky2's read_field rejects non-canonical encodings
     if (proof_out[i] >= gl::P) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: non-canonical field element");
+  return P2MT_OK;
+}
+
+// debug: timeline of the dataflow witness interpreter.  enable = 1 allocates the trace buffer (one tick per generator); after a
+// prove / generate_witness, out[3 * i .. 3 * i + 3) = (kind, level, completion tick at 100 MHz) of generator i in schedule order.
+extern "C" int p2mt_debug_witness_trace(p2mt_circuit_data* c, int enable, uint64_t* out, size_t cap, size_t* n_out) {
+  if (!c) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  const size_t n_ops = c->ops_cap;
+  if (enable && !c->d_trace) {
+    if (hipMalloc((void**)&c->d_trace, (n_ops + 1) * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(trace) failed");
+    P2MT_HIP(hipMemset(c->d_trace, 0, (n_ops + 1) * 8));
+  }
+  if (!out) return P2MT_OK;
+  if (!c->d_trace || cap < 3 * n_ops) return p2mt::fail(P2MT_EINVAL, "witness_trace: not enabled or buffer too small");
+  std::vector<u64> ticks(n_ops);
+  std::vector<WOp> ops(n_ops);
+  std::vector<u32> lvl(2 * c->n_levels + 1);
+  P2MT_HIP(hipMemcpy(ticks.data(), c->d_trace, n_ops * 8, hipMemcpyDeviceToHost));
+  P2MT_HIP(hipMemcpy(ops.data(), c->d_ops, n_ops * sizeof(WOp), hipMemcpyDeviceToHost));
+  P2MT_HIP(hipMemcpy(lvl.data(), c->d_lvl, lvl.size() * 4, hipMemcpyDeviceToHost));
+  size_t n = 0;
+  for (u32 l = 0; l < c->n_levels; ++l)
+    for (u32 o = lvl[2 * l]; o < lvl[2 * l + 2]; ++o, ++n) {
+      out[3 * n] = ops[o].kind & 0xFF;
+      out[3 * n + 1] = l;
+      out[3 * n + 2] = ticks[o];
+    }
+  if (n_out) *n_out = n;
   return P2MT_OK;
 }
