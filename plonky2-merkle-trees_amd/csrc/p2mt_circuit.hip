@@ -322,6 +322,15 @@ GL_DEV DE de_mul(DE x, DE y) {
   return DE{gl::mul_add(gl::mul(x.b, y.b), 7, gl::mul(x.a, y.a)), gl::mul_add(x.a, y.b, gl::mul(x.b, y.a))};
 }
 GL_DEV DE de_scale(DE x, u64 c) { return DE{gl::mul(x.a, c), gl::mul(x.b, c)}; }
+// multiplication by a FIXED element (the alpha of a Horner chain): 7 y.b is formed once, and the four products of a step are
+// independent of each other -- one multiplication deep instead of two (a chain step is latency-bound on its single wavefront)
+struct DEFixed {
+  u64 a, b, b7;
+};
+GL_DEV DEFixed de_fix(DE y) { return DEFixed{y.a, y.b, gl::mul(y.b, 7)}; }
+GL_DEV DE de_mul_fixed(DE x, const DEFixed& y) {
+  return DE{gl::add(gl::mul(x.a, y.a), gl::mul(x.b, y.b7)), gl::add(gl::mul(x.a, y.b), gl::mul(x.b, y.a))};
+}
 GL_DEV DE de_inv(DE x) {  // (a - bX) / (a^2 - 7 b^2)
   const u64 n = gl::canon(fsub(gl::sqr(x.a), gl::mul(gl::sqr(x.b), 7)));
   const u64 ni = gl_inv(n);
@@ -472,29 +481,31 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
   const Fresh fr = fresh_of(op);
   const u32* S = tab + (size_t)op.a * kNumWires;  // slots of the row's wires (row-tied generators only)
   auto G = [&](u32 col) { return m.get(S[col]); };
-  auto PE = [&](u32 col, DE v, u32 ord) {  // ord: ordinal of the pair's first word among the generator's outputs
-    put_out(m, S[col], v.a, fr.at(ord), err, o);
-    put_out(m, S[col + 1], v.b, fr.at(ord + 1), err, o);
-  };
   switch (op.kind & 0xFF) {
     case GEN_ARITH_EXT: {
       const u32 at = 8 * op.b;
-      u32 sl[6];
+      u32 sl[6], os[2];
       u64 in[6];
 #pragma unroll
       for (u32 i = 0; i < 6; ++i) sl[i] = S[at + i];
+      os[0] = S[at + 6], os[1] = S[at + 7];  // (output slots looked up with the operands: a store never waits for its address)
       get_many(m, sl, in);
-      PE(at + 6, de_add(de_scale(de_mul(DE{in[0], in[1]}, DE{in[2], in[3]}), op.c0), de_scale(DE{in[4], in[5]}, op.c1)), 0);
+      const DE r = de_add(de_scale(de_mul(DE{in[0], in[1]}, DE{in[2], in[3]}), op.c0), de_scale(DE{in[4], in[5]}, op.c1));
+      put_out(m, os[0], r.a, fr.at(0), err, o);
+      put_out(m, os[1], r.b, fr.at(1), err, o);
       break;
     }
     case GEN_MUL_EXT: {
       const u32 at = 6 * op.b;
-      u32 sl[4];
+      u32 sl[4], os[2];
       u64 in[4];
 #pragma unroll
       for (u32 i = 0; i < 4; ++i) sl[i] = S[at + i];
+      os[0] = S[at + 4], os[1] = S[at + 5];
       get_many(m, sl, in);
-      PE(at + 4, de_scale(de_mul(DE{in[0], in[1]}, DE{in[2], in[3]}), op.c0), 0);
+      const DE r = de_scale(de_mul(DE{in[0], in[1]}, DE{in[2], in[3]}), op.c0);
+      put_out(m, os[0], r.a, fr.at(0), err, o);
+      put_out(m, os[1], r.b, fr.at(1), err, o);
       break;
     }
     case GEN_QUOTIENT_EXT: {
@@ -516,31 +527,42 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 #pragma unroll
       for (u32 i = 0; i < 4; ++i) sl[i] = S[2 + i];
       get_many(m, sl, in);
-      const DE alpha{in[0], in[1]};
+      const DEFixed alpha = de_fix(DE{in[0], in[1]});
       DE acc{in[2], in[3]};
-      u32 cs[kChunk];
+      // per chunk: the coefficient values and the slots of the accumulator wires the steps write (table lookups: fetched a chunk
+      // ahead, or every store would wait for its own address)
+      u32 cs[kChunk], os_cur[2 * kChunk], os_nxt[2 * kChunk];
       u64 cur[kChunk], nxt[kChunk];
-      auto load = [&](u32 base, u64 (&dst)[kChunk]) {
+      auto out_col = [](u32 i) { return i == kReducingCoeffs - 1 ? 0u : 6 + kReducingCoeffs + 2 * i; };
+      auto load = [&](u32 base, u64 (&dst)[kChunk], u32 (&od)[2 * kChunk]) {
 #pragma unroll
-        for (u32 j = 0; j < kChunk; ++j) cs[j] = S[6 + (base + j < kReducingCoeffs ? base + j : kReducingCoeffs - 1)];
+        for (u32 j = 0; j < kChunk; ++j) {
+          const u32 i = base + j < kReducingCoeffs ? base + j : kReducingCoeffs - 1;
+          cs[j] = S[6 + i];
+          od[2 * j] = S[out_col(i)];
+          od[2 * j + 1] = S[out_col(i) + 1];
+        }
         get_many(m, cs, dst);
       };
-      load(0, cur);
+      load(0, cur, os_cur);
 #pragma unroll 1
       for (u32 base = 0; base < kReducingCoeffs; base += kChunk) {
-        if (base + kChunk < kReducingCoeffs) load(base + kChunk, nxt);
+        if (base + kChunk < kReducingCoeffs) load(base + kChunk, nxt, os_nxt);
 #pragma unroll
         for (u32 j = 0; j < kChunk; ++j) {
           const u32 i = base + j;
           if (i < kReducingCoeffs) {
-            acc = de_mul(acc, alpha);
+            acc = de_mul_fixed(acc, alpha);
             acc.a = gl::add(acc.a, cur[j]);
-            if (i == kReducingCoeffs - 1) PE(0, acc, 0);
-            else PE(6 + kReducingCoeffs + 2 * i, acc, 2 + 2 * i);
+            const u32 ord = i == kReducingCoeffs - 1 ? 0 : 2 + 2 * i;
+            put_out(m, os_cur[2 * j], acc.a, fr.at(ord), err, o);
+            put_out(m, os_cur[2 * j + 1], acc.b, fr.at(ord + 1), err, o);
           }
         }
 #pragma unroll
         for (u32 j = 0; j < kChunk; ++j) cur[j] = nxt[j];
+#pragma unroll
+        for (u32 j = 0; j < 2 * kChunk; ++j) os_cur[j] = os_nxt[j];
       }
       break;
     }
@@ -551,33 +573,38 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 #pragma unroll
       for (u32 i = 0; i < 4; ++i) sl[i] = S[2 + i];
       get_many(m, sl, in);
-      const DE alpha{in[0], in[1]};
+      const DEFixed alpha = de_fix(DE{in[0], in[1]});
       DE acc{in[2], in[3]};
-      u32 cs[2 * kChunk];
+      u32 cs[2 * kChunk], os_cur[2 * kChunk], os_nxt[2 * kChunk];
       u64 cur[2 * kChunk], nxt[2 * kChunk];
-      auto load = [&](u32 base, u64 (&dst)[2 * kChunk]) {
+      auto out_col = [](u32 i) { return i == kReducingExtCoeffs - 1 ? 0u : 6 + 2 * kReducingExtCoeffs + 2 * i; };
+      auto load = [&](u32 base, u64 (&dst)[2 * kChunk], u32 (&od)[2 * kChunk]) {
 #pragma unroll
-        for (u32 j = 0; j < 2 * kChunk; ++j) {
-          const u32 w = 2 * base + j;
-          cs[j] = S[6 + (w < 2 * kReducingExtCoeffs ? w : 2 * kReducingExtCoeffs - 1)];
+        for (u32 j = 0; j < kChunk; ++j) {
+          const u32 i = base + j < kReducingExtCoeffs ? base + j : kReducingExtCoeffs - 1;
+          cs[2 * j] = S[6 + 2 * i];
+          cs[2 * j + 1] = S[7 + 2 * i];
+          od[2 * j] = S[out_col(i)];
+          od[2 * j + 1] = S[out_col(i) + 1];
         }
         get_many(m, cs, dst);
       };
-      load(0, cur);
+      load(0, cur, os_cur);
 #pragma unroll 1
       for (u32 base = 0; base < kReducingExtCoeffs; base += kChunk) {
-        if (base + kChunk < kReducingExtCoeffs) load(base + kChunk, nxt);
+        if (base + kChunk < kReducingExtCoeffs) load(base + kChunk, nxt, os_nxt);
 #pragma unroll
         for (u32 j = 0; j < kChunk; ++j) {
           const u32 i = base + j;
           if (i < kReducingExtCoeffs) {
-            acc = de_add(de_mul(acc, alpha), DE{cur[2 * j], cur[2 * j + 1]});
-            if (i == kReducingExtCoeffs - 1) PE(0, acc, 0);
-            else PE(6 + 2 * kReducingExtCoeffs + 2 * i, acc, 2 + 2 * i);
+            acc = de_add(de_mul_fixed(acc, alpha), DE{cur[2 * j], cur[2 * j + 1]});
+            const u32 ord = i == kReducingExtCoeffs - 1 ? 0 : 2 + 2 * i;
+            put_out(m, os_cur[2 * j], acc.a, fr.at(ord), err, o);
+            put_out(m, os_cur[2 * j + 1], acc.b, fr.at(ord + 1), err, o);
           }
         }
 #pragma unroll
-        for (u32 j = 0; j < 2 * kChunk; ++j) cur[j] = nxt[j];
+        for (u32 j = 0; j < 2 * kChunk; ++j) cur[j] = nxt[j], os_cur[j] = os_nxt[j];
       }
       break;
     }
@@ -594,19 +621,27 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
     case GEN_BASE_SPLIT: {
       const u64 v = gl::canon(G(0));
       if (v >> kBaseSumLimbs) atomicCAS(err, 0, (int)o + 1);  // "Integer too large to fit in given number of limbs"
-#pragma unroll 9
-      for (u32 j = 0; j < kBaseSumLimbs; ++j) put_out(m, S[1 + j], (v >> j) & 1, fr.at(j), err, o);
+      u32 os[kBaseSumLimbs];  // the limb wires' slots, looked up together
+#pragma unroll
+      for (u32 j = 0; j < kBaseSumLimbs; ++j) os[j] = S[1 + j];
+#pragma unroll
+      for (u32 j = 0; j < kBaseSumLimbs; ++j) put_out(m, os[j], (v >> j) & 1, fr.at(j), err, o);
       break;
     }
     case GEN_RANDOM_ACCESS: {
       const u32 at = 18 * op.b;
+      u32 os[1 + kRaBits];  // claimed element, then the index bits
+      os[0] = S[at + 1];
+#pragma unroll
+      for (u32 j = 0; j < kRaBits; ++j) os[1 + j] = S[74 + kRaBits * op.b + j];
       const u64 idx = gl::canon(G(at));
       if (idx >= 16) {
         atomicCAS(err, 0, (int)o + 1);  // "Access index is larger than the vector size"
         break;
       }
-      put_out(m, S[at + 1], G(at + 2 + (u32)idx), fr.at(0), err, o);
-      for (u32 j = 0; j < kRaBits; ++j) put_out(m, S[74 + kRaBits * op.b + j], (idx >> j) & 1, fr.at(1 + j), err, o);
+      put_out(m, os[0], G(at + 2 + (u32)idx), fr.at(0), err, o);
+#pragma unroll
+      for (u32 j = 0; j < kRaBits; ++j) put_out(m, os[1 + j], (idx >> j) & 1, fr.at(1 + j), err, o);
       break;
     }
     case GEN_INTERPOLATION: {
@@ -618,9 +653,16 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       DE vals[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) vals[i] = DE{in[1 + 2 * i], in[2 + 2 * i]};
+      u32 os[12];  // wires 35 .. 46: the outputs
+#pragma unroll
+      for (u32 i = 0; i < 12; ++i) os[i] = S[35 + i];
+      auto PO = [&](u32 col, DE v, u32 ord) {
+        put_out(m, os[col - 35], v.a, fr.at(ord), err, o);
+        put_out(m, os[col - 34], v.b, fr.at(ord + 1), err, o);
+      };
       const DE point{in[33], in[34]};
       const DE x = de_scale(point, gl_inv(gl::canon(in[0])));  // shifted_evaluation_point = evaluation_point / shift
-      PE(45, x, 10);
+      PO(45, x, 10);
       DE ev{0, 0}, pr{1, 0};
       auto step = [&](int i) {
         const DE term{gl::sub_c(x.a, gates_rec::kCosetDomainDev[i]), x.b};
@@ -630,15 +672,15 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
       };
 #pragma unroll
       for (int i = 0; i < 6; ++i) step(i);
-      PE(37, ev, 2);
-      PE(41, pr, 6);
+      PO(37, ev, 2);
+      PO(41, pr, 6);
 #pragma unroll
       for (int i = 6; i < 11; ++i) step(i);
-      PE(39, ev, 4);
-      PE(43, pr, 8);
+      PO(39, ev, 4);
+      PO(43, pr, 8);
 #pragma unroll
       for (int i = 11; i < 16; ++i) step(i);
-      PE(35, ev, 0);
+      PO(35, ev, 0);
       break;
     }
     case GEN_POSEIDON_MDS: {
@@ -647,6 +689,9 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 #pragma unroll
       for (u32 i = 0; i < 24; ++i) sl[i] = S[i];
       get_many(m, sl, in);
+      u32 os[24];
+#pragma unroll
+      for (u32 i = 0; i < 24; ++i) os[i] = S[24 + i];
       DE st[12];
 #pragma unroll
       for (u32 i = 0; i < 12; ++i) st[i] = DE{in[2 * i], in[2 * i + 1]};
@@ -655,7 +700,8 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
         DE acc = r == 0 ? de_scale(st[0], 8) : DE{0, 0};
 #pragma unroll
         for (u32 i = 0; i < 12; ++i) acc = de_add(acc, de_scale(st[(i + r) % 12], gates_rec::mds_circ((int)i)));
-        PE(24 + 2 * r, acc, 2 * r);
+        put_out(m, os[2 * r], acc.a, fr.at(2 * r), err, o);
+        put_out(m, os[2 * r + 1], acc.b, fr.at(2 * r + 1), err, o);
       }
       break;
     }
