@@ -220,7 +220,10 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                    "leaves_per_gpu": n, "total_leaves": n * world, "hashes_per_step": total_hashes,
                    "poseidon_variant": {"mds": mds.value, "partial": partial.value},
                    "stage1": info["key"],
-                   "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none"},
+                   "sharding": "leaf ranges per rank + all-gather of 32-byte shard roots" if world > 1 else "none",
+                   "exchange": ("device-resident: p2mt_mmr_root_dev -> all_gather_into_tensor (RCCL) -> one combine launch -> "
+                                "one read-back" if shard._device_exchange() else
+                                ("host round trip (gloo rehearsal backend)" if dist is not None else "none (one rank)"))},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS,
                      "traffic": pmc.get("hbm_bytes_per_launch"),
@@ -742,8 +745,37 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N ...` -> `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`
+    as a child process (one rank per GPU over RCCL); returns its exit code.  Rank 0's JSON line reaches stdout unchanged."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(
+        description=__doc__.split("\n\n")[0],
+        epilog="multi-GPU examples (no launcher needed; torch.distributed.run works too):\n"
+               "  python bench.py --gpus 8                                   weak scaling: 2^24 leaves per GPU, one 2^27-leaf MMR\n"
+               "  python bench.py --gpus 8 --scaling strong                  BASELINE's headline: one 2^24-leaf MMR over 8 GPUs\n"
+               "  python bench.py --gpus 8 --log-leaves 23                   BASELINE config 5: 2^26 leaves, 2^23 per GPU\n"
+               "  python bench.py --gpus 2 --backend gloo --single-device    rehearsal of the N > 1 path on a 1-GPU box\n"
+               "  python bench.py --gpus 1 --force-collective                rehearsal of the RCCL exchange with one rank",
+        formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -762,23 +794,40 @@ def main():
                     help="torch.distributed backend; gloo + --single-device exist only to exercise the N>1 code "
                          "path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="test only: every rank uses GPU 0")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: still create the process group (world_size 1) and go through the device-resident exchange "
+                         "(root -> all_gather_into_tensor -> combine launch): rehearses the RCCL path on a 1-GPU box")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver's launcher would.  This runs before
+        # torch is imported or any HIP call is made (a process that has touched the GPU must never be replaced or forked), the
+        # ranks are fresh child processes, and their output and exit code are passed through.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or without a "
+                         "launcher at all (bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    if not args.single_device and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU (%d visible): one process per GPU; --single-device exists for rehearsals only"
+                         % (local_rank, torch.cuda.device_count()))
     dev_index = 0 if args.single_device else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # --force-collective without a launcher: a one-rank group on the loopback
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:

@@ -165,6 +165,9 @@ int p2mt_mmr_copy_elements(const p2mt_mmr *m, size_t first, size_t count, uint64
 int p2mt_mmr_peaks(const p2mt_mmr *m, uint64_t *peaks_out /*[<=64][4]*/, int *n_peaks);
 /* MMR::bagging_the_peaks (:122-127): hash_or_noop over all peak elements (one peak => the peak). */
 int p2mt_mmr_root(const p2mt_mmr *m, uint64_t *root_out /*[4]*/);
+/* The same with the result left in device memory: enqueued on the library stream, nothing synchronised (what the sharded
+ * build hands to the all-gather without a host round trip). */
+int p2mt_mmr_root_dev(const p2mt_mmr *m, uint64_t *d_root_out /*[4], device*/);
 /* MMR::get_proof (:209-223) = get_subtree_proof_elm (:147-176) + get_peaks. */
 int p2mt_mmr_proof(const p2mt_mmr *m, size_t mmr_index, uint64_t *siblings_out /*[<=64][4]*/,
                    uint8_t *lefts_out /*[<=64]*/, int *n_siblings, uint64_t *peaks_out /*[<=64][4]*/, int *n_peaks,
@@ -202,6 +205,10 @@ int p2mt_mmr_load(p2mt_mmr *m, const char *path);
  * log2(world) levels.  top_nodes_out: (world-1) HashOuts, level-major bottom-up; root_out: the peak. */
 int p2mt_mmr_combine_shard_roots(const uint64_t *shard_roots /*[world][4]*/, size_t world,
                                  uint64_t *top_nodes_out /*[world-1][4] or NULL*/, uint64_t *root_out /*[4]*/);
+/* The same on device pointers: ONE launch for all log2(world) levels on the library stream, nothing synchronised, so a step of
+ * the sharded build is build -> p2mt_mmr_root_dev -> all-gather (RCCL) -> this -> one 32-byte read-back.  world <= 1024. */
+int p2mt_mmr_combine_shard_roots_dev(const uint64_t *d_shard_roots /*[world][4]*/, size_t world,
+                                     uint64_t *d_top_nodes_out /*[world-1][4] or NULL*/, uint64_t *d_root_out /*[4]*/);
 /* post-order position of the first element of shard `rank` and of top node (height h above shard roots, index j) */
 size_t p2mt_mmr_shard_first_pos(size_t n_local, size_t rank);
 size_t p2mt_mmr_node_pos(size_t last_leaf, unsigned height); /* 2L - popcount(L) + h */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "p2mt_mmr_load": (C.c_int, [voidp, C.c_char_p]),
     "p2mt_mmr_peaks": (C.c_int, [voidp, voidp, intp]),
     "p2mt_mmr_root": (C.c_int, [voidp, voidp]),
+    "p2mt_mmr_root_dev": (C.c_int, [voidp, voidp]),
     "p2mt_mmr_proof": (C.c_int, [voidp, C.c_size_t, voidp, voidp, intp, voidp, intp, sizep]),
     "p2mt_mmr_proof_batch": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp, voidp]),
     "p2mt_mmr_proof_batch_dev": (C.c_int, [voidp, voidp, C.c_size_t, C.c_size_t, voidp, voidp, voidp]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "p2mt_mmr_proof_verify_batch": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp, C.c_int, voidp, voidp,
                                               C.c_size_t, voidp]),
     "p2mt_mmr_combine_shard_roots": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_mmr_combine_shard_roots_dev": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
     "p2mt_mmr_shard_first_pos": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "p2mt_mmr_node_pos": (C.c_size_t, [C.c_size_t, C.c_uint]),
     "p2mt_ntt_batch": (C.c_int, [voidp, C.c_uint, C.c_size_t, C.c_int]),

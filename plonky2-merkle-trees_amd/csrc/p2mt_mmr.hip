@@ -215,6 +215,31 @@ __global__ void k_bag_peaks(const u64* __restrict__ peaks, int n_peaks, u64* __r
   store_hash(root_out, o);
 }
 
+// The top log2(world) levels above the gathered shard roots in ONE launch: a single 1024-lane workgroup, one
+// wavefront per node on the 12-lane layout, levels handed on through LDS.  world <= kMaxWorld.
+constexpr unsigned kMaxWorld = 1024;
+__global__ __launch_bounds__(1024) void k_combine_roots(const u64* __restrict__ roots, unsigned world, u64* __restrict__ top,
+                                                        u64* __restrict__ root_out, PermCtx ctx) {
+  __shared__ u64 rc_lds[360];
+  __shared__ __attribute__((aligned(16))) u64 lvl[2][kMaxWorld * 4];  // ping-pong: level l lives in lvl[l & 1]
+  ctx = stage_round_constants(rc_lds, ctx);
+  for (unsigned k = threadIdx.x; k < world * 4; k += blockDim.x) lvl[0][k] = gl::canon(roots[k]);
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  unsigned l = 0, off = 0;  // off: nodes of the lower top levels already written (level-major, bottom-up)
+  for (unsigned cnt = world; cnt > 1; cnt >>= 1, ++l) {
+    const u64* src = lvl[l & 1];
+    u64* dst = lvl[(l + 1) & 1];
+    for (unsigned j = wave; j < cnt / 2; j += n_waves) {  // wave-uniform
+      two_to_one_wave(src + 8 * j, src + 8 * j + 4, dst + 4 * j, ctx);
+      if (top && (threadIdx.x & 63) < 4) top[4 * (off + j) + (threadIdx.x & 63)] = dst[4 * j + (threadIdx.x & 63)];
+    }
+    off += cnt / 2;
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) root_out[threadIdx.x] = lvl[l & 1][threadIdx.x];
+}
+
 // remainder of the greedy perfect-subtree decomposition of x == height of the element at index x
 // (get_heights_bitmap_for_mmr_size(x).1, :39-81)
 __host__ __device__ inline unsigned mmr_remainder(size_t x) {
@@ -758,6 +783,16 @@ static int mmr_peaks_root(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks, 
   return P2MT_OK;
 }
 
+extern "C" int p2mt_mmr_root_dev(const p2mt_mmr* m, uint64_t* d_root_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!m || !d_root_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  P2MT_TRY(mmr_flush(m));
+  PosList pl;
+  P2MT_TRY(mmr_peak_positions(m, &pl));
+  P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, m->scratch, d_root_out);
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_mmr_peaks(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks) {
   if (!peaks_out || !n_peaks) return p2mt::fail(P2MT_EINVAL, "null pointer");
   return mmr_peaks_root(m, peaks_out, n_peaks, nullptr);
@@ -890,27 +925,36 @@ extern "C" int p2mt_mmr_proof_verify(const uint64_t* siblings, const uint8_t* le
   return P2MT_OK;
 }
 
+extern "C" int p2mt_mmr_combine_shard_roots_dev(const uint64_t* d_shard_roots, size_t world, uint64_t* d_top_nodes_out,
+                                                uint64_t* d_root_out) {
+  P2MT_TRY(p2mt::ensure_init());
+  if (!d_shard_roots || !d_root_out || world == 0 || (world & (world - 1)) || world > kMaxWorld)
+    return p2mt::fail(P2MT_EINVAL, "world must be a power of two <= 1024");
+  // (the reference hashes nothing at world == 1: the kernel then only canonicalises and copies the root)
+  hipLaunchKernelGGL(k_combine_roots, dim3(1), dim3(1024), 0, rt().stream, d_shard_roots, (unsigned)world, d_top_nodes_out,
+                     d_root_out, p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
 extern "C" int p2mt_mmr_combine_shard_roots(const uint64_t* shard_roots, size_t world, uint64_t* top_nodes_out,
                                             uint64_t* root_out) {
   P2MT_TRY(p2mt::ensure_init());
-  if (!shard_roots || !root_out || world == 0 || (world & (world - 1))) return p2mt::fail(P2MT_EINVAL, "world must be a power of two");
+  if (!shard_roots || !root_out || world == 0 || (world & (world - 1)) || world > kMaxWorld)
+    return p2mt::fail(P2MT_EINVAL, "world must be a power of two <= 1024");
   if (world == 1) {
     memcpy(root_out, shard_roots, 32);
     return P2MT_OK;
   }
   // level-major pairing of the shard roots: world/2 + world/4 + ... + 1 = world-1 nodes
-  DevBuf b;
-  P2MT_TRY(b.alloc((2 * world - 1) * 32));
+  DevBuf b;  // [world roots | world-1 top nodes | root]
+  P2MT_TRY(b.alloc(2 * world * 32));
   hipStream_t st = rt().stream;
-  P2MT_HIP(hipMemcpyAsync(b.p, shard_roots, world * 32, hipMemcpyHostToDevice, st));
-  u64* cur = b.as<u64>();
-  for (size_t cnt = world; cnt > 1; cnt /= 2) {
-    P2MT_TRY(p2mt::launch_merkle_level_dev(cur, cur + 4 * cnt, cnt / 2));
-    cur += 4 * cnt;
-  }
-  if (top_nodes_out)
-    P2MT_HIP(hipMemcpyAsync(top_nodes_out, b.as<u64>() + 4 * world, (world - 1) * 32, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipMemcpyAsync(root_out, cur, 32, hipMemcpyDeviceToHost, st));
+  u64* d = b.as<u64>();
+  P2MT_HIP(hipMemcpyAsync(d, shard_roots, world * 32, hipMemcpyHostToDevice, st));
+  P2MT_TRY(p2mt_mmr_combine_shard_roots_dev(d, world, d + 4 * world, d + 4 * (2 * world - 1)));
+  if (top_nodes_out) P2MT_HIP(hipMemcpyAsync(top_nodes_out, d + 4 * world, (world - 1) * 32, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(root_out, d + 4 * (2 * world - 1), 32, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
 }

@@ -3,7 +3,8 @@
 One process per GPU.  Rank r of `world` (a power of two) owns leaves [r*n_local, (r+1)*n_local), builds that
 perfect subtree locally (no data-path collective), then ONE all-gather of the 32-byte shard roots
 (torch.distributed: backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests) and
-log2(world) top levels hashed redundantly on every rank.  The exchange is latency-bound (world x 32 B);
+log2(world) top levels hashed redundantly on every rank.  With RCCL the roots never leave HBM: root -> all_gather_into_tensor ->
+one combine launch -> one 32-byte-scale read-back (`finish_dev`); with gloo the roots travel through the host (`finish`).  The exchange is latency-bound (world x 32 B);
 link bandwidth is irrelevant, so no ring/bucket tuning applies.
 
 Global post-order geometry (A.4): rank r's nodes occupy [first_pos(r), first_pos(r) + 2*n_local - 1) with
@@ -66,17 +67,50 @@ class ShardedMMR:
         return out.cpu().numpy().view(np.uint64).reshape(self.world, 4).copy()
 
     # ---- build
+    def _device_exchange(self):
+        """True when the exchange can stay in HBM: RCCL ("nccl") moves device tensors, gloo needs host memory."""
+        return self.dist is not None and self.dist.get_backend() == "nccl"
+
     def build_dev(self, d_leaves):
         """d_leaves: this rank's n_local leaves, resident in HBM (torch tensor or raw device pointer)."""
         self.local.reset()
         self.local.extend_dev(d_leaves, self.n_local)
+        if self._device_exchange():
+            return self.finish_dev()
         local_root = self.local.bagging_the_peaks()  # perfect subtree: one peak == its root
         return self.finish(local_root)
 
     def build(self, leaves):
         self.local.reset()
         self.local.extend(leaves)
+        if self._device_exchange():
+            return self.finish_dev()
         return self.finish(self.local.bagging_the_peaks())
+
+    def finish_dev(self):
+        """The exchange without a host round trip (RCCL): root of the local subtree written to HBM by the library ->
+        ONE all_gather_into_tensor of world x 32 B on preallocated device tensors -> ONE launch for the log2(world) top
+        levels (p2mt_mmr_combine_shard_roots_dev) -> one read-back of [roots | top nodes | root].  The library enqueues on
+        the default stream, which is torch's current stream here, so the collective is ordered after the build and the
+        combine after the collective without any host synchronisation."""
+        import torch
+        w = self.world
+        if getattr(self, "_d_all", None) is None:
+            # [w roots | w-1 top nodes | root] x 4 words; the local root is all-gathered from its own slot's copy
+            self._d_all = torch.zeros(2 * w * 4, dtype=torch.int64, device="cuda")
+            self._d_mine = torch.zeros(4, dtype=torch.int64, device="cuda")
+            self._h_all = torch.zeros(2 * w * 4, dtype=torch.int64).pin_memory()
+        lib = N.lib()
+        N.check(lib.p2mt_mmr_root_dev(self.local._h, N.ptr(self._d_mine)))
+        self.dist.all_gather_into_tensor(self._d_all[:4 * w], self._d_mine)
+        base = self._d_all.data_ptr()
+        N.check(lib.p2mt_mmr_combine_shard_roots_dev(base, w, base + 32 * w if w > 1 else None, base + 32 * (2 * w - 1)))
+        self._h_all.copy_(self._d_all)  # synchronises (device -> pinned host)
+        host = self._h_all.numpy().view(np.uint64).reshape(2 * w, 4)
+        self.shard_roots = host[:w].copy()
+        self.top_nodes = host[w:2 * w - 1].copy()
+        self.root = host[2 * w - 1].copy()
+        return self.root
 
     def finish(self, local_root):
         self.shard_roots = self.gather_roots(local_root)

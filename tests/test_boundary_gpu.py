@@ -214,3 +214,101 @@ def test_bench_prove_replicas_on_one_device(pkg):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "proofs/s"
     assert out["config"]["proofs_per_step"] == 256 and out["value"] > 1000
+
+
+# ---------------------------------------------------------------- round 3: the exchange stays in HBM; bench.py starts its own ranks
+class _FakeRcclGroup:
+    """Stands in for torch.distributed with the RCCL backend on ONE device: all_gather_into_tensor fills the output from the
+    roots the other "ranks" (shards built in this process) left in device memory.  Everything else -- p2mt_mmr_root_dev, the
+    preallocated device tensors, the single combine launch, the one read-back -- is the product's finish_dev()."""
+
+    def __init__(self, d_roots, rank):
+        self.d_roots, self.rank = d_roots, rank
+
+    def get_backend(self):
+        return "nccl"
+
+    def all_gather_into_tensor(self, out, mine):
+        import torch
+        assert out.is_cuda and mine.is_cuda and out.numel() == self.d_roots.numel()
+        assert torch.equal(mine, self.d_roots[4 * self.rank:4 * self.rank + 4]), "local root handed to the collective"
+        out.copy_(self.d_roots)
+
+
+@pytest.mark.parametrize("world", [1, 2, 8, 64])
+def test_device_resident_exchange(pkg, oracle, world):
+    """finish_dev(): root -> (all-gather) -> p2mt_mmr_combine_shard_roots_dev -> read-back, all on device pointers, against the
+    oracle's monolithic MMR (roots, every top node at its post-order position, the root)."""
+    import torch
+    k = 12
+    n, n_local = 1 << k, (1 << k) // world
+    leaves = pkg.synthetic.splitmix_leaves(n, 1234 + world)
+    d_all = torch.from_numpy(leaves.view(np.int64)).cuda()
+    full = oracle.mmr(leaves)
+    full_el = full.elements
+    d_roots = torch.zeros(4 * world, dtype=torch.int64, device="cuda")
+    shards = []
+    for r in range(world):
+        sh = pkg.ShardedMMR(pkg, n_local, r, world, None)
+        sh.local.reset()
+        sh.local.extend_dev(d_all[r * n_local:(r + 1) * n_local], n_local)
+        pkg._native.check(pkg.lib().p2mt_mmr_root_dev(sh.local._h, pkg._native.ptr(d_roots[4 * r:4 * r + 4])))
+        shards.append(sh)
+    torch.cuda.synchronize()
+    for r in (0, world - 1):
+        sh = shards[r]
+        sh.dist = _FakeRcclGroup(d_roots, r)
+        root = sh.finish_dev()
+        assert np.array_equal(root, full.bagging_the_peaks())
+        for q in range(world):
+            assert np.array_equal(sh.shard_roots[q], full_el[sh.first_pos(q) + 2 * n_local - 2])
+        off = 0
+        for h in range(1, sh.g + 1):
+            for j in range(world >> h):
+                assert np.array_equal(full_el[sh.top_node_pos(h, j)], sh.top_nodes[off + j]), (h, j)
+            off += world >> h
+    # refusals of the device entry point
+    lib, ptr = pkg.lib(), pkg._native.ptr
+    assert lib.p2mt_mmr_combine_shard_roots_dev(ptr(d_roots), 3, None, ptr(d_roots)) == pkg._native.P2MT_EINVAL
+    assert lib.p2mt_mmr_combine_shard_roots_dev(ptr(d_roots), 2048, None, ptr(d_roots)) == pkg._native.P2MT_EINVAL
+    assert lib.p2mt_mmr_combine_shard_roots_dev(None, 2, None, ptr(d_roots)) == pkg._native.P2MT_EINVAL
+
+
+def _bench_json(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("scaling,log_leaves", [("weak", 14), ("strong", 15)])
+def test_bench_starts_its_own_ranks(pkg, oracle, scaling, log_leaves):
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the command the driver uses for N = 1, with --gpus 2): bench.py
+    spawns torch.distributed.run itself before touching the GPU, forwards rank 0's JSON line and the exit code."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--single-device", "--log-leaves", str(log_leaves), "--scaling", scaling, "--no-prove", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env_clean, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    local_log = log_leaves - 1 if scaling == "strong" else log_leaves
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    leaves = np.concatenate([pkg.synthetic.bench_leaves(local_log, r) for r in range(2)])
+    assert [int(x) for x in oracle.mmr(leaves).bagging_the_peaks()] == out["root"]
+    # a failing child is not swallowed: more ranks than the (single) device without --single-device must exit non-zero
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--backend", "gloo", "--log-leaves", "10", "--no-prove", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=dict(env_clean, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=900, cwd=ROOT)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert bad.returncode != 0
+
+
+def test_bench_rccl_exchange_one_rank(pkg, oracle):
+    """The RCCL branch itself on the one GPU this box has: process group "nccl" with one rank, the device-resident exchange
+    (p2mt_mmr_root_dev -> all_gather_into_tensor over RCCL -> combine launch -> read-back) inside bench.py's timed steps."""
+    out = _bench_json([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "3",
+                       "--warmup", "1", "--log-leaves", "16", "--no-prove", "--no-cpu-baseline"])
+    leaves = pkg.synthetic.bench_leaves(16, 0)
+    assert [int(x) for x in oracle.mmr(leaves).bagging_the_peaks()] == out["root"]
+    assert out["config"]["exchange"].startswith("device")
