@@ -114,6 +114,8 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
                                                      u64* __restrict__ elements, size_t block0, size_t n_blocks,
                                                      PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
+  poseidon_fast::MfmaCtx mc;  // PR == 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
+  if constexpr (PR == 2) mc = poseidon_fast::mfma_ctx_init();
   const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
   if (blk >= block0 + n_blocks) return;
   const size_t first_leaf = blk << LV;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
       two_to_one_r<IMPL_FAST, PR, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {  // leaf pair: 10 of the 12 first S-boxes are constants
         ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
         rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
-      });
+      }, &mc);
       merges = (unsigned)__builtin_ctz(~pairs_done);  // trailing ones: carries of the binary counter
       pairs_done += 1;
       h = 1;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
         load_hash(sp, ll);
 #pragma unroll
         for (int k = 0; k < 4; ++k) rr[k] = cur[k];
-      });
+      }, &mc);
       merges -= 1;
       h += 1;
       store_hash(elements + 4 * node_pos(first_leaf + 2 * pairs_done - 1, h), o);
@@ -561,7 +563,10 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
   hipLaunchKernelGGL((k_mmr_subtree<LVV, BB>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, a >> span_log, \
                      n_blocks, p2mt::perm_ctx())
       if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64); else P2MT_SUB(5, 256); }
-      else if (rt().partial) {  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
+      else if (rt().partial == 2) {  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 2>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
+                           m->elements, a >> span_log, n_blocks, p2mt::perm_ctx());
+      } else if (rt().partial) {  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
         hipLaunchKernelGGL((k_mmr_subtree<4, 256, 1>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
                            m->elements, a >> span_log, n_blocks, p2mt::perm_ctx());
       } else { if (sb == 64) P2MT_SUB(4, 64); else if (sb == 128) P2MT_SUB(4, 128); else P2MT_SUB(4, 256); }

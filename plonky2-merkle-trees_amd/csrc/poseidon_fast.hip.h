@@ -187,6 +187,123 @@ GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
   });
 }
 
+// ------------------------------------------------------------------ MDS layer on the matrix pipe (round 3 A/B)
+// The MDS is a 12 x 12 contraction with 6-bit constants.  On 8-bit limbs of the state words it fits
+// v_mfma_i32_4x4x4_16b_i8, whose 16 blocks are independent 4x4x4 products over the lanes 4b..4b+3: with one hash per lane the B
+// operand of lane n is four bytes of hash n (byte t of words j0..j0+3), the A operand is a per-lane constant (MDS[r0 + lane%4][j0..j0+3])
+// and the four result registers of lane n are rows r0..r0+3 of ITS OWN hash -- no cross-lane movement (layout confirmed by
+// tools/ubench_mfma.hip).  Per layer: 24 v_xor (bytes -> signed), 48 v_perm_b32 (six 4x4 byte transposes), 72 MFMAs
+// (8 limbs x 3 row blocks x 3 K steps; the accumulators start at 128 * rowsum, which undoes the signed-byte offset), 96
+// v_mad_u64_u32 putting the 18-bit limb sums back together (the next round's constant rides in as the chain's initial addend), then
+// the same 96 -> 64 bit fold as the VALU form.
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+struct MfmaCtx {
+  u32 a[3][3];       // a[rb][jb]: bytes k = 0..3 = MDS[4 rb + (lane & 3)][4 jb + k]
+  mfma_v4i cinit[2]; // 128 * rowsum of rows 0..3 / of any other four rows
+};
+constexpr u32 mds_rowsum(int r) {
+  u32 t = 0;
+  for (int c = 0; c < 12; ++c) t += poseidon::mds_entry(r, c);
+  return t;
+}
+GL_DEV MfmaCtx mfma_ctx_init() {
+  MfmaCtx c;
+  const unsigned i = threadIdx.x & 3;
+  poseidon::static_for<0, 3>([&](auto rbc) {
+    constexpr int rb = decltype(rbc)::value;
+    poseidon::static_for<0, 3>([&](auto jbc) {
+      constexpr int jb = decltype(jbc)::value;
+      auto pack = [](int row) constexpr -> u32 {
+        return poseidon::mds_entry(row, 4 * jb) | (poseidon::mds_entry(row, 4 * jb + 1) << 8) |
+               (poseidon::mds_entry(row, 4 * jb + 2) << 16) | (poseidon::mds_entry(row, 4 * jb + 3) << 24);
+      };
+      constexpr u32 p0 = pack(4 * rb), p1 = pack(4 * rb + 1), p2 = pack(4 * rb + 2), p3 = pack(4 * rb + 3);
+      c.a[rb][jb] = i == 0 ? p0 : (i == 1 ? p1 : (i == 2 ? p2 : p3));
+    });
+  });
+  static_assert(mds_rowsum(1) == 256 && mds_rowsum(2) == 256 && mds_rowsum(3) == 256 && mds_rowsum(11) == 256, "circulant rows");
+  c.cinit[0] = mfma_v4i{(int)(128 * mds_rowsum(0)), 128 * 256, 128 * 256, 128 * 256};
+  c.cinit[1] = mfma_v4i{128 * 256, 128 * 256, 128 * 256, 128 * 256};
+  return c;
+}
+// acc += a * k, k wave-uniform (SGPR)
+GL_DEV void mac_sgpr(u64& acc, u32 a, u32 k) {
+  u64 unused;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "s"(k));
+}
+// first link: d = a * 1 + init, init a wave-uniform 64-bit value (SGPR pair)
+GL_DEV u64 mac_one_first(u32 a, u64 init_uniform) {
+  u64 d, unused;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(unused) : "v"(a), "s"(init_uniform));
+  return d;
+}
+GL_DEV u64 mac_one_first0(u32 a) {
+  u64 d, unused;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, 0" : "=v"(d), "=s"(unused) : "v"(a));
+  return d;
+}
+template <bool ADD, int ROWS = 12>
+GL_DEV void mds_layer_mfma(u64 (&s)[12], const u64* __restrict__ add, u64& sticky, const MfmaCtx& mc) {
+  // B operands: bt[jb][t] = (byte t of words 4jb .. 4jb+3) ^ 0x80, t = 0..7 over the 64-bit word
+  u32 bt[3][8];
+#pragma unroll
+  for (int jb = 0; jb < 3; ++jb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32 w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (u32)(s[4 * jb + k] >> (32 * h)) ^ 0x80808080u;
+      const u32 p01l = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), p01h = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+      const u32 p23l = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), p23h = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+      bt[jb][4 * h + 0] = __builtin_amdgcn_perm(p23l, p01l, 0x05040100u);
+      bt[jb][4 * h + 1] = __builtin_amdgcn_perm(p23l, p01l, 0x07060302u);
+      bt[jb][4 * h + 2] = __builtin_amdgcn_perm(p23h, p01h, 0x05040100u);
+      bt[jb][4 * h + 3] = __builtin_amdgcn_perm(p23h, p01h, 0x07060302u);
+    }
+  }
+  poseidon::static_for<0, (ROWS + 3) / 4>([&](auto rbc) {
+    constexpr int rb = decltype(rbc)::value;
+    // eight independent accumulation chains, K step by K step: no MFMA waits for the one issued just before it
+    mfma_v4i d[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) d[t] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)mc.a[rb][0], (int)bt[0][t], mc.cinit[rb ? 1 : 0], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) d[t] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)mc.a[rb][1], (int)bt[1][t], d[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) d[t] = __builtin_amdgcn_mfma_i32_4x4x4i8((int)mc.a[rb][2], (int)bt[2][t], d[t], 0, 0, 0);
+    // The results are consumed by inline-asm mads, which the compiler's hazard recogniser does not look into: a VALU read of an
+    // XDL result needs passes + 3 = 5 wait states on gfx950 (software-managed).  This statement depends on all eight
+    // accumulators, so it sits behind the last MFMA and in front of every consumer.
+    asm volatile("s_nop 7" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+    poseidon::static_for<0, 4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int r = 4 * rb + i;
+      if constexpr (r < ROWS) {
+        u64 al, ah;  // sum_t d_t 2^(8t) over the low / high half, every d_t in [0, 2^18)
+        if constexpr (ADD) {
+          const u64 c = add[r];
+          al = mac_one_first((u32)d[0][i], (u64)(u32)c);
+          ah = mac_one_first((u32)d[4][i], (u64)(u32)(c >> 32));
+        } else {
+          al = mac_one_first0((u32)d[0][i]);
+          ah = mac_one_first0((u32)d[4][i]);
+        }
+        mac_sgpr(al, (u32)d[1][i], 1u << 8);
+        mac_sgpr(ah, (u32)d[5][i], 1u << 8);
+        mac_sgpr(al, (u32)d[2][i], 1u << 16);
+        mac_sgpr(ah, (u32)d[6][i], 1u << 16);
+        mac_sgpr(al, (u32)d[3][i], 1u << 24);
+        mac_sgpr(ah, (u32)d[7][i], 1u << 24);
+        ah = add32((u32)(al >> 32), ah);
+        const u64 val = ((u64)(u32)ah << 32) | (u32)al;
+        u64 cm;
+        s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);
+        sticky |= cm;
+      }
+    });
+  });
+}
+
 // ------------------------------------------------------------------ sparse partial rounds (SPARSE = true)
 // plonky2's "fast" partial rounds (poseidon.rs partial_first_constant_layer / mds_partial_layer_init / mds_partial_layer_fast):
 //   s += FIRST;  s[1..] = INIT * s[1..]  (11 x 11, once);  22 x { s0 = sbox(s[0]) + K_r;  d = 25 s0 + sum_j W_rj s[j];
@@ -254,9 +371,20 @@ GL_DEV u64 mul_add_flag(u64 x, u64 k, u64 c, u64& sticky) {
 //   [leaf, 0, 0, 0] (hash_or_noop's zero padding, quirk Q1), i.e. half of all hashes of a tree build.  Only words 0 and 4 go
 //   through the first S-box layer; the other ten S-box outputs are the constants (rc[i])^7, read from rc[360 + ..].
 // SPARSE: the 22 partial rounds in the sparse form above (same function; the dense form is the default and the redo path).
-template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false>
-GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
+// MFMA: the dense MDS layers on the matrix pipe (mds_layer_mfma; `mc` from mfma_ctx_init(), made while every lane of the wave was
+//   still active).  Same function, same flag semantics.
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, bool MFMA = false>
+GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
   u64 sticky = 0;
+  static_assert(!(MFMA && (EXACT || SPARSE)), "the matrix-pipe MDS exists in the flag form with dense partial rounds only");
+  auto mds = [&](auto add_tag, auto rows_tag, const u64* add) {
+    constexpr bool kAdd = decltype(add_tag)::value;
+    constexpr int kRows = decltype(rows_tag)::value;
+    if constexpr (MFMA) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
+    else mds_layer<kAdd, kRows, EXACT>(s, add, sticky);
+  };
+  using T = std::true_type;
+  using R12 = std::integral_constant<int, 12>;
   auto sbox = [&](u64 x) -> u64 {
     if constexpr (EXACT) return exact::pow7(x);
     else return pow7(x, sticky);
@@ -273,7 +401,7 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
     }
 #pragma unroll
     for (int i = 8; i < 12; ++i) s[i] = rc[360 + (i - 8)];
-    mds_layer<true, 12, EXACT>(s, rc + 12, sticky);
+    mds(T{}, R12{}, rc + 12);
   } else {  // round 0
 #pragma unroll
     for (int i = 0; i < kVar; ++i) s[i] = gl::add_c(s[i], rc[i]);  // round 0 constants, exact
@@ -283,14 +411,14 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
 #pragma unroll
       for (int i = 8; i < 12; ++i) s[i] = rc[360 + (i - 8)];
     }
-    mds_layer<true, 12, EXACT>(s, rc + 12, sticky);
+    mds(T{}, R12{}, rc + 12);
   }
   static_assert(!(SPARSE && EXACT), "the exact redo path keeps the dense partial rounds");
 #pragma unroll 1
   for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS - (SPARSE ? 1 : 0); ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
-    mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
+    mds(T{}, R12{}, rc + 12 * (r + 1));
   }
   if constexpr (SPARSE) {
     {  // last full round of the first half: the addend of its MDS layer is FIRST instead of round 4's constants
@@ -341,18 +469,18 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc) {
 #pragma unroll 1
     for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {
       s[0] = sbox(s[0]);
-      mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
+      mds(T{}, R12{}, rc + 12 * (r + 1));
     }
   }
 #pragma unroll 1
   for (int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; r < POSEIDON_ROUNDS - 1; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
-    mds_layer<true, 12, EXACT>(s, rc + 12 * (r + 1), sticky);
+    mds(T{}, R12{}, rc + 12 * (r + 1));
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
-  mds_layer<false, OUT_ROWS, EXACT>(s, nullptr, sticky);
+  mds(std::false_type{}, std::integral_constant<int, OUT_ROWS>{}, nullptr);
   return sticky;
 }
 

@@ -310,7 +310,8 @@ extern "C" int p2mt_sync(void) {
 extern "C" const char* p2mt_last_error(void) { return p2mt::err_buf(); }
 
 extern "C" int p2mt_set_variant(int mds, int partial) {
-  if (mds < 0 || mds > 2 || partial < 0 || partial > 1) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  // partial: 0 dense, 1 sparse partial rounds; 2 (with mds == 2 only) = dense with the MDS layers on the matrix pipe (stage-1 A/B)
+  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 2 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
   return P2MT_OK;

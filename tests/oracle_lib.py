@@ -17,6 +17,8 @@ _u8p = C.POINTER(C.c_uint8)
 
 
 def build_oracle(force=False):
+    if os.environ.get("P2MT_ORACLE_SO"):  # the sanitizer leg (oracle/Makefile asan) points the tests at its own build
+        return os.environ["P2MT_ORACLE_SO"]
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):

@@ -2,6 +2,7 @@
 matches the reference's tables, and compute entry points fail loudly without a GPU (no CPU fallback)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -134,3 +135,34 @@ def test_circuit_builder_host_logic_matches_oracle(pkg, oracle, n_sib, n_peaks):
         with pytest.raises(pkg.P2mtError) as e:
             b.build()
         assert e.value.code == -3
+
+
+def test_rust_ffi_matches_header():
+    """shim/src/ffi.rs (the Rust extern block a maintainer of the reference links against; source only, no Rust toolchain here) is
+    generated from include/p2mt.h: it must be current and declare every exported function exactly once."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"])
+    assert r.returncode == 0, "shim/src/ffi.rs is stale: run python tools/gen_rust_ffi.py"
+    hdr = open(os.path.join(ROOT, "include", "p2mt.h")).read()
+    declared = set(re.findall(r"\b(p2mt_[a-z0-9_]+)\s*\(", hdr)) - {"p2mt_status"}
+    ffi = open(os.path.join(ROOT, "shim", "src", "ffi.rs")).read()
+    have = re.findall(r"pub fn (p2mt_\w+)\(", ffi)
+    assert sorted(have) == sorted(declared)
+    # the shim's modules call only functions the extern block declares
+    for rel in ("lib.rs", "simple_merkle_tree/simple_merkle_tree.rs", "mmr/merkle_mountain_ranges.rs"):
+        src = open(os.path.join(ROOT, "shim", "src", rel)).read()
+        for name in set(re.findall(r"ffi::(p2mt_\w+)", src)):
+            assert name in declared, (rel, name)
+    # the reference's public signatures are kept (file:line in the shim's docs)
+    mmr = open(os.path.join(ROOT, "shim", "src", "mmr", "merkle_mountain_ranges.rs")).read()
+    for sig in ("pub fn new() -> Self", "pub fn add_leaf(&mut self, leaf: GoldilocksField)",
+                "pub fn get_heights_bitmap_for_mmr_size(mmr_size: usize) -> (u64, usize)",
+                "pub fn get_mmr_index(leaf_normal_index: usize) -> usize",
+                "pub fn verify(self, leaf: GoldilocksField, root: HashOut<GoldilocksField>) -> bool",
+                "pub fn get_subtree_proof_elm(mmr: MMR, mmr_index: usize) -> Vec<(HashOut<GoldilocksField>, bool)>"):
+        assert sig in mmr, sig
+    mt = open(os.path.join(ROOT, "shim", "src", "simple_merkle_tree", "simple_merkle_tree.rs")).read()
+    for sig in ("pub fn build(leaves: Vec<GoldilocksField>) -> Self",
+                "pub fn get_merkle_proof(self, leaf_index: usize) -> Vec<HashOut<GoldilocksField>>",
+                "pub fn get_in_between_hashes(self, leaf_index: usize) -> Vec<HashOut<GoldilocksField>>"):
+        assert sig in mt, sig

@@ -269,6 +269,31 @@ def test_stage1_sparse_partial_rounds_variant(pkg, oracle):
         pkg.set_variant(*DEFAULT_VARIANT)
 
 
+def test_mfma_mds_variant(pkg, oracle):
+    """Variant (2, 2): the stage-1 MMR kernel with every MDS layer on the matrix pipe (v_mfma_i32_4x4x4_16b_i8 over 8-bit limbs, one
+    hash per lane, no cross-lane movement; an A/B that came out even, profiles/r03_mds_mfma_ab.txt, kept selectable) is the same
+    function: all nodes equal the oracle's on a ragged size (partial waves: the MFMA ignores EXEC) and on limb patterns that
+    stress the signed-byte offset (all-0x00, all-0x7F/0x80/0xFF bytes, p - 1), with and without the forced exact redo."""
+    n = (1 << 16) + 4099
+    leaves = splitmix_leaves(n, 0x5EED0322)
+    pat = [0, 1, P - 1, 0x7F7F7F7F7F7F7F7F, 0x8080808080808080, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF, 0x80FF7F0001FE807F,
+           0xFEFEFEFEFEFEFEFE, 0x0101010101010101]
+    leaves[:1024] = np.array([pat[i % len(pat)] for i in range(1024)], dtype=np.uint64)
+    om = oracle.mmr(leaves)
+    try:
+        pkg.set_variant(2, 2)
+        a = pkg.MMR.from_leaves(leaves)
+        assert np.array_equal(a.elements, om.elements)
+        pkg.lib().p2mt_debug_force_fallback(1)
+        b = pkg.MMR.from_leaves(leaves[:1 << 12])
+        assert np.array_equal(b.elements, oracle.mmr(leaves[:1 << 12]).elements)
+        with pytest.raises(Exception):
+            pkg.set_variant(0, 2)  # the matrix-pipe form exists for the fast path only
+    finally:
+        pkg.lib().p2mt_debug_force_fallback(0)
+        pkg.set_variant(*DEFAULT_VARIANT)
+
+
 def test_mmr_checkpoint_roundtrip(pkg, oracle, tmp_path):
     """save -> load -> extend continues exactly where the saved MMR stopped; corrupted files are rejected."""
     leaves = splitmix_leaves(3000, 0x5EED0099)
