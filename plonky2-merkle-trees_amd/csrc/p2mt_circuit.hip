@@ -1821,87 +1821,122 @@ int witness_status(p2mt_circuit_data* c, const int* err) {
 
 // ==================================================================================================== C ABI: builder
 extern "C" int p2mt_cb_create(p2mt_circuit_builder** out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   *out = new (std::nothrow) p2mt_circuit_builder;
   return *out ? P2MT_OK : p2mt::fail(P2MT_ENOMEM, "out of host memory");
+  });
 }
 extern "C" int p2mt_cb_destroy(p2mt_circuit_builder* b) {
+  return p2mt::abi_guard([&]() -> int {
   delete b;
   return P2MT_OK;
+  });
 }
 #define CB_ARGS(b, out) \
   if (!(b) || !(out)) return p2mt::fail(P2MT_EINVAL, "null pointer")
 extern "C" int p2mt_cb_add_virtual_target(p2mt_circuit_builder* b, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   *out = cb_virtual(b);
   return P2MT_OK;
+  });
 }
 extern "C" int p2mt_cb_constant(p2mt_circuit_builder* b, uint64_t c, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   *out = cb_constant(b, c);
   return P2MT_OK;
+  });
 }
 extern "C" int p2mt_cb_connect(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b) return p2mt::fail(P2MT_EINVAL, "null pointer");
   return cb_connect(b, x, y);
+  });
 }
 extern "C" int p2mt_cb_arithmetic(p2mt_circuit_builder* b, uint64_t const_0, uint64_t const_1, p2mt_target multiplicand_0,
                                   p2mt_target multiplicand_1, p2mt_target addend, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_arithmetic(b, const_0, const_1, multiplicand_0, multiplicand_1, addend, out);
+  });
 }
 extern "C" int p2mt_cb_add(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_arithmetic(b, 1, 1, x, cb_constant(b, 1), y, out);
+  });
 }
 extern "C" int p2mt_cb_sub(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_arithmetic(b, 1, gl::P - 1, x, cb_constant(b, 1), y, out);
+  });
 }
 extern "C" int p2mt_cb_mul(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_arithmetic(b, 1, 0, x, y, x, out);
+  });
 }
 extern "C" int p2mt_cb_mul_add(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target z, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_arithmetic(b, 1, 1, x, y, z, out);
+  });
 }
 extern "C" int p2mt_cb_mul_sub(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target z, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_arithmetic(b, 1, gl::P - 1, x, y, z, out);
+  });
 }
 extern "C" int p2mt_cb_not(p2mt_circuit_builder* b, p2mt_target x, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   const u64 one = cb_constant(b, 1);
   return cb_arithmetic(b, 1, gl::P - 1, one, one, x, out);
+  });
 }
 extern "C" int p2mt_cb_or(p2mt_circuit_builder* b, p2mt_target b1, p2mt_target b2, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   u64 res_minus_b2;
   P2MT_TRY(cb_arithmetic(b, gl::P - 1, 1, b1, b2, b1, &res_minus_b2));
   return cb_arithmetic(b, 1, 1, res_minus_b2, cb_constant(b, 1), b2, out);
+  });
 }
 extern "C" int p2mt_cb_assert_bool(p2mt_circuit_builder* b, p2mt_target x) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b) return p2mt::fail(P2MT_EINVAL, "null pointer");
   u64 z;
   P2MT_TRY(cb_arithmetic(b, 1, gl::P - 1, x, x, x, &z));
   return cb_connect(b, z, cb_constant(b, 0));
+  });
 }
 extern "C" int p2mt_cb_add_virtual_bool_target_safe(p2mt_circuit_builder* b, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   *out = cb_virtual(b);
   return p2mt_cb_assert_bool(b, *out);
+  });
 }
 extern "C" int p2mt_cb_is_equal(p2mt_circuit_builder* b, p2mt_target x, p2mt_target y, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   return cb_is_equal(b, x, y, out);
+  });
 }
 extern "C" int p2mt_cb_hash_n_to_hash_no_pad(p2mt_circuit_builder* b, const p2mt_target* inputs, size_t n, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   if (n && !inputs) return p2mt::fail(P2MT_EINVAL, "null pointer");
   return cb_hash_no_pad(b, inputs, n, out);
+  });
 }
 extern "C" int p2mt_cb_hash_or_noop(p2mt_circuit_builder* b, const p2mt_target* inputs, size_t n, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   if (n && !inputs) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n <= 4) {
@@ -1911,17 +1946,21 @@ extern "C" int p2mt_cb_hash_or_noop(p2mt_circuit_builder* b, const p2mt_target* 
     return P2MT_OK;
   }
   return cb_hash_no_pad(b, inputs, n, out);
+  });
 }
 extern "C" int p2mt_cb_register_public_inputs(p2mt_circuit_builder* b, const p2mt_target* targets, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b || (n && !targets)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (size_t k = 0; k < n; ++k) P2MT_TRY(cb_check(b, targets[k], true));
   b->public_inputs.insert(b->public_inputs.end(), targets, targets + n);
   return P2MT_OK;
+  });
 }
 extern "C" size_t p2mt_cb_num_gates(const p2mt_circuit_builder* b) { return b ? b->gates.size() : 0; }
 
 // ==================================================================================================== build()
 extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c) return P2MT_OK;
   if (c->ch) p2mt_challenger_destroy(c->ch);
   if (c->vch) p2mt_challenger_destroy(c->vch);
@@ -1936,9 +1975,11 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   }
   delete c;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
+  return p2mt::abi_guard([&]() -> int {
   CB_ARGS(b, out);
   P2MT_TRY(p2mt::ensure_init());
   if (b->built) return p2mt::fail(P2MT_EINVAL, "build: this builder was already built (CircuitBuilder::build consumes self)");
@@ -2223,9 +2264,11 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   guard.c = nullptr;
   *out = c;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_circuit_get_info(const p2mt_circuit_data* c, p2mt_circuit_info* info) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c || !info) return p2mt::fail(P2MT_EINVAL, "null pointer");
   info->degree_bits = c->degree_bits;
   info->num_gate_types = c->n_kinds;
@@ -2243,6 +2286,7 @@ extern "C" int p2mt_circuit_get_info(const p2mt_circuit_data* c, p2mt_circuit_in
     info->group_end[g] = g < c->n_kinds ? c->ge[g] : 0;
   }
   return P2MT_OK;
+  });
 }
 int p2mt_circuit_common_data(const p2mt_circuit_data* c, p2mt_common_data* out) {
   if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -2258,41 +2302,54 @@ int p2mt_circuit_common_data(const p2mt_circuit_data* c, p2mt_common_data* out) 
 }
 
 extern "C" int p2mt_circuit_public_inputs(const p2mt_circuit_data* c, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c || (c->n_pi && !out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (u32 k = 0; k < c->n_pi; ++k) out[k] = c->public_inputs[k];
   return P2MT_OK;
+  });
 }
 extern "C" int p2mt_circuit_constants_sigmas(const p2mt_circuit_data* c, uint64_t* values_out, uint64_t* cap_out, uint64_t* digest_out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (values_out) std::copy(c->h_cs.begin(), c->h_cs.end(), values_out);
   if (cap_out) std::copy(c->cs_cap, c->cs_cap + 64, cap_out);
   if (digest_out) std::copy(c->digest, c->digest + 4, digest_out);
   return P2MT_OK;
+  });
 }
 
 // ==================================================================================================== PartialWitness
 extern "C" int p2mt_pw_create(p2mt_partial_witness** out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   *out = new (std::nothrow) p2mt_partial_witness;
   return *out ? P2MT_OK : p2mt::fail(P2MT_ENOMEM, "out of host memory");
+  });
 }
 extern "C" int p2mt_pw_destroy(p2mt_partial_witness* pw) {
+  return p2mt::abi_guard([&]() -> int {
   delete pw;
   return P2MT_OK;
+  });
 }
 extern "C" int p2mt_pw_set_target(p2mt_partial_witness* pw, p2mt_target t, uint64_t value) {
+  return p2mt::abi_guard([&]() -> int {
   if (!pw) return p2mt::fail(P2MT_EINVAL, "null pointer");
   pw->sets.emplace_back(t, value % gl::P);
   return P2MT_OK;
+  });
 }
 extern "C" int p2mt_pw_clear(p2mt_partial_witness* pw) {
+  return p2mt::abi_guard([&]() -> int {
   if (!pw) return p2mt::fail(P2MT_EINVAL, "null pointer");
   pw->sets.clear();
   return P2MT_OK;
+  });
 }
 
 // ==================================================================================================== prove
 extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* wires_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !pw || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_TRY(fill_witness(c, &pw, 1));
@@ -2303,6 +2360,7 @@ extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_pa
   P2MT_HIP(hipStreamSynchronize(st));
   err[3] = 0;  // (the opening-point flag belongs to prove)
   return witness_status(c, err);
+  });
 }
 
 static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, unsigned B, uint64_t* proofs_out,
@@ -2312,6 +2370,7 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* p
 // is so oversubscribed by other work that a wait runs out of its budget, the launch drains with an error flag instead of hanging,
 // and the proof is redone ONCE with the single-workgroup interpreter, which has no such assumption.
 extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witness* pw, uint64_t* proof_out, size_t proof_cap) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !pw || !proof_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_cap < c->proof_len) return p2mt::fail(P2MT_EINVAL, "prove: proof buffer too small (p2mt_circuit_get_info)");
@@ -2324,6 +2383,7 @@ extern "C" int p2mt_circuit_prove(p2mt_circuit_data* c, const p2mt_partial_witne
     c->force_single_workgroup = false;
   }
   return rc;
+  });
 }
 
 // One pass of the prover pipeline over B proofs (B = 1 outside a batch; inside one every launch carries the proofs in grid z
@@ -2434,6 +2494,7 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* p
 
 // intermediates of the last p2mt_circuit_prove on this circuit (parity tests)
 extern "C" int p2mt_circuit_prove_trace(const p2mt_circuit_data* c, int what, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   const u64* src;
@@ -2449,6 +2510,7 @@ extern "C" int p2mt_circuit_prove_trace(const p2mt_circuit_data* c, int what, ui
   P2MT_HIP(hipMemcpyAsync(out, src, words * 8, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // ==================================================================================================== verify
@@ -2637,6 +2699,7 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
 }  // namespace
 
 extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, size_t proof_len, int* accepted, int* reason) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !proof || !accepted) return p2mt::fail(P2MT_EINVAL, "null pointer");
   int dummy = 0;
@@ -2650,6 +2713,7 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
     P2MT_TRY(p2mt_challenger_create(&c->vch));
   }
   return verify_pass(c, c->d_verify, c->vch, 0, proof, proof_len, 1, accepted, reason);
+  });
 }
 
 // circuit_data.verify for n proofs of this circuit, proofs[i] at proofs + i * proof_stride words: passes of up to 256 proofs with
@@ -2657,6 +2721,7 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
 // arithmetic of each proof on a few host threads.  accepted[i] / reason[i] as p2mt_circuit_verify.
 extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* proofs, size_t n, size_t proof_stride, int* accepted,
                                          int* reason) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !proofs || !accepted || !reason) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_stride < c->proof_len) return p2mt::fail(P2MT_EINVAL, "verify_batch: proof_stride < proof_len");
@@ -2698,6 +2763,7 @@ extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* p
                          accepted + at, reason + at));
   }
   return P2MT_OK;
+  });
 }
 
 // ==================================================================================================== many proofs
@@ -2708,6 +2774,7 @@ extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* p
 extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_t n_handles,
                                        const p2mt_partial_witness* const* witnesses, size_t n, uint64_t* proofs_out,
                                        size_t proof_stride, int* status_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!circuits || !witnesses || !proofs_out || n_handles == 0) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (size_t t = 0; t < n_handles; ++t) {
@@ -2746,6 +2813,7 @@ extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_
   for (auto& th : pool) th.join();
   const int rc = first_err.load();
   return rc == P2MT_OK ? P2MT_OK : p2mt::fail(rc, "prove_many: at least one prove failed (see status_out)");
+  });
 }
 
 // ==================================================================================================== batched prover
@@ -2789,6 +2857,7 @@ struct p2mt_batch_prover {
 };
 
 extern "C" int p2mt_batch_prover_create(p2mt_circuit_data* c, size_t batch, p2mt_batch_prover** out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (batch == 0 || batch > 4096) return p2mt::fail(P2MT_EINVAL, "batch_prover: batch must be in 1..4096");
@@ -2798,9 +2867,11 @@ extern "C" int p2mt_batch_prover_create(p2mt_circuit_data* c, size_t batch, p2mt
   b->B = (unsigned)batch;
   *out = b;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_batch_prover_destroy(p2mt_batch_prover* b) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b) return P2MT_OK;
   if (b->d_block) {
     (void)hipStreamSynchronize(rt().stream);
@@ -2810,6 +2881,7 @@ extern "C" int p2mt_batch_prover_destroy(p2mt_batch_prover* b) {
   if (b->pp.ch) p2mt::challenger_unwrap(b->pp.ch);
   delete b;
   return P2MT_OK;
+  });
 }
 
 // first use: size the per-proof scratch arena from one tracked single-proof run, then allocate the blocks
@@ -2887,6 +2959,7 @@ static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness
 // proof's status, the return value is the first non-zero one.  Every witness must set the same targets in the same order.
 extern "C" int p2mt_batch_prover_prove(p2mt_batch_prover* b, const p2mt_partial_witness* const* witnesses, size_t n,
                                        uint64_t* proofs_out, size_t proof_stride, int* status_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!b || !witnesses || !proofs_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_stride < b->c->proof_len) return p2mt::fail(P2MT_EINVAL, "prove_batch: proof_stride < proof_len (p2mt_circuit_get_info)");
@@ -2923,6 +2996,7 @@ extern "C" int p2mt_batch_prover_prove(p2mt_batch_prover* b, const p2mt_partial_
     }
   }
   return rc;
+  });
 }
 
 extern "C" size_t p2mt_batch_prover_batch(const p2mt_batch_prover* b) { return b ? b->B : 0; }
@@ -2974,12 +3048,17 @@ inline u64 get_le(const uint8_t* src) {
 
 extern "C" size_t p2mt_proof_bytes_len(const p2mt_circuit_data* c) {
   if (!c) return 0;
-  const ProofShape sh = proof_shape(c);
-  return c->proof_len * 8 + sh.n_queries * sh.per_query.size();
+  try {  // (size_t result: 0 on failure; proof_shape builds a vector)
+    const ProofShape sh = proof_shape(c);
+    return c->proof_len * 8 + sh.n_queries * sh.per_query.size();
+  } catch (...) {
+    return 0;
+  }
 }
 
 extern "C" int p2mt_proof_to_bytes(const p2mt_circuit_data* c, const uint64_t* proof, size_t proof_len, uint8_t* bytes_out,
                                    size_t bytes_cap) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c || !proof || !bytes_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_len != c->proof_len) return p2mt::fail(P2MT_EINVAL, "proof_to_bytes: wrong proof length for this circuit");
   if (bytes_cap < p2mt_proof_bytes_len(c)) return p2mt::fail(P2MT_EINVAL, "proof_to_bytes: output buffer too small (p2mt_proof_bytes_len)");
@@ -2999,10 +3078,12 @@ extern "C" int p2mt_proof_to_bytes(const p2mt_circuit_data* c, const uint64_t* p
   words(sh.tail_words);
   if ((size_t)(w - proof) != proof_len) return p2mt::fail(P2MT_EHIP, "proof_to_bytes: internal layout mismatch");
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_proof_from_bytes(const p2mt_circuit_data* c, const uint8_t* bytes, size_t n_bytes, uint64_t* proof_out,
                                      size_t proof_cap) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c || !bytes || !proof_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (proof_cap < c->proof_len) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: proof buffer too small");
   if (n_bytes != p2mt_proof_bytes_len(c)) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: wrong length for this circuit");
@@ -3023,11 +3104,13 @@ extern "C" int p2mt_proof_from_bytes(const p2mt_circuit_data* c, const uint8_t* 
   for (size_t i = 0; i < c->proof_len; ++i)  // plonky2's read_field rejects non-canonical encodings
     if (proof_out[i] >= gl::P) return p2mt::fail(P2MT_EINVAL, "proof_from_bytes: non-canonical field element");
   return P2MT_OK;
+  });
 }
 
 // debug: timeline of the dataflow witness interpreter.  enable = 1 allocates the trace buffer (one tick per generator); after a
 // prove / generate_witness, out[3 * i .. 3 * i + 3) = (kind, level, completion tick at 100 MHz) of generator i in schedule order.
 extern "C" int p2mt_debug_witness_trace(p2mt_circuit_data* c, int enable, uint64_t* out, size_t cap, size_t* n_out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c) return p2mt::fail(P2MT_EINVAL, "null pointer");
   const size_t n_ops = c->ops_cap;
   if (enable && !c->d_trace) {
@@ -3051,4 +3134,5 @@ extern "C" int p2mt_debug_witness_trace(p2mt_circuit_data* c, int enable, uint64
     }
   if (n_out) *n_out = n;
   return P2MT_OK;
+  });
 }

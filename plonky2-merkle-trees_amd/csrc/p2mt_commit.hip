@@ -603,6 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_field_op(int op, const u64* __
 }  // namespace
 
 extern "C" int p2mt_debug_field_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* flag_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!a || !b || !out || !flag_out || op < 0 || op > 5) return p2mt::fail(P2MT_EINVAL, "bad argument");
@@ -621,10 +622,12 @@ extern "C" int p2mt_debug_field_op(int op, const uint64_t* a, const uint64_t* b,
   P2MT_HIP(hipMemcpyAsync(flag_out, bf.p, n, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== fft_with_options / ifft_with_options
 extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_polys, int inverse) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n_polys == 0) return P2MT_OK;
   if (!d_data || log_n > 32) return p2mt::fail(P2MT_EINVAL, "ntt: bad argument (2-adicity of the field is 32)");
@@ -639,9 +642,11 @@ extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_pol
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamSynchronize(rt().stream));  // tmp dies with this call
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_ntt_batch(uint64_t* data, unsigned log_n, size_t n_polys, int inverse) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n_polys == 0) return P2MT_OK;
   if (!data || log_n > 32) return p2mt::fail(P2MT_EINVAL, "ntt: bad argument");
@@ -653,6 +658,7 @@ extern "C" int p2mt_ntt_batch(uint64_t* data, unsigned log_n, size_t n_polys, in
   P2MT_HIP(hipMemcpyAsync(data, b.p, bytes, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // LDE into leaf order (poly-major): d_out[p][brev(i)] = f_p(shift * w_N^i)
@@ -680,6 +686,7 @@ int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned
 
 extern "C" int p2mt_coset_lde_batch_dev(const uint64_t* d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
                                         size_t n_polys, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n_polys == 0) return P2MT_OK;
   if (!d_coeffs || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -693,10 +700,12 @@ extern "C" int p2mt_coset_lde_batch_dev(const uint64_t* d_coeffs, unsigned log_n
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_coset_lde_batch(const uint64_t* coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
                                     size_t n_polys, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n_polys == 0) return P2MT_OK;
   if (!coeffs || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -709,6 +718,7 @@ extern "C" int p2mt_coset_lde_batch(const uint64_t* coeffs, unsigned log_n, unsi
   P2MT_HIP(hipMemcpyAsync(out, bo.p, out_bytes, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== MerkleTree::new(leaves, cap_height)
@@ -749,6 +759,7 @@ static int merkle_levels_to_cap(u64* d_level0, size_t n, unsigned cap_height, u6
 
 extern "C" int p2mt_merkle_cap_commit_dev(const uint64_t* d_leaves, size_t n, size_t width, unsigned cap_height,
                                           uint64_t* d_digests_out, uint64_t* d_cap_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   const int k = log2_strict(n);
   if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree::new: n must be a power of two >= 2^cap_height");
@@ -757,6 +768,7 @@ extern "C" int p2mt_merkle_cap_commit_dev(const uint64_t* d_leaves, size_t n, si
   if (!d_level0 || (unsigned)k == cap_height) P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLevel0, n * 32, (void**)&d_level0));
   P2MT_TRY(p2mt::launch_hash_rows_dev(d_leaves, n, width, 1, d_level0));
   return merkle_levels_to_cap(d_level0, n, cap_height, (unsigned)k == cap_height ? nullptr : d_digests_out, d_cap_out);
+  });
 }
 
 static size_t digests_count(size_t n, unsigned cap_height) {
@@ -768,6 +780,7 @@ static size_t digests_count(size_t n, unsigned cap_height) {
 
 extern "C" int p2mt_merkle_cap_commit(const uint64_t* leaves, size_t n, size_t width, unsigned cap_height,
                                       uint64_t* digests_out, uint64_t* cap_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   const int k = log2_strict(n);
   if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree::new: n must be a power of two >= 2^cap_height");
@@ -783,6 +796,7 @@ extern "C" int p2mt_merkle_cap_commit(const uint64_t* leaves, size_t n, size_t w
   P2MT_HIP(hipMemcpyAsync(cap_out, bc.p, ncap * 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== plonky2's MerkleTree { digests } layout
@@ -816,6 +830,7 @@ __global__ __launch_bounds__(kBlock) void k_digests_to_plonky2(const u64* __rest
 
 extern "C" int p2mt_merkle_digests_to_plonky2_layout_dev(const uint64_t* d_level_major, size_t n_leaves, unsigned cap_height,
                                                          uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   const int k = log2_strict(n_leaves);
   if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree: n must be a power of two >= 2^cap_height");
@@ -826,10 +841,12 @@ extern "C" int p2mt_merkle_digests_to_plonky2_layout_dev(const uint64_t* d_level
                      cap_height, nd);
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_merkle_digests_to_plonky2_layout(const uint64_t* level_major, size_t n_leaves, unsigned cap_height,
                                                      uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   const int k = log2_strict(n_leaves);
   if (k < 0 || cap_height > (unsigned)k) return p2mt::fail(P2MT_EINVAL, "MerkleTree: n must be a power of two >= 2^cap_height");
@@ -844,6 +861,7 @@ extern "C" int p2mt_merkle_digests_to_plonky2_layout(const uint64_t* level_major
   P2MT_HIP(hipMemcpyAsync(out, bo.p, nd * 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== PolynomialBatch::from_values / from_coeffs
@@ -925,9 +943,11 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
 extern "C" int p2mt_polynomial_batch_commit_dev(const uint64_t* d_polys, int is_values, size_t n_polys, unsigned log_n,
                                                 unsigned rate_bits, unsigned cap_height, uint64_t* d_leaves_out,
                                                 uint64_t* d_digests_out, uint64_t* d_cap_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   return p2mt::commit_batch_dev(d_polys, is_values, n_polys, log_n, rate_bits, cap_height, nullptr, nullptr, d_leaves_out,
                                 d_digests_out, d_cap_out);
+  });
 }
 
 // PolynomialValues::coset_ifft(shift): plain IFFT gives c_k shift^k; the bit-reversal pass also divides by n shift^k.
@@ -965,6 +985,7 @@ int p2mt::coset_ifft_dev(uint64_t* d_vals, unsigned log_n, size_t n_polys, uint6
 extern "C" int p2mt_polynomial_batch_commit(const uint64_t* polys, int is_values, size_t n_polys, unsigned log_n,
                                             unsigned rate_bits, unsigned cap_height, uint64_t* leaves_out,
                                             uint64_t* digests_out, uint64_t* cap_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!polys || !cap_out || n_polys == 0) return p2mt::fail(P2MT_EINVAL, "bad argument");
   const unsigned log_big = log_n + rate_bits;
@@ -986,4 +1007,5 @@ extern "C" int p2mt_polynomial_batch_commit(const uint64_t* polys, int is_values
   P2MT_HIP(hipMemcpyAsync(cap_out, bc.p, ncap * 32, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }

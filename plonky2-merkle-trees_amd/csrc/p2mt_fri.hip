@@ -574,6 +574,7 @@ void p2mt::challenger_unwrap(p2mt_challenger* c) { delete c; }
 
 // =================================================================== Challenger
 extern "C" int p2mt_challenger_create(p2mt_challenger** out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   p2mt_challenger* c = new (std::nothrow) p2mt_challenger;
@@ -585,9 +586,11 @@ extern "C" int p2mt_challenger_create(p2mt_challenger** out) {
   P2MT_HIP(hipMemsetAsync(c->d, 0, sizeof(ChState), rt().stream));
   *out = c;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_destroy(p2mt_challenger* c) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c) return P2MT_OK;
   if (c->d && c->owned) {
     (void)hipStreamSynchronize(rt().stream);
@@ -595,23 +598,29 @@ extern "C" int p2mt_challenger_destroy(p2mt_challenger* c) {
   }
   delete c;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_clone(const p2mt_challenger* src, p2mt_challenger** out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!src || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_TRY(p2mt_challenger_create(out));
   P2MT_HIP(hipMemcpyAsync((*out)->d, src->d, sizeof(ChState), hipMemcpyDeviceToDevice, rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_observe_dev(p2mt_challenger* c, const uint64_t* d_elements, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n && !d_elements)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n == 0) return P2MT_OK;
   return launch_challenger(c->d, d_elements, n, nullptr, 0);
+  });
 }
 
 extern "C" int p2mt_challenger_observe(p2mt_challenger* c, const uint64_t* elements, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n && !elements)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n == 0) return P2MT_OK;
@@ -621,38 +630,48 @@ extern "C" int p2mt_challenger_observe(p2mt_challenger* c, const uint64_t* eleme
   P2MT_TRY(launch_challenger(c->d, b.as<u64>(), n, nullptr, 0));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_reset(p2mt_challenger* c) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_HIP(hipMemsetAsync(c->d, 0, sizeof(ChState), rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_duplex_dev(p2mt_challenger* c, const uint64_t* d_elements, size_t n_obs, uint64_t* d_out,
                                           size_t n_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n_obs && !d_elements) || (n_out && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n_obs == 0 && n_out == 0) return P2MT_OK;
   return launch_challenger(c->d, d_elements, n_obs, d_out, n_out);
+  });
 }
 
 extern "C" int p2mt_challenger_restart_duplex_dev(p2mt_challenger* c, const uint64_t* d_elements, size_t n_obs, uint64_t* d_out,
                                                   size_t n_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n_obs && !d_elements) || (n_out && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   return launch_challenger(c->d, d_elements, n_obs, d_out, n_out, true);
+  });
 }
 
 extern "C" int p2mt_challenger_get_challenges_dev(p2mt_challenger* c, size_t n, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n && !d_out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n == 0) return P2MT_OK;
   return launch_challenger(c->d, nullptr, 0, d_out, n);
+  });
 }
 
 extern "C" int p2mt_challenger_get_challenges(p2mt_challenger* c, size_t n, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!c || (n && !out)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (n == 0) return P2MT_OK;
@@ -662,9 +681,11 @@ extern "C" int p2mt_challenger_get_challenges(p2mt_challenger* c, size_t n, uint
   P2MT_HIP(hipMemcpyAsync(out, b.p, n * 8, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_get_state(const p2mt_challenger* c, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   ChState h;
   P2MT_HIP(hipMemcpyAsync(&h, c->d, sizeof h, hipMemcpyDeviceToHost, rt().stream));
@@ -675,9 +696,11 @@ extern "C" int p2mt_challenger_get_state(const p2mt_challenger* c, uint64_t* out
   out[28] = h.n_in;
   out[29] = h.n_out;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_challenger_set_state(p2mt_challenger* c, const uint64_t* in) {
+  return p2mt::abi_guard([&]() -> int {
   if (!c || !in) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (in[28] > 7 || in[29] > 8) return p2mt::fail(P2MT_EINVAL, "challenger state: buffer counts out of range");
   ChState h;
@@ -689,11 +712,13 @@ extern "C" int p2mt_challenger_set_state(p2mt_challenger* c, const uint64_t* in)
   P2MT_HIP(hipMemcpyAsync(c->d, &h, sizeof h, hipMemcpyHostToDevice, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== OpeningSet evaluation
 extern "C" int p2mt_eval_polys_ext_dev(const uint64_t* d_coeffs, size_t n_polys, unsigned log_n, const uint64_t point[2],
                                        uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n_polys == 0) return P2MT_OK;
   if (!d_coeffs || !point || !d_out || log_n > 24 || n_polys > 0x7FFFFFFF) return p2mt::fail(P2MT_EINVAL, "eval_polys_ext: bad argument");
@@ -701,10 +726,12 @@ extern "C" int p2mt_eval_polys_ext_dev(const uint64_t* d_coeffs, size_t n_polys,
                      point[1] % gl::P, d_out);
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_eval_polys_ext(const uint64_t* coeffs, size_t n_polys, unsigned log_n, const uint64_t point[2],
                                    uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n_polys == 0) return P2MT_OK;
   if (!coeffs || !point || !out || log_n > 24) return p2mt::fail(P2MT_EINVAL, "eval_polys_ext: bad argument");
@@ -716,6 +743,7 @@ extern "C" int p2mt_eval_polys_ext(const uint64_t* coeffs, size_t n_polys, unsig
   P2MT_HIP(hipMemcpyAsync(out, bo.p, n_polys * 16, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 // FriOpenings: every batch's polynomials at the batch's point, batches concatenated, one launch
@@ -779,6 +807,7 @@ int p2mt::fri_openings_points_dev(const p2mt_fri_oracle* oracles, size_t n_oracl
 
 extern "C" int p2mt_fri_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                      size_t n_batches, unsigned degree_bits, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!oracles || !batches || !d_out || n_oracles == 0 || degree_bits > 24) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
   p2mt::FriPointsDev pts{};
@@ -786,10 +815,12 @@ extern "C" int p2mt_fri_openings_dev(const p2mt_fri_oracle* oracles, size_t n_or
   P2MT_TRY(p2mt::fri_openings_points_dev(oracles, n_oracles, batches, n_batches, pts, degree_bits, d_out));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_fri_openings(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                  size_t n_batches, unsigned degree_bits, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!oracles || !batches || !out || n_oracles == 0 || degree_bits > 24) return p2mt::fail(P2MT_EINVAL, "fri_openings: bad argument");
   std::vector<DevBuf> bufs(n_oracles + 1);
@@ -809,10 +840,12 @@ extern "C" int p2mt_fri_openings(const p2mt_fri_oracle* oracles, size_t n_oracle
   P2MT_HIP(hipMemcpyAsync(out, bufs[n_oracles].p, total * 16, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== FRI
 extern "C" int p2mt_fri_params_standard(unsigned degree_bits, p2mt_fri_params* out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   memset(out, 0, sizeof *out);
   out->degree_bits = degree_bits;
@@ -828,6 +861,7 @@ extern "C" int p2mt_fri_params_standard(unsigned degree_bits, p2mt_fri_params* o
     d -= arity_bits;
   }
   return P2MT_OK;
+  });
 }
 
 extern "C" size_t p2mt_fri_proof_len(const p2mt_fri_params* p, size_t n_oracles, const uint64_t* n_polys) {
@@ -850,11 +884,13 @@ extern "C" size_t p2mt_fri_proof_len(const p2mt_fri_params* p, size_t n_oracles,
 extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                            size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch,
                                            uint64_t* d_proof) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!batches || n_batches == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
   p2mt::FriPointsDev pts{};
   P2MT_TRY(upload_points(batches, n_batches, &pts));
   return p2mt::fri_prove_openings_epilogue_dev(oracles, n_oracles, batches, n_batches, pts, p, ch, d_proof, nullptr, nullptr, 0, 0);
+  });
 }
 
 // The same with the opening points as device values and a device-to-host copy enqueued behind the speculative tail of the
@@ -1077,6 +1113,7 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
 
 extern "C" int p2mt_fri_prove_openings(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                        size_t n_batches, const p2mt_fri_params* p, p2mt_challenger* ch, uint64_t* proof_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!oracles || !proof_out || n_oracles == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
   if (!params_ok(p)) return p2mt::fail(P2MT_EINVAL, "fri: unsupported FriParams");
@@ -1106,4 +1143,5 @@ extern "C" int p2mt_fri_prove_openings(const p2mt_fri_oracle* oracles, size_t n_
   P2MT_HIP(hipMemcpyAsync(proof_out, bp.p, total * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }

@@ -264,14 +264,17 @@ using p2mt::rt;
 
 // =================================================================== stateless batch entry points
 extern "C" int p2mt_poseidon_permute_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_DISPATCH(k_permute_batch, grid_for(n), kBlock, d_in, d_out, n);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_poseidon_permute_batch(const uint64_t* in, uint64_t* out, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -283,17 +286,21 @@ extern "C" int p2mt_poseidon_permute_batch(const uint64_t* in, uint64_t* out, si
   P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 96, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_two_to_one_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_DISPATCH(k_two_to_one_batch, grid_for(n), kBlock, d_in, d_out, n);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_two_to_one_batch(const uint64_t* in, uint64_t* out, size_t n) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!in || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -305,6 +312,7 @@ extern "C" int p2mt_two_to_one_batch(const uint64_t* in, uint64_t* out, size_t n
   P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 static int hash_rows_host(const uint64_t* in, size_t n, size_t len, int noop_short, uint64_t* out) {
@@ -322,22 +330,31 @@ static int hash_rows_host(const uint64_t* in, size_t n, size_t len, int noop_sho
 }
 
 extern "C" int p2mt_hash_or_noop_batch(const uint64_t* in, size_t n, size_t len, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   return hash_rows_host(in, n, len, 1, out);
+  });
 }
 extern "C" int p2mt_hash_no_pad_batch(const uint64_t* in, size_t n, size_t len, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   return hash_rows_host(in, n, len, 0, out);
+  });
 }
 extern "C" int p2mt_hash_or_noop_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   return p2mt::launch_hash_rows_dev(d_in, n, len, 1, d_out);
+  });
 }
 extern "C" int p2mt_hash_no_pad_batch_dev(const uint64_t* d_in, size_t n, size_t len, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   return p2mt::launch_hash_rows_dev(d_in, n, len, 0, d_out);
+  });
 }
 
 extern "C" int p2mt_poseidon_gate_witness_batch_dev(const uint64_t* d_inputs, const uint8_t* d_swaps, size_t n,
                                                     uint64_t* d_wires_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!d_inputs || !d_swaps || !d_wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -345,9 +362,11 @@ extern "C" int p2mt_poseidon_gate_witness_batch_dev(const uint64_t* d_inputs, co
                      d_wires_out);
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_poseidon_gate_witness_batch(const uint64_t* inputs, const uint8_t* swaps, size_t n, uint64_t* wires_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!inputs || !swaps || !wires_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -362,6 +381,7 @@ extern "C" int p2mt_poseidon_gate_witness_batch(const uint64_t* inputs, const ui
   P2MT_HIP(hipMemcpyAsync(wires_out, bo.p, n * 135 * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }
 
 // =================================================================== simple_merkle_tree.rs
@@ -371,6 +391,7 @@ static int log2_strict(size_t n) {
 }
 
 extern "C" int p2mt_merkle_build_pow2_dev(const uint64_t* d_leaves, size_t n, uint64_t* d_levels, uint64_t* d_root) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   const int k = log2_strict(n);
   if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
@@ -386,9 +407,11 @@ extern "C" int p2mt_merkle_build_pow2_dev(const uint64_t* d_leaves, size_t n, ui
     cur_n /= 2;
   }
   return p2mt::launch_merkle_level_dev(cur, d_root, 1);  // root = two_to_one(last[0], last[1])
+  });
 }
 
 extern "C" int p2mt_merkle_build_pow2(const uint64_t* leaves, size_t n, uint64_t* levels_out, uint64_t* root_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   const int k = log2_strict(n);
   if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
@@ -403,6 +426,7 @@ extern "C" int p2mt_merkle_build_pow2(const uint64_t* leaves, size_t n, uint64_t
   P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 static const uint64_t* level_ptr(const uint64_t* levels, size_t n, int level) {
@@ -412,16 +436,19 @@ static const uint64_t* level_ptr(const uint64_t* levels, size_t n, int level) {
 }
 
 extern "C" int p2mt_merkle_get_proof(const uint64_t* levels, size_t n, size_t leaf_index, uint64_t* proof_out) {
+  return p2mt::abi_guard([&]() -> int {
   const int k = log2_strict(n);
   if (k < 1 || !levels || !proof_out) return p2mt::fail(P2MT_EINVAL, "get_merkle_proof: bad tree");
   if (leaf_index >= n) return p2mt::fail(P2MT_EINVAL, "get_merkle_proof: assert!(leaf_index < n)");
   size_t idx = leaf_index;
   for (int i = 0; i < k; ++i, idx >>= 1) memcpy(proof_out + 4 * i, level_ptr(levels, n, i) + 4 * (idx ^ 1), 32);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_merkle_get_in_between_hashes(const uint64_t* levels, const uint64_t* root, size_t n,
                                                  size_t leaf_index, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   const int k = log2_strict(n);
   if (k < 1 || !levels || !root || !out) return p2mt::fail(P2MT_EINVAL, "get_in_between_hashes: bad tree");
   if (leaf_index >= n) return p2mt::fail(P2MT_EINVAL, "get_in_between_hashes: assert!(leaf_index < n)");
@@ -429,10 +456,12 @@ extern "C" int p2mt_merkle_get_in_between_hashes(const uint64_t* levels, const u
   for (int i = 1; i < k; ++i, idx >>= 1) memcpy(out + 4 * (i - 1), level_ptr(levels, n, i) + 4 * idx, 32);
   memcpy(out + 4 * (k - 1), root, 32);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_verify_merkle_proof_batch(const uint64_t* leaves, const uint64_t* leaf_indices, const uint64_t* roots,
                                               const uint64_t* hashes, size_t n_hashes, size_t m, uint8_t* result_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (m == 0) return P2MT_OK;
   if (!leaves || !leaf_indices || !roots || (!hashes && n_hashes) || !result_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
@@ -452,5 +481,6 @@ extern "C" int p2mt_verify_merkle_proof_batch(const uint64_t* leaves, const uint
   P2MT_HIP(hipMemcpyAsync(result_out, bo.p, m, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }
 

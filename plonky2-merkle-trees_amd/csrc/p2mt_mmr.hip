@@ -109,15 +109,26 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
 // ONE inlined permutation.  Pending left siblings (at most one per height) live in a per-lane LDS stack; the control
 // flow is the binary-counter carry chain and is identical in all lanes.  A lane's 2^(LV+1)-1 nodes are a contiguous
 // post-order span, written node by node.  HBM traffic is the same algorithmic minimum as k_mmr_tile.
+// Chunk signalling (round 3): the launch covers blocks [block0, block0 + n_blocks) on a grid aligned to BLK blocks (grid_base is a
+// multiple of BLK, so a workgroup never straddles a chunk of 2^chunk_shift blocks).  A workgroup that lies in chunk c of
+// [chunk_first, chunk_first + n_chunks) publishes its nodes (agent-scope release) and adds 1 to chunk_cnt[c - chunk_first]; k_mmr_gate
+// on a second stream turns "all workgroups of chunk c have arrived" into a stream dependency, so that the upper levels of a finished
+// chunk run underneath the rest of this launch instead of behind it.
+struct ChunkSignal {
+  unsigned* cnt;           // null: no signalling
+  unsigned shift;          // log2(blocks per chunk)
+  unsigned long long first;  // first chunk index (in units of chunks of blocks)
+  unsigned n;
+};
 template <unsigned LV, int BLK, int PR = 0>
 __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ leaves, size_t leaf_base,
                                                      u64* __restrict__ elements, size_t block0, size_t n_blocks,
-                                                     PermCtx ctx) {
+                                                     size_t grid_base, ChunkSignal sig, PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
   poseidon_fast::MfmaCtx mc;  // PR == 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
   if constexpr (PR == 2) mc = poseidon_fast::mfma_ctx_init();
-  const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
-  if (blk >= block0 + n_blocks) return;
+  const size_t blk = grid_base + (size_t)blockIdx.x * BLK + threadIdx.x;
+  if (blk >= block0 && blk < block0 + n_blocks) {
   const size_t first_leaf = blk << LV;
   const u64* lp = leaves + (first_leaf - leaf_base);
   u64 cur[4] = {0, 0, 0, 0};
@@ -156,6 +167,35 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
     for (int k = 0; k < 4; ++k) cur[k] = o[k];
     if (merges == 0 && h < LV) store_hash(&stack[h - 1][threadIdx.x * 4], cur);  // becomes a pending left sibling
   }
+  }  // active lane
+  if (sig.cnt) {  // wave-uniform kernel argument
+    const size_t c = (grid_base + (size_t)blockIdx.x * BLK) >> sig.shift;
+    if (c >= sig.first && c - sig.first < sig.n) {  // workgroup-uniform; such a workgroup is fully active
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's node stores have left the CU ...
+      __syncthreads();                                   // ... and so have every other wave's of the workgroup
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines: the reader may sit on another XCD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&sig.cnt[c - sig.first], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// One lane waits until all `target` workgroups of a chunk have arrived, then re-arms the counter for the next build and exits:
+// whatever follows on this stream starts (with the usual kernel-start acquire) after the chunk's nodes were published.  The wait is
+// bounded (wall clock): on a timeout -- the stage-1 launch failed or never ran -- *err_host is set and the build reports P2MT_EHIP.
+__global__ void k_mmr_gate(unsigned* cnt, unsigned target, unsigned long long timeout_ticks, int* err_host) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();  // constant 100 MHz
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(64);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      *err_host = 1;
+      break;
+    }
+  }
+  __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // MMR level (post-order, in place): node j of height h
@@ -393,6 +433,54 @@ struct p2mt_mmr {
   std::vector<u64> pending; // add_leaf queue (host), flushed as one bulk extend before the MMR is observed
 };
 
+// Side resources of the chunked build (per host thread, like the library stream): a high-priority stream on which the gates and
+// the upper levels of finished chunks run underneath the stage-1 launch, the fork / join events, the chunk counters and a pinned
+// error word the gate kernel can set.
+namespace {
+constexpr unsigned kMaxChunks = 16;
+struct MmrSide {
+  hipStream_t su = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  unsigned* d_cnt = nullptr;
+  int* h_err = nullptr;  // hipHostMalloc (mapped): written by k_mmr_gate on a timeout
+  int init() {
+    if (su) return P2MT_OK;
+    int lo = 0, hi = 0;
+    P2MT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (least, greatest)
+    P2MT_HIP(hipStreamCreateWithPriority(&su, hipStreamNonBlocking, hi));
+    P2MT_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    P2MT_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    P2MT_HIP(hipMalloc((void**)&d_cnt, kMaxChunks * sizeof(unsigned)));
+    P2MT_HIP(hipMemset(d_cnt, 0, kMaxChunks * sizeof(unsigned)));
+    P2MT_HIP(hipHostMalloc((void**)&h_err, sizeof(int), hipHostMallocMapped));
+    *h_err = 0;
+    return P2MT_OK;
+  }
+  void release() {
+    if (su) {
+      (void)hipStreamSynchronize(su);
+      (void)hipStreamDestroy(su);
+      (void)hipEventDestroy(ev_fork);
+      (void)hipEventDestroy(ev_join);
+      (void)hipFree(d_cnt);
+      (void)hipHostFree(h_err);
+    }
+    su = nullptr;
+  }
+};
+thread_local MmrSide tl_side;
+int chunks_enabled() {  // env P2MT_CHUNKS=0 selects the unchunked build (A/B)
+  static const int on = [] {
+    const char* e = getenv("P2MT_CHUNKS");
+    return e ? atoi(e) != 0 : 1;
+  }();
+  return on;
+}
+}  // namespace
+namespace p2mt {
+void mmr_release_thread() { tl_side.release(); }
+}  // namespace p2mt
+
 static constexpr size_t kMaxPendingLeaves = (size_t)1 << 20;
 static int mmr_extend_host(p2mt_mmr* m, const uint64_t* leaves, size_t k);
 // The add_leaf queue is dropped only once its leaves are in `elements`: a failed flush (allocation, copy) leaves the queue
@@ -407,13 +495,26 @@ static int mmr_flush(const p2mt_mmr* cm) {
 // test hook (p2mt_debug_fail_allocs): the next `n` device allocations made while growing an MMR report out-of-memory
 static int g_fail_allocs = 0;
 extern "C" int p2mt_debug_fail_allocs(int n) {
+  return p2mt::abi_guard([&]() -> int {
   g_fail_allocs = n < 0 ? 0 : n;
+  return P2MT_OK;
+  });
+}
+
+// a gate of the chunked build timed out (the stage-1 launch failed or never ran): reported by the next synchronising call
+static int mmr_side_error() {
+  if (tl_side.h_err && *tl_side.h_err) {
+    *tl_side.h_err = 0;
+    (void)hipMemset(tl_side.d_cnt, 0, kMaxChunks * sizeof(unsigned));
+    return p2mt::fail(P2MT_EHIP, "chunked MMR build: a chunk of the stage-1 launch never completed (gate timeout)");
+  }
   return P2MT_OK;
 }
 
 static size_t mmr_len_for(size_t n_leaves) { return 2 * n_leaves - (size_t)__builtin_popcountll((unsigned long long)n_leaves); }
 
 extern "C" int p2mt_mmr_create(p2mt_mmr** out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   p2mt_mmr* m = new (std::nothrow) p2mt_mmr();
@@ -425,14 +526,17 @@ extern "C" int p2mt_mmr_create(p2mt_mmr** out) {
   }
   *out = m;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_destroy(p2mt_mmr* m) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m) return P2MT_OK;
   if (m->elements) (void)hipFree(m->elements);
   if (m->scratch) (void)hipFree(m->scratch);
   delete m;
   return P2MT_OK;
+  });
 }
 
 static int mmr_grow(p2mt_mmr* m, size_t need_nodes) {
@@ -459,27 +563,35 @@ static int mmr_grow(p2mt_mmr* m, size_t need_nodes) {
 }
 
 extern "C" int p2mt_mmr_reserve(p2mt_mmr* m, size_t n_leaves) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   if (n_leaves >> 40) return p2mt::fail(P2MT_ERANGE, "MMR too large");
   return mmr_grow(m, 2 * n_leaves);
+  });
 }
 
 extern "C" int p2mt_mmr_reset(p2mt_mmr* m) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   m->n_leaves = 0;
   m->pending.clear();
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_add_leaf(p2mt_mmr* m, uint64_t leaf) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   m->pending.push_back(leaf);
   return m->pending.size() >= kMaxPendingLeaves ? mmr_flush(m) : P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_flush(p2mt_mmr* m) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   return mmr_flush(m);
+  });
 }
 
 // one level over [j0, j1) of height h: one wavefront per node while the level is small (latency-bound), one
@@ -513,11 +625,13 @@ static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
 // hi: j in [lo>>h, hi>>h).  Stages of fused tiles (2^(h0+kTileLog)-leaf aligned blocks, n_lev levels each) cover the
 // bulk while a level still has more nodes than the quad/wave-per-node paths like; ragged edges and the thin top go
 // level by level.
-static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size_t n0, size_t n1, unsigned cap) {
+// h_from > 0: the nodes of height <= h_from exist already (a finished chunk); only heights h_from+1..cap are built.
+static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size_t n0, size_t n1, unsigned cap,
+                        unsigned h_from = 0) {
   if (n1 <= n0) return P2MT_OK;
   hipStream_t st = rt().stream;
   const unsigned kTileLog = rt().mds == 2 ? rt().tile_log : 11;  // 2^kTileLog inputs per workgroup (12 / 24 / 48 KB of LDS)
-  unsigned h0 = 0;
+  unsigned h0 = h_from;
   for (;;) {
     if (h0 > 0 && (h0 >= cap || (n1 >> (h0 + 1)) <= (n0 >> (h0 + 1)))) break;  // no node above h0 (or not ours)
     // levels this stage would fuse: stage 1 stops while every level fills whole waves; later stages also stop where
@@ -556,23 +670,78 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
     }
     if (sub_lv) {
       const size_t n_blocks = (b - a) >> span_log;
-      const int prof_slot = p2mt::prof_begin();  // stage 1 is the dominant launch
       const unsigned sb = rt().subtree_block;
-      const unsigned sgrid = (unsigned)((n_blocks + sb - 1) / sb);
-#define P2MT_SUB(LVV, BB) \
-  hipLaunchKernelGGL((k_mmr_subtree<LVV, BB>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, a >> span_log, \
-                     n_blocks, p2mt::perm_ctx())
-      if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64); else P2MT_SUB(5, 256); }
-      else if (rt().partial == 2) {  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 2>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
-                           m->elements, a >> span_log, n_blocks, p2mt::perm_ctx());
-      } else if (rt().partial) {  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 1>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
-                           m->elements, a >> span_log, n_blocks, p2mt::perm_ctx());
-      } else { if (sb == 64) P2MT_SUB(4, 64); else if (sb == 128) P2MT_SUB(4, 128); else P2MT_SUB(4, 256); }
+      const size_t block0 = a >> span_log;
+      const size_t grid_base = block0 / sb * sb;  // grid aligned to whole workgroups of blocks (lanes in front of block0 stay idle)
+      const unsigned sgrid = (unsigned)((block0 + n_blocks - grid_base + sb - 1) / sb);
+      // Chunked build: the aligned 2^cl-leaf subtrees inside [a, b) (8..15 of them) each signal their completion from inside the
+      // stage-1 launch; their upper levels (sub_lv+1 .. cl) run on the side stream underneath the rest of the launch.
+      ChunkSignal sig{nullptr, 0, 0, 0};
+      unsigned cl = 0;
+      size_t c0 = 0, c1 = 0;
+      if (chunks_enabled() && sb == 256 && cap > sub_lv && p2mt::batch_B() == 1) {
+        const size_t span = b - a;
+        unsigned lg = 63 - (unsigned)__builtin_clzll((unsigned long long)span);
+        cl = lg >= 3 ? lg - 3 : 0;
+        if (cl >= 17 && cl <= cap) {  // chunks of >= 2^17 leaves = 32 workgroups; smaller builds keep the plain path
+          c0 = (a + (((size_t)1 << cl) - 1)) >> cl;
+          c1 = b >> cl;
+          if (c1 > c0 + 1 && c1 - c0 <= kMaxChunks && tl_side.init() == P2MT_OK) {
+            sig.cnt = tl_side.d_cnt;
+            sig.shift = cl - span_log;
+            sig.first = c0;
+            sig.n = (unsigned)(c1 - c0);
+          }
+        }
+      }
+      if (sig.cnt) {  // fork: the side stream starts behind everything enqueued on the library stream so far
+        P2MT_HIP(hipEventRecord(tl_side.ev_fork, st));
+        P2MT_HIP(hipStreamWaitEvent(tl_side.su, tl_side.ev_fork, 0));
+      }
+      const int prof_slot = p2mt::prof_begin();  // stage 1 is the dominant launch
+#define P2MT_SUB(LVV, BB, PRR) \
+  hipLaunchKernelGGL((k_mmr_subtree<LVV, BB, PRR>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks, \
+                     grid_base, sig, p2mt::perm_ctx())
+      if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
+      else if (rt().partial == 2 && sb == 256) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
+      else if (rt().partial == 1 && sb == 256) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
+      else { if (sb == 64) P2MT_SUB(4, 64, 0); else if (sb == 128) P2MT_SUB(4, 128, 0); else P2MT_SUB(4, 256, 0); }
 #undef P2MT_SUB
       P2MT_LAUNCH_CHECK();
       p2mt::prof_end(prof_slot);
+      if (sig.cnt) {
+        const unsigned target = 1u << (cl - span_log - 8);  // workgroups (256 blocks of 2^span_log leaves) per chunk
+        int rc = P2MT_OK;
+        {
+          p2mt::StreamScope on_side(tl_side.su);
+          for (size_t c = c0; c < c1 && rc == P2MT_OK; ++c) {
+            hipLaunchKernelGGL(k_mmr_gate, dim3(1), dim3(64), 0, tl_side.su, sig.cnt + (c - c0), target,
+                               (unsigned long long)20 * 100000000ull, tl_side.h_err);
+            if (hipGetLastError() != hipSuccess) rc = p2mt::fail(P2MT_EHIP, "k_mmr_gate launch failed");
+            if (rc == P2MT_OK) rc = build_levels(m, nullptr, 0, c << cl, (c + 1) << cl, cl, sub_lv);
+          }
+        }
+        // join: the library stream continues behind the stage-1 launch AND the side stream (even after an error above, so that
+        // nothing of this build is still in flight on a stream the caller does not know about)
+        P2MT_HIP(hipEventRecord(tl_side.ev_join, tl_side.su));
+        P2MT_HIP(hipStreamWaitEvent(st, tl_side.ev_join, 0));
+        P2MT_TRY(rc);
+        // what the chunks did not cover: the ragged edges of the fused levels, heights sub_lv+1..cl outside the chunks, and
+        // everything above the chunk roots
+        for (unsigned h = 1; h <= sub_lv; ++h) {
+          P2MT_TRY(launch_level(m, h, n0 >> h, a >> h));
+          P2MT_TRY(launch_level(m, h, b >> h, n1 >> h));
+        }
+        for (unsigned h = sub_lv + 1; h <= cap && (n1 >> h) > (n0 >> h); ++h) {
+          if (h <= cl) {
+            P2MT_TRY(launch_level(m, h, n0 >> h, (c0 << cl) >> h));
+            P2MT_TRY(launch_level(m, h, (c1 << cl) >> h, n1 >> h));
+          } else {
+            P2MT_TRY(launch_level(m, h, n0 >> h, n1 >> h));
+          }
+        }
+        return P2MT_OK;
+      }
     } else {
       const unsigned grid = (unsigned)((b - a) >> span_log);
       const size_t t0 = a >> span_log;
@@ -631,17 +800,21 @@ static int mmr_extend_host(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
 }
 
 extern "C" int p2mt_mmr_extend_dev(p2mt_mmr* m, const uint64_t* d_leaves, size_t k) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   P2MT_TRY(mmr_flush(m));  // queued add_leaf calls come first
   return mmr_extend_dev_noflush(m, d_leaves, k);
+  });
 }
 
 extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   P2MT_TRY(mmr_flush(m));
   return mmr_extend_host(m, leaves, k);
+  });
 }
 
 // (sizes are known without flushing: the queue only adds leaves)
@@ -653,6 +826,7 @@ extern "C" const uint64_t* p2mt_mmr_elements_dev(const p2mt_mmr* m) {
 }
 
 extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t count, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   P2MT_TRY(mmr_flush(m));
   const size_t len = mmr_len_for(m->n_leaves);
@@ -661,7 +835,8 @@ extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t co
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_HIP(hipMemcpyAsync(out, m->elements + 4 * first, count * 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
-  return P2MT_OK;
+  return mmr_side_error();
+  });
 }
 
 // ---------------------------------------------------------------- checkpoint
@@ -678,6 +853,7 @@ uint64_t fold_checksum(const uint64_t* p, size_t n_words) {
 }  // namespace
 
 extern "C" int p2mt_mmr_save(const p2mt_mmr* m, const char* path) {
+  return p2mt::abi_guard([&]() -> int {
   if (!m || !path) return p2mt::fail(P2MT_EINVAL, "null argument");
   P2MT_TRY(mmr_flush(m));
   const size_t len = mmr_len_for(m->n_leaves);
@@ -698,9 +874,11 @@ extern "C" int p2mt_mmr_save(const p2mt_mmr* m, const char* path) {
   const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && (host.empty() || fwrite(host.data(), 8, host.size(), f) == host.size());
   if (fclose(f) != 0 || !ok) return p2mt::fail(P2MT_EINVAL, "mmr_save: short write");
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_load(p2mt_mmr* m, const char* path) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!m || !path) return p2mt::fail(P2MT_EINVAL, "null argument");
   FILE* f = fopen(path, "rb");
@@ -754,6 +932,7 @@ extern "C" int p2mt_mmr_load(p2mt_mmr* m, const char* path) {
   m->pending.clear();
   m->n_leaves = h.n_leaves;
   return P2MT_OK;
+  });
 }
 
 // peaks left to right = one per set bit of N, decreasing height; the peak of height b ends at the running leaf prefix
@@ -785,10 +964,11 @@ static int mmr_peaks_root(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks, 
   if (root_out) P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   if (n_peaks) *n_peaks = pl.n;
-  return P2MT_OK;
+  return mmr_side_error();
 }
 
 extern "C" int p2mt_mmr_root_dev(const p2mt_mmr* m, uint64_t* d_root_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!m || !d_root_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_TRY(mmr_flush(m));
@@ -796,20 +976,26 @@ extern "C" int p2mt_mmr_root_dev(const p2mt_mmr* m, uint64_t* d_root_out) {
   P2MT_TRY(mmr_peak_positions(m, &pl));
   P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, m->scratch, d_root_out);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_peaks(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks) {
+  return p2mt::abi_guard([&]() -> int {
   if (!peaks_out || !n_peaks) return p2mt::fail(P2MT_EINVAL, "null pointer");
   return mmr_peaks_root(m, peaks_out, n_peaks, nullptr);
+  });
 }
 
 extern "C" int p2mt_mmr_root(const p2mt_mmr* m, uint64_t* root_out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!root_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   return mmr_peaks_root(m, nullptr, nullptr, root_out);
+  });
 }
 
 extern "C" int p2mt_mmr_proof_batch_dev(const p2mt_mmr* m, const uint64_t* d_mmr_indices, size_t count, size_t max_siblings,
                                         uint64_t* d_siblings_out, uint8_t* d_lefts_out, int32_t* d_n_siblings_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   P2MT_TRY(mmr_flush(m));
@@ -822,10 +1008,12 @@ extern "C" int p2mt_mmr_proof_batch_dev(const p2mt_mmr* m, const uint64_t* d_mmr
                      d_mmr_indices, count, max_siblings, d_siblings_out, d_lefts_out, d_n_siblings_out);
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indices, size_t count, size_t max_siblings,
                                     uint64_t* siblings_out, uint8_t* lefts_out, int32_t* n_siblings_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
   if (count == 0) return P2MT_OK;
@@ -850,10 +1038,12 @@ extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indic
     if ((size_t)n_siblings_out[i] > max_siblings) return p2mt::fail(P2MT_EINVAL, "get_proof: max_siblings too small");
   }
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_proof(const p2mt_mmr* m, size_t mmr_index, uint64_t* siblings_out, uint8_t* lefts_out,
                               int* n_siblings, uint64_t* peaks_out, int* n_peaks, size_t* mmr_size) {
+  return p2mt::abi_guard([&]() -> int {
   if (!siblings_out || !lefts_out || !n_siblings || !peaks_out || !n_peaks) return p2mt::fail(P2MT_EINVAL, "null pointer");
   const uint64_t idx = mmr_index;
   int32_t ns = 0;
@@ -862,11 +1052,13 @@ extern "C" int p2mt_mmr_proof(const p2mt_mmr* m, size_t mmr_index, uint64_t* sib
   *n_siblings = ns;
   if (mmr_size) *mmr_size = p2mt_mmr_len(m);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_proof_verify_batch_dev(const uint64_t* d_siblings, const uint8_t* d_lefts, const int32_t* d_n_siblings,
                                                size_t max_siblings, const uint64_t* d_peaks, int n_peaks,
                                                const uint64_t* d_leaves, const uint64_t* d_root, size_t m, int8_t* d_status_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (m == 0) return P2MT_OK;
   if (!d_n_siblings || !d_peaks || !d_leaves || !d_root || !d_status_out || n_peaks < 1 || n_peaks > 64)
@@ -878,11 +1070,13 @@ extern "C" int p2mt_mmr_proof_verify_batch_dev(const uint64_t* d_siblings, const
   P2MT_DISPATCH(k_mmr_verify_batch, grid_for(m), kBlock, d_siblings, d_lefts, d_n_siblings, max_siblings ? max_siblings : 1,
                 d_peaks, n_peaks, d_leaves, d_root, (const u64*)d_bagged, m, d_status_out);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8_t* lefts, const int32_t* n_siblings,
                                            size_t max_siblings, const uint64_t* peaks, int n_peaks, const uint64_t* leaves,
                                            const uint64_t* root, size_t m, int8_t* status_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (m == 0) return P2MT_OK;
   if (!n_siblings || !peaks || !leaves || !root || !status_out || n_peaks < 0 || n_peaks > 64)
@@ -917,10 +1111,12 @@ extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8
   P2MT_HIP(hipMemcpyAsync(status_out, bo.p, m, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_proof_verify(const uint64_t* siblings, const uint8_t* lefts, int n_siblings, const uint64_t* peaks,
                                      int n_peaks, uint64_t leaf, const uint64_t* root, int* result_out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!result_out || n_siblings < 0 || n_siblings > P2MT_MAX_PROOF_LEN) return p2mt::fail(P2MT_EINVAL, "bad argument");
   int8_t status = 0;
   const int32_t ns = n_siblings;
@@ -928,10 +1124,12 @@ extern "C" int p2mt_mmr_proof_verify(const uint64_t* siblings, const uint8_t* le
   if (status == (int8_t)P2MT_ENOTPEAK) return p2mt::fail(P2MT_ENOTPEAK, "MMR_proof::verify: assert!(self.peaks.contains(&next_hash))");
   *result_out = status;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_combine_shard_roots_dev(const uint64_t* d_shard_roots, size_t world, uint64_t* d_top_nodes_out,
                                                 uint64_t* d_root_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!d_shard_roots || !d_root_out || world == 0 || (world & (world - 1)) || world > kMaxWorld)
     return p2mt::fail(P2MT_EINVAL, "world must be a power of two <= 1024");
@@ -940,10 +1138,12 @@ extern "C" int p2mt_mmr_combine_shard_roots_dev(const uint64_t* d_shard_roots, s
                      d_root_out, p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_mmr_combine_shard_roots(const uint64_t* shard_roots, size_t world, uint64_t* top_nodes_out,
                                             uint64_t* root_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!shard_roots || !root_out || world == 0 || (world & (world - 1)) || world > kMaxWorld)
     return p2mt::fail(P2MT_EINVAL, "world must be a power of two <= 1024");
@@ -962,4 +1162,5 @@ extern "C" int p2mt_mmr_combine_shard_roots(const uint64_t* shard_roots, size_t 
   P2MT_HIP(hipMemcpyAsync(root_out, d + 4 * (2 * world - 1), 32, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }

@@ -138,6 +138,7 @@ int p2mt::partial_products_async_dev(const uint64_t* d_wires, const uint64_t* d_
 extern "C" int p2mt_permutation_partial_products_dev(const uint64_t* d_wires, const uint64_t* d_sigmas, const uint64_t* k_is,
                                                      const uint64_t* betas, const uint64_t* gammas, size_t num_challenges,
                                                      size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!d_wires || !d_sigmas || !k_is || !betas || !gammas || !d_out) return p2mt::fail(P2MT_EINVAL, "partial_products: null pointer");
   if (chunk < 2 || num_routed == 0 || num_routed > 4096 || degree_bits > 24 || num_challenges == 0 || num_challenges > 16)
@@ -165,11 +166,13 @@ extern "C" int p2mt_permutation_partial_products_dev(const uint64_t* d_wires, co
   P2MT_HIP(hipStreamSynchronize(st));
   if (flag) return p2mt::fail(P2MT_EINVAL, "partial_products: zero denominator (plonky2 panics on this division)");
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_permutation_partial_products(const uint64_t* wires, const uint64_t* sigmas, const uint64_t* k_is,
                                                  const uint64_t* betas, const uint64_t* gammas, size_t num_challenges,
                                                  size_t num_routed, unsigned degree_bits, unsigned chunk, uint64_t* out) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (!wires || !sigmas || !out) return p2mt::fail(P2MT_EINVAL, "partial_products: null pointer");
   if (chunk < 2 || num_routed == 0 || num_routed > 4096 || degree_bits > 24 || num_challenges == 0 || num_challenges > 16)
@@ -189,4 +192,5 @@ extern "C" int p2mt_permutation_partial_products(const uint64_t* wires, const ui
   P2MT_HIP(hipMemcpyAsync(out, bo.p, out_words * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
+  });
 }

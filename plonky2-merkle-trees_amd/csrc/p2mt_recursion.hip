@@ -571,23 +571,28 @@ void verify_merkle_proof_to_cap(B* b, const std::vector<u64>& leaf_data, const s
 
 // ==================================================================================================== C ABI
 extern "C" int p2mt_cb_add_virtual_proof_with_pis(p2mt_circuit_builder* b, const p2mt_circuit_data* inner, p2mt_target* out, size_t out_len) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b || !inner || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   p2mt_common_data cd;
   P2MT_TRY(p2mt_circuit_common_data(inner, &cd));
   if (out_len != cd.proof_len) return p2mt::fail(P2MT_EINVAL, "add_virtual_proof_with_pis: out_len must be the inner circuit's proof_len");
   for (size_t k = 0; k < out_len; ++k) out[k] = cb_virtual(b);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_cb_add_virtual_verifier_data(p2mt_circuit_builder* b, unsigned cap_height, p2mt_target* out) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b || !out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (cap_height != kCapHeight) return p2mt::fail(P2MT_EINVAL, "add_virtual_verifier_data: cap_height must be 4 (standard_recursion_config)");
   for (size_t k = 0; k < 64 + 4; ++k) out[k] = cb_virtual(b);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_cb_verify_proof(p2mt_circuit_builder* b, const p2mt_target* proof_with_pis, size_t proof_len,
                                     const p2mt_target* verifier_data, const p2mt_circuit_data* inner) {
+  return p2mt::abi_guard([&]() -> int {
   if (!b || !proof_with_pis || !verifier_data || !inner) return p2mt::fail(P2MT_EINVAL, "null pointer");
   p2mt_common_data cd;
   P2MT_TRY(p2mt_circuit_common_data(inner, &cd));
@@ -719,23 +724,28 @@ extern "C" int p2mt_cb_verify_proof(p2mt_circuit_builder* b, const p2mt_target* 
     connect_ext(b, reduce_ext(b, to_ext(b, subgroup_x), final_poly), old_eval);  // final_poly.eval_scalar
   }
   return P2MT_OK;
+  });
 }
 
 // pw.set_proof_with_pis_target(&target, &proof) (mmr_plonky2_verifier_1_recursion.rs:201): target[i] <- word[i]
 extern "C" int p2mt_pw_set_proof_with_pis_target(p2mt_partial_witness* pw, const p2mt_target* proof_target, const uint64_t* proof_words,
                                                  size_t proof_len) {
+  return p2mt::abi_guard([&]() -> int {
   if (!pw || !proof_target || !proof_words) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (size_t k = 0; k < proof_len; ++k) P2MT_TRY(p2mt_pw_set_target(pw, proof_target[k], proof_words[k]));
   return P2MT_OK;
+  });
 }
 
 // pw.set_verifier_data_target(&target, &inner.verifier_only) (:202): constants_sigmas_cap and circuit_digest of the inner circuit
 extern "C" int p2mt_pw_set_verifier_data_target(p2mt_partial_witness* pw, const p2mt_target* verifier_data_target,
                                                 const p2mt_circuit_data* inner) {
+  return p2mt::abi_guard([&]() -> int {
   if (!pw || !verifier_data_target || !inner) return p2mt::fail(P2MT_EINVAL, "null pointer");
   p2mt_common_data cd;
   P2MT_TRY(p2mt_circuit_common_data(inner, &cd));
   for (size_t k = 0; k < 64; ++k) P2MT_TRY(p2mt_pw_set_target(pw, verifier_data_target[k], cd.cs_cap[k]));
   for (size_t k = 0; k < 4; ++k) P2MT_TRY(p2mt_pw_set_target(pw, verifier_data_target[64 + k], cd.digest[k]));
   return P2MT_OK;
+  });
 }

@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <exception>
+#include <new>
+
 #include "../../include/p2mt.h"
 
 namespace p2mt {
@@ -53,6 +56,23 @@ Runtime& rt();
 int fail_hip(hipError_t e, const char* what, const char* file, int line);
 int fail(int code, const char* msg);
 int ensure_init();
+// No exception crosses the C ABI: every `extern "C" int` body runs inside this guard.  std::bad_alloc (a std::vector
+// growing inside the builder, the batch prover's staging, a worker pool) becomes P2MT_ENOMEM, anything else P2MT_EINVAL with its
+// what() as the message.
+template <typename F>
+inline int abi_guard(F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(P2MT_ENOMEM, "out of host memory (std::bad_alloc inside the library)");
+  } catch (const std::exception& e) {
+    return fail(P2MT_EINVAL, e.what());
+  } catch (...) {
+    return fail(P2MT_EINVAL, "unexpected C++ exception inside the library");
+  }
+}
+// exported by p2mt_mmr.hip: frees the calling thread's side stream / events / counters of the chunked MMR build
+void mmr_release_thread();
 // record an event on the library stream if profiling is on (slot = 2*i for start, 2*i+1 for stop)
 int prof_begin();
 void prof_end(int slot);

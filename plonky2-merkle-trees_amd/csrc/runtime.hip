@@ -194,12 +194,14 @@ int ensure_init() {
 using p2mt::rt;
 
 extern "C" int p2mt_device_count(void) {
+  return p2mt::abi_guard([&]() -> int {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return n;
+  });
 }
 
 // The process-global state is written under one lock; a process drives ONE device (one process per GPU): the twiddle / coset
@@ -207,6 +209,7 @@ extern "C" int p2mt_device_count(void) {
 // of leaving them pointing at the old one.
 static std::mutex g_init_mutex;
 extern "C" int p2mt_init(int device) {
+  return p2mt::abi_guard([&]() -> int {
   std::lock_guard<std::mutex> lock(g_init_mutex);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -269,19 +272,24 @@ extern "C" int p2mt_init(int device) {
   }
   rt().initialised = true;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_thread_stream_create(void) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   P2MT_HIP(hipSetDevice(rt().device));  // the current device is per thread too
   hipStream_t s = nullptr;
   P2MT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   rt().stream = s;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_thread_stream_destroy(void) {
+  return p2mt::abi_guard([&]() -> int {
   hipStream_t s = rt().stream;
+  p2mt::mmr_release_thread();
   p2mt::scratch_release_thread();
   if (s) {
     P2MT_HIP(hipStreamSynchronize(s));
@@ -289,62 +297,80 @@ extern "C" int p2mt_thread_stream_destroy(void) {
   }
   rt().stream = nullptr;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_set_throughput_mode(int on) {
+  return p2mt::abi_guard([&]() -> int {
   rt().throughput = on != 0;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_set_stream(void* hip_stream) {
+  return p2mt::abi_guard([&]() -> int {
   rt().stream = static_cast<hipStream_t>(hip_stream);
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_sync(void) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" const char* p2mt_last_error(void) { return p2mt::err_buf(); }
 
 extern "C" int p2mt_set_variant(int mds, int partial) {
+  return p2mt::abi_guard([&]() -> int {
   // partial: 0 dense, 1 sparse partial rounds; 2 (with mds == 2 only) = dense with the MDS layers on the matrix pipe (stage-1 A/B)
   if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 2 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_debug_force_fallback(int on) {
+  return p2mt::abi_guard([&]() -> int {
   rt().force_fallback = on ? 1 : 0;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_get_variant(int* mds, int* partial) {
+  return p2mt::abi_guard([&]() -> int {
   if (mds) *mds = rt().mds;
   if (partial) *partial = rt().partial;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_get_build_config(int* subtree_levels, int* tile_log, int* subtree_block) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());  // the knobs are read from the environment at init
   if (subtree_levels) *subtree_levels = rt().mds == 2 ? (int)rt().subtree_levels : 0;
   if (tile_log) *tile_log = rt().mds == 2 ? (int)rt().tile_log : 11;
   if (subtree_block) *subtree_block = (int)rt().subtree_block;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_profile_enable(int on) {
+  return p2mt::abi_guard([&]() -> int {
   rt().profile = on != 0;
   rt().prof_n = 0;
   return P2MT_OK;
+  });
 }
 
 // Sum and count of the HIP-event durations recorded around the dominant kernel launches since the last
 // p2mt_profile_enable(1); synchronises the stream.
 extern "C" int p2mt_profile_read(float* total_ms, int* launches) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   float sum = 0;
@@ -357,15 +383,19 @@ extern "C" int p2mt_profile_read(float* total_ms, int* launches) {
   if (launches) *launches = rt().prof_n;
   rt().prof_n = 0;
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_timer_start(void) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   P2MT_HIP(hipEventRecord(rt().ev_start, rt().stream));
   return P2MT_OK;
+  });
 }
 
 extern "C" int p2mt_timer_stop(float* elapsed_ms) {
+  return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   P2MT_HIP(hipEventRecord(rt().ev_stop, rt().stream));
   P2MT_HIP(hipEventSynchronize(rt().ev_stop));
@@ -373,4 +403,5 @@ extern "C" int p2mt_timer_stop(float* elapsed_ms) {
   P2MT_HIP(hipEventElapsedTime(&ms, rt().ev_start, rt().ev_stop));
   if (elapsed_ms) *elapsed_ms = ms;
   return P2MT_OK;
+  });
 }
