@@ -584,11 +584,12 @@ inline BoolTarget or_list(CircuitBuilder& builder, const std::vector<BoolTarget>
 inline HashOutTarget pick_hash(CircuitBuilder& builder, const HashOutTarget& option1, const HashOutTarget& option2,
                                BoolTarget pick_left) {
   const BoolTarget opposite = builder.not_(pick_left);
+  // call order as in common.rs:48-55 -- four `mul`s, then four `mul_add`s: the builder packs arithmetic operations into gate slots
+  // in call order, so a different interleaving gives different gate rows as soon as a gate is partly filled
+  Target t[4];
+  for (int i = 0; i < 4; ++i) t[i] = builder.mul(option2.elements[i], opposite.target);
   HashOutTarget out;
-  for (int i = 0; i < 4; ++i) {
-    const Target t = builder.mul(option2.elements[i], opposite.target);
-    out.elements[i] = builder.mul_add(option1.elements[i], pick_left.target, t);
-  }
+  for (int i = 0; i < 4; ++i) out.elements[i] = builder.mul_add(option1.elements[i], pick_left.target, t[i]);
   return out;
 }
 

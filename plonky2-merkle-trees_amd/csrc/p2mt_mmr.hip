@@ -109,26 +109,15 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
 // ONE inlined permutation.  Pending left siblings (at most one per height) live in a per-lane LDS stack; the control
 // flow is the binary-counter carry chain and is identical in all lanes.  A lane's 2^(LV+1)-1 nodes are a contiguous
 // post-order span, written node by node.  HBM traffic is the same algorithmic minimum as k_mmr_tile.
-// Chunk signalling (round 3): the launch covers blocks [block0, block0 + n_blocks) on a grid aligned to BLK blocks (grid_base is a
-// multiple of BLK, so a workgroup never straddles a chunk of 2^chunk_shift blocks).  A workgroup that lies in chunk c of
-// [chunk_first, chunk_first + n_chunks) publishes its nodes (agent-scope release) and adds 1 to chunk_cnt[c - chunk_first]; k_mmr_gate
-// on a second stream turns "all workgroups of chunk c have arrived" into a stream dependency, so that the upper levels of a finished
-// chunk run underneath the rest of this launch instead of behind it.
-struct ChunkSignal {
-  unsigned* cnt;           // null: no signalling
-  unsigned shift;          // log2(blocks per chunk)
-  unsigned long long first;  // first chunk index (in units of chunks of blocks)
-  unsigned n;
-};
 template <unsigned LV, int BLK, int PR = 0>
 __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ leaves, size_t leaf_base,
                                                      u64* __restrict__ elements, size_t block0, size_t n_blocks,
-                                                     size_t grid_base, ChunkSignal sig, PermCtx ctx) {
+                                                     PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
-  poseidon_fast::MfmaCtx mc;  // PR == 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
-  if constexpr (PR == 2) mc = poseidon_fast::mfma_ctx_init();
-  const size_t blk = grid_base + (size_t)blockIdx.x * BLK + threadIdx.x;
-  if (blk >= block0 && blk < block0 + n_blocks) {
+  poseidon_fast::MfmaCtx mc;  // PR >= 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
+  if constexpr (PR >= 2) mc = poseidon_fast::mfma_ctx_init();
+  const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
+  if (blk >= block0 + n_blocks) return;
   const size_t first_leaf = blk << LV;
   const u64* lp = leaves + (first_leaf - leaf_base);
   u64 cur[4] = {0, 0, 0, 0};
@@ -167,35 +156,6 @@ __global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ lea
     for (int k = 0; k < 4; ++k) cur[k] = o[k];
     if (merges == 0 && h < LV) store_hash(&stack[h - 1][threadIdx.x * 4], cur);  // becomes a pending left sibling
   }
-  }  // active lane
-  if (sig.cnt) {  // wave-uniform kernel argument
-    const size_t c = (grid_base + (size_t)blockIdx.x * BLK) >> sig.shift;
-    if (c >= sig.first && c - sig.first < sig.n) {  // workgroup-uniform; such a workgroup is fully active
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's node stores have left the CU ...
-      __syncthreads();                                   // ... and so have every other wave's of the workgroup
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines: the reader may sit on another XCD
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&sig.cnt[c - sig.first], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
-
-// One lane waits until all `target` workgroups of a chunk have arrived, then re-arms the counter for the next build and exits:
-// whatever follows on this stream starts (with the usual kernel-start acquire) after the chunk's nodes were published.  The wait is
-// bounded (wall clock): on a timeout -- the stage-1 launch failed or never ran -- *err_host is set and the build reports P2MT_EHIP.
-__global__ void k_mmr_gate(unsigned* cnt, unsigned target, unsigned long long timeout_ticks, int* err_host) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const unsigned long long t0 = wall_clock64();  // constant 100 MHz
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(64);
-    if (wall_clock64() - t0 > timeout_ticks) {
-      *err_host = 1;
-      break;
-    }
-  }
-  __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // MMR level (post-order, in place): node j of height h
@@ -433,54 +393,6 @@ struct p2mt_mmr {
   std::vector<u64> pending; // add_leaf queue (host), flushed as one bulk extend before the MMR is observed
 };
 
-// Side resources of the chunked build (per host thread, like the library stream): a high-priority stream on which the gates and
-// the upper levels of finished chunks run underneath the stage-1 launch, the fork / join events, the chunk counters and a pinned
-// error word the gate kernel can set.
-namespace {
-constexpr unsigned kMaxChunks = 16;
-struct MmrSide {
-  hipStream_t su = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  unsigned* d_cnt = nullptr;
-  int* h_err = nullptr;  // hipHostMalloc (mapped): written by k_mmr_gate on a timeout
-  int init() {
-    if (su) return P2MT_OK;
-    int lo = 0, hi = 0;
-    P2MT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (least, greatest)
-    P2MT_HIP(hipStreamCreateWithPriority(&su, hipStreamNonBlocking, hi));
-    P2MT_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    P2MT_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    P2MT_HIP(hipMalloc((void**)&d_cnt, kMaxChunks * sizeof(unsigned)));
-    P2MT_HIP(hipMemset(d_cnt, 0, kMaxChunks * sizeof(unsigned)));
-    P2MT_HIP(hipHostMalloc((void**)&h_err, sizeof(int), hipHostMallocMapped));
-    *h_err = 0;
-    return P2MT_OK;
-  }
-  void release() {
-    if (su) {
-      (void)hipStreamSynchronize(su);
-      (void)hipStreamDestroy(su);
-      (void)hipEventDestroy(ev_fork);
-      (void)hipEventDestroy(ev_join);
-      (void)hipFree(d_cnt);
-      (void)hipHostFree(h_err);
-    }
-    su = nullptr;
-  }
-};
-thread_local MmrSide tl_side;
-int chunks_enabled() {  // env P2MT_CHUNKS=0 selects the unchunked build (A/B)
-  static const int on = [] {
-    const char* e = getenv("P2MT_CHUNKS");
-    return e ? atoi(e) != 0 : 1;
-  }();
-  return on;
-}
-}  // namespace
-namespace p2mt {
-void mmr_release_thread() { tl_side.release(); }
-}  // namespace p2mt
-
 static constexpr size_t kMaxPendingLeaves = (size_t)1 << 20;
 static int mmr_extend_host(p2mt_mmr* m, const uint64_t* leaves, size_t k);
 // The add_leaf queue is dropped only once its leaves are in `elements`: a failed flush (allocation, copy) leaves the queue
@@ -499,16 +411,6 @@ extern "C" int p2mt_debug_fail_allocs(int n) {
   g_fail_allocs = n < 0 ? 0 : n;
   return P2MT_OK;
   });
-}
-
-// a gate of the chunked build timed out (the stage-1 launch failed or never ran): reported by the next synchronising call
-static int mmr_side_error() {
-  if (tl_side.h_err && *tl_side.h_err) {
-    *tl_side.h_err = 0;
-    (void)hipMemset(tl_side.d_cnt, 0, kMaxChunks * sizeof(unsigned));
-    return p2mt::fail(P2MT_EHIP, "chunked MMR build: a chunk of the stage-1 launch never completed (gate timeout)");
-  }
-  return P2MT_OK;
 }
 
 static size_t mmr_len_for(size_t n_leaves) { return 2 * n_leaves - (size_t)__builtin_popcountll((unsigned long long)n_leaves); }
@@ -672,76 +574,19 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       const size_t n_blocks = (b - a) >> span_log;
       const unsigned sb = rt().subtree_block;
       const size_t block0 = a >> span_log;
-      const size_t grid_base = block0 / sb * sb;  // grid aligned to whole workgroups of blocks (lanes in front of block0 stay idle)
-      const unsigned sgrid = (unsigned)((block0 + n_blocks - grid_base + sb - 1) / sb);
-      // Chunked build: the aligned 2^cl-leaf subtrees inside [a, b) (8..15 of them) each signal their completion from inside the
-      // stage-1 launch; their upper levels (sub_lv+1 .. cl) run on the side stream underneath the rest of the launch.
-      ChunkSignal sig{nullptr, 0, 0, 0};
-      unsigned cl = 0;
-      size_t c0 = 0, c1 = 0;
-      if (chunks_enabled() && sb == 256 && cap > sub_lv && p2mt::batch_B() == 1) {
-        const size_t span = b - a;
-        unsigned lg = 63 - (unsigned)__builtin_clzll((unsigned long long)span);
-        cl = lg >= 3 ? lg - 3 : 0;
-        if (cl >= 17 && cl <= cap) {  // chunks of >= 2^17 leaves = 32 workgroups; smaller builds keep the plain path
-          c0 = (a + (((size_t)1 << cl) - 1)) >> cl;
-          c1 = b >> cl;
-          if (c1 > c0 + 1 && c1 - c0 <= kMaxChunks && tl_side.init() == P2MT_OK) {
-            sig.cnt = tl_side.d_cnt;
-            sig.shift = cl - span_log;
-            sig.first = c0;
-            sig.n = (unsigned)(c1 - c0);
-          }
-        }
-      }
-      if (sig.cnt) {  // fork: the side stream starts behind everything enqueued on the library stream so far
-        P2MT_HIP(hipEventRecord(tl_side.ev_fork, st));
-        P2MT_HIP(hipStreamWaitEvent(tl_side.su, tl_side.ev_fork, 0));
-      }
+      const unsigned sgrid = (unsigned)((n_blocks + sb - 1) / sb);
       const int prof_slot = p2mt::prof_begin();  // stage 1 is the dominant launch
 #define P2MT_SUB(LVV, BB, PRR) \
   hipLaunchKernelGGL((k_mmr_subtree<LVV, BB, PRR>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks, \
-                     grid_base, sig, p2mt::perm_ctx())
+                     p2mt::perm_ctx())
       if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
       else if (rt().partial == 2 && sb == 256) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
+      else if (rt().partial == 3 && sb == 256) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
       else if (rt().partial == 1 && sb == 256) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
       else { if (sb == 64) P2MT_SUB(4, 64, 0); else if (sb == 128) P2MT_SUB(4, 128, 0); else P2MT_SUB(4, 256, 0); }
 #undef P2MT_SUB
       P2MT_LAUNCH_CHECK();
       p2mt::prof_end(prof_slot);
-      if (sig.cnt) {
-        const unsigned target = 1u << (cl - span_log - 8);  // workgroups (256 blocks of 2^span_log leaves) per chunk
-        int rc = P2MT_OK;
-        {
-          p2mt::StreamScope on_side(tl_side.su);
-          for (size_t c = c0; c < c1 && rc == P2MT_OK; ++c) {
-            hipLaunchKernelGGL(k_mmr_gate, dim3(1), dim3(64), 0, tl_side.su, sig.cnt + (c - c0), target,
-                               (unsigned long long)20 * 100000000ull, tl_side.h_err);
-            if (hipGetLastError() != hipSuccess) rc = p2mt::fail(P2MT_EHIP, "k_mmr_gate launch failed");
-            if (rc == P2MT_OK) rc = build_levels(m, nullptr, 0, c << cl, (c + 1) << cl, cl, sub_lv);
-          }
-        }
-        // join: the library stream continues behind the stage-1 launch AND the side stream (even after an error above, so that
-        // nothing of this build is still in flight on a stream the caller does not know about)
-        P2MT_HIP(hipEventRecord(tl_side.ev_join, tl_side.su));
-        P2MT_HIP(hipStreamWaitEvent(st, tl_side.ev_join, 0));
-        P2MT_TRY(rc);
-        // what the chunks did not cover: the ragged edges of the fused levels, heights sub_lv+1..cl outside the chunks, and
-        // everything above the chunk roots
-        for (unsigned h = 1; h <= sub_lv; ++h) {
-          P2MT_TRY(launch_level(m, h, n0 >> h, a >> h));
-          P2MT_TRY(launch_level(m, h, b >> h, n1 >> h));
-        }
-        for (unsigned h = sub_lv + 1; h <= cap && (n1 >> h) > (n0 >> h); ++h) {
-          if (h <= cl) {
-            P2MT_TRY(launch_level(m, h, n0 >> h, (c0 << cl) >> h));
-            P2MT_TRY(launch_level(m, h, (c1 << cl) >> h, n1 >> h));
-          } else {
-            P2MT_TRY(launch_level(m, h, n0 >> h, n1 >> h));
-          }
-        }
-        return P2MT_OK;
-      }
     } else {
       const unsigned grid = (unsigned)((b - a) >> span_log);
       const size_t t0 = a >> span_log;
@@ -835,7 +680,7 @@ extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t co
   if (!out) return p2mt::fail(P2MT_EINVAL, "null pointer");
   P2MT_HIP(hipMemcpyAsync(out, m->elements + 4 * first, count * 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
-  return mmr_side_error();
+  return P2MT_OK;
   });
 }
 
@@ -964,7 +809,7 @@ static int mmr_peaks_root(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks, 
   if (root_out) P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   if (n_peaks) *n_peaks = pl.n;
-  return mmr_side_error();
+  return P2MT_OK;
 }
 
 extern "C" int p2mt_mmr_root_dev(const p2mt_mmr* m, uint64_t* d_root_out) {

@@ -371,18 +371,19 @@ GL_DEV u64 mul_add_flag(u64 x, u64 k, u64 c, u64& sticky) {
 //   [leaf, 0, 0, 0] (hash_or_noop's zero padding, quirk Q1), i.e. half of all hashes of a tree build.  Only words 0 and 4 go
 //   through the first S-box layer; the other ten S-box outputs are the constants (rc[i])^7, read from rc[360 + ..].
 // SPARSE: the 22 partial rounds in the sparse form above (same function; the dense form is the default and the redo path).
-// MFMA: the dense MDS layers on the matrix pipe (mds_layer_mfma; `mc` from mfma_ctx_init(), made while every lane of the wave was
-//   still active).  Same function, same flag semantics.
-template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, bool MFMA = false>
+// MFMA: 1 = every dense MDS layer on the matrix pipe, 2 = only those of the 22 partial rounds (mds_layer_mfma; `mc` from
+//   mfma_ctx_init(), made while every lane of the wave was still active).  Same function, same flag semantics.
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
   u64 sticky = 0;
   static_assert(!(MFMA && (EXACT || SPARSE)), "the matrix-pipe MDS exists in the flag form with dense partial rounds only");
-  auto mds = [&](auto add_tag, auto rows_tag, const u64* add) {
+  auto mds4 = [&](auto add_tag, auto rows_tag, const u64* add, auto in_partial_round) {
     constexpr bool kAdd = decltype(add_tag)::value;
     constexpr int kRows = decltype(rows_tag)::value;
-    if constexpr (MFMA) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
+    if constexpr (MFMA == 1 || (MFMA == 2 && decltype(in_partial_round)::value)) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
     else mds_layer<kAdd, kRows, EXACT>(s, add, sticky);
   };
+  auto mds = [&](auto add_tag, auto rows_tag, const u64* add) { mds4(add_tag, rows_tag, add, std::false_type{}); };
   using T = std::true_type;
   using R12 = std::integral_constant<int, 12>;
   auto sbox = [&](u64 x) -> u64 {
@@ -469,7 +470,7 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc =
 #pragma unroll 1
     for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {
       s[0] = sbox(s[0]);
-      mds(T{}, R12{}, rc + 12 * (r + 1));
+      mds4(T{}, R12{}, rc + 12 * (r + 1), T{});
     }
   }
 #pragma unroll 1

@@ -71,8 +71,6 @@ inline int abi_guard(F&& f) noexcept {
     return fail(P2MT_EINVAL, "unexpected C++ exception inside the library");
   }
 }
-// exported by p2mt_mmr.hip: frees the calling thread's side stream / events / counters of the chunked MMR build
-void mmr_release_thread();
 // record an event on the library stream if profiling is on (slot = 2*i for start, 2*i+1 for stop)
 int prof_begin();
 void prof_end(int slot);

@@ -289,7 +289,6 @@ extern "C" int p2mt_thread_stream_create(void) {
 extern "C" int p2mt_thread_stream_destroy(void) {
   return p2mt::abi_guard([&]() -> int {
   hipStream_t s = rt().stream;
-  p2mt::mmr_release_thread();
   p2mt::scratch_release_thread();
   if (s) {
     P2MT_HIP(hipStreamSynchronize(s));
@@ -326,8 +325,8 @@ extern "C" const char* p2mt_last_error(void) { return p2mt::err_buf(); }
 
 extern "C" int p2mt_set_variant(int mds, int partial) {
   return p2mt::abi_guard([&]() -> int {
-  // partial: 0 dense, 1 sparse partial rounds; 2 (with mds == 2 only) = dense with the MDS layers on the matrix pipe (stage-1 A/B)
-  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 2 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  // partial: 0 dense, 1 sparse partial rounds; 2 / 3 (with mds == 2 only) = dense with all / only the partial rounds' MDS layers on the matrix pipe (stage-1 A/B)
+  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 3 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
   return P2MT_OK;

@@ -272,6 +272,24 @@ static void test_mmr_verifier_1_recursion_7leaves() {
   for (int k = 0; k < 4; ++k) REQUIRE(final_proof.public_inputs[k] == root.elements[k]);
 }
 
+// A caller that does arithmetic BEFORE pick_hash (common.rs:42-58): three `mul`s leave an ArithmeticGate partly filled, so the
+// order in which pick_hash issues its eight operations decides which gate slots they land in.  The digest is printed;
+// tests/test_cpp_mirror.py compares it with the Python mirror's and the oracle's for the same circuit.
+static void test_pick_hash_call_order() {
+  CircuitBuilder builder;
+  const Target x = builder.add_virtual_target(), y = builder.add_virtual_target();
+  const Target m1 = builder.mul(x, y), m2 = builder.mul(m1, y), m3 = builder.mul(m2, x);
+  const HashOutTarget h1 = builder.add_virtual_hash(), h2 = builder.add_virtual_hash();
+  const BoolTarget pick_left = builder.add_virtual_bool_target_safe();
+  const HashOutTarget out = pick_hash(builder, h1, h2, pick_left);
+  builder.register_public_inputs(out.elements);
+  builder.register_public_input(m3);
+  CircuitData data = builder.build();
+  const HashOut d = data.circuit_digest();
+  std::printf("pick_hash_call_order digest: %llu %llu %llu %llu\n", (unsigned long long)d.elements[0],
+              (unsigned long long)d.elements[1], (unsigned long long)d.elements[2], (unsigned long long)d.elements[3]);
+}
+
 int main() {
   if (p2mt_device_count() == 0) { std::fprintf(stderr, "no GPU: the product has no CPU fallback\n"); return 77; }
   check(p2mt_init(0));
@@ -287,6 +305,7 @@ int main() {
   test_mmr_verifier_3leaves();
   test_inner_merkle_proof_3leaves();
   test_mmr_verifier_1_recursion_7leaves();
+  test_pick_hash_call_order();
   std::puts("cpp mirror: 8 reference tests + prover pieces + the recursion passed");
   return 0;
 }

@@ -32,3 +32,43 @@ def test_reference_unit_tests_through_cpp_mirror():
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "8 reference tests + prover pieces + the recursion passed" in r.stdout
+
+
+def _pick_hash_circuit(builder, pick_hash):
+    x, y = builder.add_virtual_target(), builder.add_virtual_target()
+    m1 = builder.mul(x, y)
+    m2 = builder.mul(m1, y)
+    m3 = builder.mul(m2, x)
+    h1, h2 = builder.add_virtual_hash(), builder.add_virtual_hash()
+    pick_left = builder.add_virtual_bool_target_safe()
+    out = pick_hash(builder, h1, h2, pick_left)
+    builder.register_public_inputs(out)
+    builder.register_public_inputs([m3])
+    return builder.build()
+
+
+@pytest.mark.gpu
+def test_pick_hash_call_order_is_the_references_in_every_mirror():
+    """common.rs:48-55 issues four `mul`s and then four `mul_add`s.  With arithmetic in front of it (three `mul`s leave an
+    ArithmeticGate partly filled) any other interleaving lands in different gate slots: the C++ mirror, the Python mirror and the
+    oracle's builder must give ONE circuit digest (round 2's C++ mirror interleaved mul / mul_add per element)."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import __graft_entry__ as ge
+    from oracle import circuit as OC
+    from oracle_lib import Oracle
+    pkg = ge.load_package()
+    pkg.init(0)
+    from plonky2_merkle_trees_amd import mmr_plonky2_verifier as G
+    cd = _pick_hash_circuit(pkg.CircuitBuilder(), G.pick_hash)
+    ocd = _pick_hash_circuit(OC.CircuitBuilder(Oracle()), OC.pick_hash)
+    want = [int(v) for v in np.asarray(ocd.circuit_digest).reshape(4)]
+    assert [int(v) for v in cd.constants_sigmas()[2]] == want
+    _build()
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("pick_hash_call_order digest:")][0]
+    assert [int(v) for v in line.split(":")[1].split()] == want
