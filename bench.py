@@ -147,6 +147,103 @@ def cpu_baseline_mmr(host_leaves, gpu_elements_sha256, gpu_root, sample_log=20, 
             "_roots": (b1_root, fast_root, sample_log, fast_log)}
 
 
+def transfer_times(torch, host_leaves, mmr):
+    """H2D of the leaves and D2H of the node array, reported separately: the timed region starts with the leaves
+    resident in HBM and ends with the 32-byte root on the host; these are what a caller holding host buffers pays on top."""
+    n = host_leaves.size
+    pinned = torch.from_numpy(host_leaves.view(np.int64)).pin_memory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d = pinned.cuda(non_blocking=False)
+    torch.cuda.synchronize()
+    h2d_pinned = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    d2 = torch.from_numpy(host_leaves.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    h2d_pageable = (time.perf_counter() - t0) * 1e3
+    del d, d2
+    count = len(mmr)
+    out = np.empty((count, 4), np.uint64)
+    out.fill(0)  # fault the pages in before timing
+    t0 = time.perf_counter()
+    got = mmr.copy_elements(0, count)
+    d2h = (time.perf_counter() - t0) * 1e3
+    assert got.shape == out.shape
+    return {"h2d_ms_leaves_pinned": h2d_pinned, "h2d_ms_leaves_pageable": h2d_pageable, "leaves_bytes": int(n * 8),
+            "d2h_ms_elements_pageable": d2h, "elements_bytes": int(count * 32),
+            "note": "not part of `value`: leaves are resident in HBM when the timed region starts and only the root comes back; "
+                    "D2H includes allocating and faulting in the destination (what MMR.elements costs a caller)"}
+
+
+def run_config2(torch, pkg, lib, cpu_baseline=True):
+    """BASELINE.md B3 / BASELINE.json config 2: mmr::merkle_mountain_ranges build + get_proof, 2^20 leaves, 1 GPU -- build from
+    device-resident leaves, get_proof + MMR_proof::verify for the four fixed leaves {0, 1, 777 777, 2^20 - 1}
+    (/root/reference/src/mmr/merkle_mountain_ranges.rs:209-252), the same through the oracle on one host core, and the batched
+    proof service (p2mt_mmr_proof_batch / _verify_batch) on 2^20 proofs."""
+    n = 1 << 20
+    leaves = splitmix_leaves(n, 0x5EED0000 + 2)
+    d_leaves = torch.from_numpy(leaves.view(np.int64)).cuda()
+    m = pkg.MMR()
+    m.reserve(n)
+    idxs = [0, 1, 777777, n - 1]
+
+    def build():
+        m.reset()
+        m.extend_dev(d_leaves, n)
+        return m.bagging_the_peaks()
+
+    for _ in range(3):
+        root = build()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        root = build()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    build_ms = float(np.median(ts))
+    ts, proofs = [], None
+    for _ in range(10):
+        t0 = time.perf_counter()
+        proofs = [m.get_proof_normal_index(i) for i in idxs]
+        oks = [pr.verify(int(leaves[i]), root) for pr, i in zip(proofs, idxs)]
+        ts.append((time.perf_counter() - t0) * 1e3)
+    assert all(oks)
+    four_ms = float(np.median(ts))
+    # batched proof service: every leaf's proof in one call, verified in one call (host buffers in and out)
+    sel = np.arange(0, n, 4)  # every fourth leaf: 2^18 proofs (168 MB of siblings through host buffers)
+    all_idx = np.array([2 * int(i) - bin(int(i)).count("1") for i in sel], np.uint64)
+    t0 = time.perf_counter()
+    sib, lefts, ns = m.get_proof_batch(all_idx, max_siblings=20)
+    t1 = time.perf_counter()
+    status = pkg.verify_proof_batch(sib, lefts, ns, m.get_peaks(), leaves[sel], root)
+    t2 = time.perf_counter()
+    assert (status == 1).all() and (ns == 20).all()
+    n_service = sel.size
+    out = {"workload": "config 2 (BASELINE.md B3): 2^20-leaf MMR build + get_proof + verify for leaves {0, 1, 777777, 2^20-1}",
+           "build_ms": build_ms, "build_hashes_per_s": (n - 1) / (build_ms * 1e-3),
+           "get_proof_and_verify_4_leaves_ms": four_ms,
+           "proof_service": {"proofs": int(n_service), "get_proof_batch_proofs_per_s": n_service / (t1 - t0),
+                             "verify_batch_proofs_per_s": n_service / (t2 - t1),
+                             "note": "p2mt_mmr_proof_batch / p2mt_mmr_proof_verify_batch, host buffers in and out (PCIe-inclusive)"},
+           "root": [int(x) for x in root]}
+    if cpu_baseline:
+        o = _oracle().Oracle()
+        t0 = time.perf_counter()
+        om = o.mmr(leaves)  # the reference's add_leaf loop, spec-form port, 1 thread
+        cpu_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i, pr in zip(idxs, proofs):
+            opr = om.get_proof_normal_index(i)
+            assert np.array_equal(opr["siblings"], pr.siblings) and np.array_equal(opr["lefts"], pr.lefts)
+            assert o.mmr_proof_verify(opr["siblings"], opr["lefts"], opr["peaks"], leaves[i], om.bagging_the_peaks())
+        cpu_four = time.perf_counter() - t0
+        assert np.array_equal(om.bagging_the_peaks(), root), "config 2: GPU root != oracle root"
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "build_ms": cpu_build * 1e3, "get_proof_and_verify_4_leaves_ms": cpu_four * 1e3,
+                               "sample": "oracle/mmr.c: add_leaf loop over all 2^20 leaves, then get_proof + verify of the same four "
+                                         "leaves; proofs and root equal the GPU's",
+                               "gpu_over_cpu_build": cpu_build * 1e3 / build_ms}
+    return out
+
+
 def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
     # weak: every rank builds its own 2^log_leaves shard (per-GPU work fixed); strong: 2^log_leaves leaves in total, split
     # into world leaf ranges (BASELINE.json's "2^24 leaves at 1/2/4/8 GPUs"; config 5 = --scaling strong --log-leaves 26 --gpus 8
@@ -177,8 +274,12 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
     lib.p2mt_profile_enable(1)
     pkg._native.check(lib.p2mt_timer_start())
     t0 = time.perf_counter()
+    step_ms, t_prev = [], t0
     for _ in range(args.steps):
-        root = step()
+        root = step()  # ends with the root read-back, i.e. synchronised: per-step wall times cost nothing extra
+        t_now = time.perf_counter()
+        step_ms.append((t_now - t_prev) * 1e3)
+        t_prev = t_now
     region_ms = C.c_float(0)
     pkg._native.check(lib.p2mt_timer_stop(C.byref(region_ms)))
     fence()
@@ -234,14 +335,27 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                              "bytes, so the HBM fraction is ~2 % by construction (SURVEY.md 8d)"},
         # counter evidence for "compute-bound, the right way": share of SIMD issue cycles spent on VALU instructions and VALU
         # instructions per hash, from the committed PMC passes (null when this configuration was not profiled)
-        "valu": {"valu_busy": pmc.get("valu_busy"), "valu_busy_raw_ratio": pmc.get("valu_busy_raw_ratio"),
+        "valu": {"simd_cycles_per_valu_instr": pmc.get("simd_cycles_per_valu_instr"),
                  "valu_instr_per_hash": pmc.get("valu_instr_per_hash"), "effective_clock_ghz": pmc.get("effective_clock_ghz"),
+                 "ubench_simd_cycles_per_valu_instr": pmc.get("ubench_simd_cycles_per_valu_instr"),
                  "source": pmc.get("source"), "in_kernel_hashes_per_s": in_kernel_rate,
-                 "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), both counters from the same "
-                         "dispatches; the raw ratio of the two counters (1.00 +- 0.7 %) is clamped to 1"},
+                 "note": "simd_cycles_per_valu_instr = (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) / SQ_INSTS_VALU, both counters from "
+                         "the same dispatches: how many SIMD cycles the launch spends per VALU instruction it issues.  The "
+                         "micro-benchmarked cost of this kernel's instruction class on the same chip (tools/ubench_valu.hip: "
+                         "v_mad_u64_u32 and the other non-trivial VALU ops issue once per ~4.0-4.6 SIMD cycles, add/xor/mov once "
+                         "per ~2.3) is beside it: the kernel sits on the VALU issue cadence, so instructions per hash is the only "
+                         "lever.  (SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU on gfx950 -- an instruction count, not a busy counter -- "
+                         "which is why round 2's clamped `valu_busy` is gone.)"},
         "device_ms_per_step": region_ms.value / args.steps,
+        # SURVEY.md 8d asks for the median of the timed runs: `value` / `ms_per_step` stay total time / steps (the contract of this
+        # file); the per-step wall times (each step ends with the root read-back) give the median and the spread beside them
+        "ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(np.min(step_ms)),
+        "ms_per_step_max": float(np.max(step_ms)),
+        "value_at_median": total_hashes / (float(np.median(step_ms)) * 1e-3),
         "root": [int(x) for x in root],
     }
+    if world == 1:
+        out["transfers"] = transfer_times(torch, host_leaves, shard.local)
     if world == 1 and not args.no_cpu_baseline:
         import hashlib
         gpu_sha = hashlib.sha256(shard.local.elements.tobytes()).hexdigest()
@@ -258,6 +372,11 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
         cb["all_cores"]["gpu_over_cpu"] = value / cb["all_cores"]["value"]
         out["cpu_baseline"] = cb
     if world == 1 and not args.no_prove:
+        try:
+            out["config2_mmr_2pow20"] = run_config2(torch, pkg, lib, cpu_baseline=not args.no_cpu_baseline)
+        except Exception as e:  # the headline line must survive a failure of a secondary leg
+            out["config2_mmr_2pow20"] = {"error": repr(e)}
+    if world == 1 and not args.no_prove:
         # BASELINE.json's second metric (ms/proof), measured after and outside the timed region above
         import copy
         pa = copy.copy(args)
@@ -267,6 +386,8 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
             out["ms_per_proof_mmr_plonky2_verifier"] = {
                 "value": pr["value"], "unit": "ms", "config": pr["config"]["workload"],
                 "throughput": pr.get("throughput"), "throughput_threads": pr.get("throughput_threads"),
+                "verify_ms": pr.get("verify_ms"), "verify_batch_proofs_per_s": pr.get("verify_batch_proofs_per_s"),
+                "us_per_wave_permutation": (pr.get("roofline") or {}).get("us_per_permutation"),
                 "cpu_baseline": pr.get("cpu_baseline"),
                 "how": "python bench.py --workload prove"}
         except Exception as e:  # the headline line must survive a failure of the secondary leg
@@ -276,10 +397,25 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
             rr = run_recursion(pa, torch, pkg, lib, cpu_baseline=not args.no_cpu_baseline)
             out["ms_per_proof_mmr_plonky2_verifier_1_recursion"] = {
                 "value": rr["value"], "unit": "ms", "config": rr["config"], "verify_outer_ms": rr["verify_outer_ms"],
+                "throughput": rr.get("throughput"),
                 "cpu_baseline": rr.get("cpu_baseline"), "how": "python bench.py --workload recursion"}
         except Exception as e:
             out["ms_per_proof_mmr_plonky2_verifier_1_recursion"] = {"error": repr(e)}
     return out
+
+
+def run_probe(cmd, env=None, timeout=300):
+    """A throughput probe in its own process -> its last JSON line, or {"error": ...}: a slow, hung or crashed probe must not
+    cost the caller the JSON line it has already measured."""
+    import subprocess
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return {"error": "probe did not finish: %r" % (e,)}
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return {"error": (r.stdout + r.stderr)[-400:]}
 
 
 def run_commit(args, torch, pkg, lib):
@@ -520,26 +656,19 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
         # throughput: one prover per host thread (own stream, circuit handle, witness), in a separate process so that it can
         # run with blocking synchronisation (a device flag that must precede the HIP context; it frees the host cores the
         # spinning waits burn and lets 32 provers share the box's 16 cores) while the latency leg above keeps spinning
-        import subprocess
         env = dict(os.environ, GPU_MAX_HW_QUEUES=str(min(args.threads, 32)))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_threads_probe.py"), "4", str(args.threads), "3"],
-                           capture_output=True, text=True, env=env, timeout=300)
-        try:
-            out["throughput_threads"] = json.loads(r.stdout.strip().splitlines()[-1])
+        out["throughput_threads"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "prove_threads_probe.py"), "4",
+                                               str(args.threads), "3"], env=env)
+        if "error" not in out["throughput_threads"]:
             out["throughput_threads"]["note"] = ("independent provers on one GPU, one per host thread and stream (bound by the "
                                                  "device's dispatch-packet rate)")
-        except Exception:
-            out["throughput_threads"] = {"error": (r.stdout + r.stderr)[-400:]}
         # the batched prover (p2mt_batch_prover_*): 256 statements per pass, the proof index in a grid dimension of every launch;
-        # three host threads so that one pass's latency-bound transcript overlaps the others' grind (2 x 128: 18.8 k, 3 x 256: 22.4 k)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_batch_probe.py"), "4", "3", "256", "3"],
-                           capture_output=True, text=True, env=dict(os.environ), timeout=300)
-        try:
-            out["throughput"] = json.loads(r.stdout.strip().splitlines()[-1])
+        # three host threads so that one pass's latency-bound transcript overlaps the others' grind
+        out["throughput"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "prove_batch_probe.py"), "4", "3", "256", "3"],
+                                      env=dict(os.environ))
+        if "error" not in out["throughput"]:
             out["throughput"]["note"] = ("p2mt_batch_prover: proofs bit-identical to the single-proof path's; `value` above "
                                          "stays the single-proof latency")
-        except Exception:
-            out["throughput"] = {"error": (r.stdout + r.stderr)[-400:]}
     if not args.no_cpu_baseline:
         from oracle import circuit as OC
         o = _oracle().Oracle()
@@ -699,15 +828,10 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
     if getattr(args, "workload", "") == "recursion":
         # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks per thread at B = 32; two threads so
         # that one pass's one-workgroup witness interpreter overlaps the other's hashing)
-        import subprocess
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", "4", "2"],
-                           capture_output=True, text=True, timeout=300)
-        try:
-            out["throughput"] = json.loads(r.stdout.strip().splitlines()[-1])
+        out["throughput"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", "4", "2"])
+        if "error" not in out["throughput"]:
             out["throughput"]["note"] = ("p2mt_batch_prover on the inner and on the outer circuit, two host threads; proofs "
                                          "bit-identical to the one-at-a-time path's; `value` above stays the single-proof latency")
-        except Exception:
-            out["throughput"] = {"error": (r.stdout + r.stderr)[-400:]}
     if cpu_baseline:
         from oracle import circuit as OC, recursion as R
         o = _oracle().Oracle()

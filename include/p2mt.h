@@ -440,7 +440,10 @@ int p2mt_proof_from_bytes(const p2mt_circuit_data *c, const uint8_t *bytes, size
  * circuit must outlive it.  Device memory, allocated on the first prove: per proof of the batch ~2 MB for a 64-row circuit,
  * ~115 MB for the 2^12-row outer recursion circuit.
  * witnesses[i] -> proofs_out + i * proof_stride for i < n (any n: passes of up to `batch`); every witness must set the same
- * targets in the same order.  status_out[i] (may be NULL) = status of proof i; returns the first non-zero status. */
+ * targets in the same order.  status_out[i] (may be NULL) = status of proof i; returns the first non-zero status.  A statement
+ * whose status is non-zero (a witness that contradicts the circuit, a zero denominator, zeta in the subgroup: where plonky2 panics or
+ * returns Err) leaves ALL-ZERO words in its slot of proofs_out, never a well-formed-looking proof; the same holds for
+ * p2mt_circuit_prove's proof_out. */
 typedef struct p2mt_batch_prover p2mt_batch_prover;
 int p2mt_batch_prover_create(p2mt_circuit_data *c, size_t batch, p2mt_batch_prover **out);
 int p2mt_batch_prover_destroy(p2mt_batch_prover *b);

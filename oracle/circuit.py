@@ -94,6 +94,42 @@ def _coset_interp_tables():
 COSET_DOMAIN, COSET_WEIGHTS = _coset_interp_tables()
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Conventions of plonky2 @3b21b87d that were restated from recall AND have a plausible alternative.  ONE switch per convention; the
+# library's twin is csrc/circuit_types.h (kDigestDomainSeparator).  Flipping one is a one-line change here plus one there, then
+# `python tools/gen_prove_golden.py && python tools/gen_crosscheck_vectors.py` and the whole suite.  tools/plonky2_crosscheck
+# carries the circuit digest (and a full proof) under every alternative, so one cargo run tells which one real plonky2 uses.
+#   digest_domain_separator -- circuit_builder.rs build(): circuit_digest = hash_no_pad(cap || D || degree_bits) with
+#     "hash_pad"   D = hash_pad(domain_separator = [])   (pad10*1 to the sponge rate: hash_no_pad([1,0,0,0,0,0,0,1]))  [default]
+#     "zero_hash"  D = hash_no_pad([]) = [0, 0, 0, 0]     (what rounds 1-2 of this repository assumed)
+#     "none"       no D term (a revision older than the domain separator)
+CONVENTIONS = {"digest_domain_separator": "hash_pad"}
+DIGEST_DOMAIN_SEPARATORS = ("hash_pad", "zero_hash", "none")
+
+
+def hash_pad(o, elements):
+    """Hasher::hash_pad (plonk/config.rs): push 1, zeros until one slot short of a multiple of the rate, push 1, hash_no_pad"""
+    padded = [int(x) for x in elements] + [1]
+    while (len(padded) + 1) % 8:
+        padded.append(0)
+    padded.append(1)
+    return o.hash_no_pad(np.array(padded, np.uint64))
+
+
+def circuit_digest(o, cs_cap, degree_bits, mode=None):
+    mode = mode or CONVENTIONS["digest_domain_separator"]
+    parts = [np.asarray(cs_cap, np.uint64).reshape(-1)]
+    if mode == "hash_pad":
+        parts.append(hash_pad(o, []))
+    elif mode == "zero_hash":
+        parts.append(np.zeros(4, np.uint64))
+    else:
+        assert mode == "none", mode
+    parts.append(np.array([degree_bits], np.uint64))
+    return o.hash_no_pad(np.concatenate(parts))
+
+
 class Config:
     """CircuitConfig::standard_recursion_config() (mmr_plonky2_verifier.rs:30)."""
     num_wires = 135
@@ -714,9 +750,7 @@ class CircuitData:
         self.cs_coeffs = o.ifft_rows(self.constants_sigmas)
         self.cs_leaves, self.cs_digests, self.cs_cap = o.polynomial_batch_commit(self.constants_sigmas, True,
                                                                                 cfg.rate_bits, cfg.cap_height)
-        # circuit_digest = hash_no_pad(cap || hash_no_pad(domain_separator = []) || degree_bits)
-        self.circuit_digest = o.hash_no_pad(np.concatenate([self.cs_cap.reshape(-1), np.zeros(4, np.uint64),
-                                                            np.array([self.degree_bits], np.uint64)]))
+        self.circuit_digest = circuit_digest(o, self.cs_cap, self.degree_bits)
         self.fri_params = o.fri_params_standard(self.degree_bits)
         self.desc = o.plonk_desc(self.degree_bits, cfg.num_wires, cfg.num_routed_wires, cfg.num_constants,
                                  self.num_selectors, cfg.num_challenges, cfg.max_quotient_degree_factor, kinds,

@@ -23,6 +23,19 @@ constexpr u32 kNumWires = 135, kNumRouted = 80, kNumConsts = 2, kNumCh = 2, kQF 
 constexpr u32 kNumChunks = (kNumRouted + kQF - 1) / kQF, kNumProds = kNumChunks - 1, kNumOps = kNumRouted / 4;
 constexpr u32 kNumZs = kNumCh * (1 + kNumProds), kNumQuot = kNumCh * kQF, kNumGateConstraints = 123;
 
+// Conventions of plonky2 @3b21b87d restated from recall that have a plausible alternative: ONE switch each (the twin in the
+// CPU restatement is CONVENTIONS in its circuit module; tools/plonky2_crosscheck carries the vectors of every alternative).
+//   circuit_digest = hash_no_pad(constants_sigmas_cap || D || degree_bits), D = the digest of the (empty) domain separator:
+enum { kDomainSepHashPad = 0,   // D = hash_pad([]) = hash_no_pad([1,0,0,0,0,0,0,1])  (circuit_builder.rs build(), pad10*1)  [default]
+       kDomainSepZeroHash = 1,  // D = hash_no_pad([]) = [0,0,0,0]                      (rounds 1-2 of this repository)
+       kDomainSepNone = 2 };    // no D term                                            (a revision without domain separators)
+constexpr int kDigestDomainSeparator = kDomainSepHashPad;
+//   proof of work: the response of a candidate w is `observe(w); get_challenge()` on a copy of the transcript (fri/prover.rs
+//   fri_proof_of_work, one duplexing).  Implemented by k_fri_pow*, the transcript tail of p2mt_fri.hip, verify_fri_queries_host and
+//   the in-circuit check of p2mt_recursion.hip; if plonky2's verify reports "Invalid proof-of-work witness" on the cross-check,
+//   those four sites are what to change.
+constexpr int kPowRule = 0;
+
 // Gate types (the numbering is the oracle's ORACLE_GATE_*).  The last eight are what builder.verify_proof adds; their parameters
 // are what each gate's new_from_config yields for 80 routed / 135 wires / 2 constants, D = 2.
 enum {

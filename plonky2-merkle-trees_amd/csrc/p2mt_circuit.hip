@@ -29,6 +29,7 @@
 #include <tuple>
 #include <type_traits>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 using namespace p2mt_dev;
@@ -2250,13 +2251,26 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
     P2MT_HIP(hipStreamSynchronize(st));  // `act` dies here
   }
   if (c->n_pi) P2MT_HIP(hipMemcpyAsync(c->d_pi_slot, pi_slot.data(), c->n_pi * 4, hipMemcpyHostToDevice, st));
-  // constants_sigmas commitment and the circuit digest = hash_no_pad(cap || hash_no_pad([]) || degree_bits)
+  // constants_sigmas commitment and the circuit digest = hash_no_pad(cap || D || degree_bits)
   u64* d_cap = c->d_head + 8;  // borrowed: the proof buffer is not in use yet
   P2MT_TRY(p2mt::commit_batch_dev(c->d_cs_vals, 1, n_cs, c->degree_bits, kRateBits, kCapHeight, c->d_cs_coeffs, c->d_cs_lde,
                                   c->d_cs_leaves, nd ? c->d_cs_dig : nullptr, d_cap));
-  const u64 tail[5] = {0, 0, 0, 0, c->degree_bits};
-  P2MT_HIP(hipMemcpyAsync(d_cap + 64, tail, sizeof tail, hipMemcpyHostToDevice, st));
-  P2MT_TRY(p2mt::launch_hash_rows_dev(d_cap, 1, 69, 0, c->d_head));
+  {  // D = digest of the empty domain separator, by convention (circuit_types.h kDigestDomainSeparator), then degree_bits
+    static_assert(kPowRule == 0, "only fri_proof_of_work's observe-then-squeeze rule is implemented on the device");
+    size_t len = 64;
+    if (kDigestDomainSeparator == kDomainSepHashPad) {  // hash_pad([]): pad10*1 to the sponge rate
+      const u64 padded[8] = {1, 0, 0, 0, 0, 0, 0, 1};
+      P2MT_HIP(hipMemcpyAsync(d_cap + 72, padded, sizeof padded, hipMemcpyHostToDevice, st));
+      P2MT_TRY(p2mt::launch_hash_rows_dev(d_cap + 72, 1, 8, 0, d_cap + 64));
+      len += 4;
+    } else if (kDigestDomainSeparator == kDomainSepZeroHash) {
+      P2MT_HIP(hipMemsetAsync(d_cap + 64, 0, 32, st));
+      len += 4;
+    }
+    const u64 db = c->degree_bits;
+    P2MT_HIP(hipMemcpyAsync(d_cap + len, &db, 8, hipMemcpyHostToDevice, st));
+    P2MT_TRY(p2mt::launch_hash_rows_dev(d_cap, 1, len + 1, 0, c->d_head));
+  }
   P2MT_HIP(hipMemcpyAsync(c->cs_cap, d_cap, sizeof c->cs_cap, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipMemcpyAsync(c->digest, c->d_head, sizeof c->digest, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
@@ -2481,11 +2495,14 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* p
   int rc = P2MT_OK;
   for (unsigned bi = 0; bi < B; ++bi) {
     const u64* h = c->h_pin + (size_t)bi * c->pin_pitch + 8;
-    std::copy(h, h + c->proof_len, proofs_out + (size_t)bi * proof_stride);
     int err[4];
     memcpy(err, h + c->proof_len, sizeof err);
     if (err[2] != 0) *gave_up = 1;
     const int r = witness_status(c, err);
+    // plonky2 yields no proof where it panics or returns Err (contradicting witness, zero denominator, zeta in the subgroup): a
+    // failed statement leaves zeros, not a well-formed-looking proof of garbage, next to its non-zero status
+    if (r == P2MT_OK) std::copy(h, h + c->proof_len, proofs_out + (size_t)bi * proof_stride);
+    else std::fill(proofs_out + (size_t)bi * proof_stride, proofs_out + (size_t)bi * proof_stride + c->proof_len, (uint64_t)0);
     if (status_out) status_out[bi] = r;
     if (r != P2MT_OK && rc == P2MT_OK) rc = r;
   }
@@ -2615,12 +2632,32 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
       for (unsigned b = 0; b < B; ++b) fn(b);
       return;
     }
+    // A worker that throws (std::bad_alloc in a per-proof buffer) must not reach std::terminate, and a pool that cannot be
+    // created (std::system_error) must not leave joinable threads behind: the first exception is carried to the calling thread
+    // and rethrown there, where the entry point's abi_guard turns it into a status code.
+    std::exception_ptr first_exc;
+    std::mutex exc_mutex;
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < T; ++t)
-      pool.emplace_back([&, t] {
+    auto body = [&](unsigned t) {
+      try {
         for (unsigned b = t; b < B; b += T) fn(b);
-      });
+      } catch (...) {
+        std::lock_guard<std::mutex> g(exc_mutex);
+        if (!first_exc) first_exc = std::current_exception();
+      }
+    };
+    try {
+      pool.reserve(T);
+      for (unsigned t = 1; t < T; ++t) pool.emplace_back(body, t);
+    } catch (...) {  // fewer workers than planned: their strides are done below by this thread
+      std::lock_guard<std::mutex> g(exc_mutex);
+      if (!first_exc) first_exc = std::current_exception();
+    }
+    const unsigned started = (unsigned)pool.size() + 1;
+    body(0);
+    for (unsigned t = started; t < T; ++t) body(t);
     for (auto& th : pool) th.join();
+    if (first_exc) std::rethrow_exception(first_exc);
   };
   for_each_proof([&](unsigned b) {
     const uint64_t* proof = proofs + (size_t)b * proof_stride;
@@ -2809,8 +2846,15 @@ extern "C" int p2mt_circuit_prove_many(p2mt_circuit_data* const* circuits, size_
   };
   std::vector<std::thread> pool;
   const size_t n_workers = std::min(n_handles, n);
-  for (size_t t = 0; t < n_workers; ++t) pool.emplace_back(worker, t);
+  bool pool_failed = false;
+  try {
+    pool.reserve(n_workers);
+    for (size_t t = 0; t < n_workers; ++t) pool.emplace_back(worker, t);
+  } catch (...) {  // std::system_error: the threads that did start drain the whole queue
+    pool_failed = pool.empty();
+  }
   for (auto& th : pool) th.join();
+  if (pool_failed) return p2mt::fail(P2MT_ENOMEM, "prove_many: could not start a worker thread");
   const int rc = first_err.load();
   return rc == P2MT_OK ? P2MT_OK : p2mt::fail(rc, "prove_many: at least one prove failed (see status_out)");
   });
@@ -2885,7 +2929,24 @@ extern "C" int p2mt_batch_prover_destroy(p2mt_batch_prover* b) {
 }
 
 // first use: size the per-proof scratch arena from one tracked single-proof run, then allocate the blocks
+static int batch_prover_prepare_impl(p2mt_batch_prover* b, const p2mt_partial_witness* pw);
+// Any non-OK exit of the preparation gives everything back (device blocks -- several GB for the outer recursion circuit --, the
+// pinned staging and the challenger wrapper), so the next prove simply starts over instead of overwriting live pointers.
 static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness* pw) {
+  const int rc = batch_prover_prepare_impl(b, pw);
+  if (rc != P2MT_OK && !b->ready) {
+    (void)hipStreamSynchronize(rt().stream);
+    if (b->d_block) (void)hipFree(b->d_block);
+    if (b->h_pin) (void)hipHostFree(b->h_pin);
+    b->d_block = nullptr;
+    b->h_pin = nullptr;
+    b->pp.h_pin = nullptr;
+    if (b->pp.ch) p2mt::challenger_unwrap(b->pp.ch);
+    b->pp.ch = nullptr;
+  }
+  return rc;
+}
+static int batch_prover_prepare_impl(p2mt_batch_prover* b, const p2mt_partial_witness* pw) {
   p2mt_circuit_data* c = b->c;
   std::vector<u64> tmp(c->proof_len);
   p2mt::scratch_track_reset();
@@ -2916,6 +2977,13 @@ static int batch_prover_prepare(p2mt_batch_prover* b, const p2mt_partial_witness
     arena += b->slot_cap[k];
   }
   b->stride = (b->arena_off + arena + 255) & ~(size_t)255;
+  {  // the batched paths move per-proof fields with hipMemcpy2DAsync, block stride = pitch: HIP caps the pitch (~2 GB)
+    int max_pitch = 0;
+    P2MT_HIP(hipDeviceGetAttribute(&max_pitch, hipDeviceAttributeMaxPitch, rt().device));
+    if (max_pitch > 0 && b->stride > (size_t)max_pitch)
+      return p2mt::fail(P2MT_EINVAL, "batch prover: one proof's device block exceeds the device's maximum copy pitch (circuit too large "
+                                     "for the batched prover; use p2mt_circuit_prove)");
+  }
   if (hipMalloc((void**)&b->d_block, b->stride * b->B) != hipSuccess) {
     (void)hipGetLastError();
     b->d_block = nullptr;

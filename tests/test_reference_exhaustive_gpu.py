@@ -143,3 +143,58 @@ def test_recursion_every_leaf(pkg, oracle, n_leaves):
         assert np.array_equal(go.generate_witness(opws[0]), oo.generate_witness(w)[0])
         done += len(cases)
     assert done == n_leaves
+
+
+@pytest.mark.parametrize("n_sib,n_peaks", [(31, 1), (31, 2)])
+def test_recursion_over_a_2pow7_row_inner_circuit(pkg, oracle, n_sib, n_peaks):
+    """verify_inner_merkle_proof_circuit is generic in nr_merkle_proof_elms (mmr_plonky2_verifier_1_recursion.rs:20-75): ~31 path
+    elements -- MMRs near the reference's own 2^31-leaf limit (quirk Q6) -- pad the inner circuit to 2^7 rows, one more FRI query
+    step bit and a longer Merkle path per query than the 2^6-row case of config 4.  The outer circuit over it (still 2^12 rows):
+    built circuit == oracle's, outer witness == oracle's, the outer proof is accepted by both verifiers, a tampered inner proof
+    cannot be witnessed."""
+    from circuit_cases import synthetic_case
+    leaf, sib, lefts, peaks1, root1 = synthetic_case(oracle, n_sib, 4242 + n_peaks)
+    # n_peaks > 1: the recomputed mountain root is the LAST peak, the others are arbitrary digests; root = bagging of all of them
+    rng = np.random.default_rng(99)
+    peaks = np.concatenate([rng.integers(0, P, size=(n_peaks - 1, 4), dtype=np.uint64), peaks1]) if n_peaks > 1 else peaks1
+    root = root1 if n_peaks == 1 else oracle.hash_no_pad(peaks.reshape(-1))
+    case = (leaf, sib, lefts, peaks, root)
+    gi, gleaf, gproof_ts = pkg.verify_inner_merkle_proof_circuit(n_sib, n_peaks)
+    oi, oleaf, oproof_ts = OC.verify_inner_merkle_proof_circuit(oracle, n_sib, n_peaks)
+    assert gi.info.degree_bits == 7
+    check_build(gi, oi)
+    ipw = _inner_witness(pkg, gi, gleaf, gproof_ts, case)
+    inner_proof = gi.prove(ipw)
+    assert gi.verify(inner_proof) and oi.verify(inner_proof) == (True, 0)
+    go, gpt, gvd, gpeak_ts = pkg.complete_verification_circuit_with_inner_proof(gi.common, n_peaks)
+    oo, opt, ovd, opeak_ts = R.complete_verification_circuit_with_inner_proof(oracle, R.CommonData(oi), n_peaks)
+    assert go.info.degree_bits == 12
+    check_build(go, oo)
+
+    def outer_witness(ip):
+        pw = pkg.PartialWitness()
+        pw.set_proof_with_pis_target(gpt, ip)
+        pw.set_verifier_data_target(gvd, gi.verifier_only)
+        for pt, pk in zip(gpeak_ts, peaks):
+            pw.set_hash_target(pt, [int(x) for x in pk])
+        for k, t in enumerate(go.prover_only.public_inputs):
+            pw.set_target(t, int(root[k]))
+        return pw
+
+    opw = outer_witness(inner_proof)
+    w = {}
+    R.set_proof_with_pis_target(w.__setitem__, opt, inner_proof)
+    R.set_verifier_data_target(w.__setitem__, ovd, oi)
+    for pt, pk in zip(opeak_ts, peaks):
+        for k in range(4):
+            w[pt[k]] = int(pk[k])
+    for k in range(4):
+        w[oo.public_inputs[k]] = int(root[k])
+    assert np.array_equal(go.generate_witness(opw), oo.generate_witness(w)[0])
+    final_proof = go.prove(opw)
+    assert go.verify(final_proof) and oo.verify(final_proof) == (True, 0)
+    assert np.array_equal(final_proof[-4:], root)
+    bad = inner_proof.copy()
+    bad[300] ^= 1
+    with pytest.raises(pkg.P2mtError):
+        go.prove(outer_witness(bad))

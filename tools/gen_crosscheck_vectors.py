@@ -35,6 +35,31 @@ def main():
     tr = {}
     proof = cd.prove(pw, trace=tr)
     assert cd.verify(proof) == (True, 0)
+    # the same circuit and statement under every alternative of the recalled conventions that has one (oracle/circuit.py CONVENTIONS):
+    # the circuit digest opens the transcript, so each alternative has its own challenges and its own proof
+    variants = {}
+    default_mode = OC.CONVENTIONS["digest_domain_separator"]
+    for mode in OC.DIGEST_DOMAIN_SEPARATORS:
+        OC.CONVENTIONS["digest_domain_separator"] = mode
+        try:
+            vcd, vleaf, vproof_ts, vpeak_ts = OC.verify_mmr_proof_circuit(o, len(pr["siblings"]), len(pr["peaks"]))
+            vpw = {vleaf: 2}
+            for (ht, bt), sgl, l in zip(vproof_ts, pr["siblings"], pr["lefts"]):
+                for k in range(4):
+                    vpw[ht[k]] = int(sgl[k])
+                vpw[bt] = int(l)
+            for pt, pk in zip(vpeak_ts, pr["peaks"]):
+                for k in range(4):
+                    vpw[pt[k]] = int(pk[k])
+            for k, t in enumerate(vcd.public_inputs):
+                vpw[t] = int(root[k])
+            vproof = vcd.prove(vpw)
+            assert vcd.verify(vproof) == (True, 0)
+            variants[mode] = {"circuit_digest": [int(x) for x in vcd.circuit_digest], "proof_words": [int(x) for x in vproof],
+                              "is_default": mode == default_mode}
+        finally:
+            OC.CONVENTIONS["digest_domain_separator"] = default_mode
+    assert variants[default_mode]["proof_words"] == [int(x) for x in proof]
     out = {
         "circuit": "verify_mmr_proof_circuit(nr_merkle_proof_elms = %d, nr_peaks = %d)" % (len(pr["siblings"]), len(pr["peaks"])),
         "mmr_leaves": [1, 2, 3], "leaf_index": 1,
@@ -55,6 +80,8 @@ def main():
                         "plonk_sigmas[80][2] | wires[135][2] | plonk_zs[2][2] | plonk_zs_next[2][2] | partial_products[18][2] | "
                         "quotient_polys[16][2] | FriProof | public_inputs[4]" % (cd.num_selectors + 2),
         "proof_words": [int(x) for x in proof],
+        "digest_domain_separator_default": default_mode,
+        "digest_domain_separator_variants": variants,
         "notes": ["unused PublicInputGate wires are ZERO here (plonky2's randomize_unused_pi_wires puts random values there): "
                   "wires_cap and everything after it differ from a plonky2-generated proof, but this proof is a valid witness and "
                   "plonky2's verify() must accept it if every convention in DESIGN.md's checklist matches",

@@ -51,12 +51,31 @@ fn main() -> Result<()> {
     let cap0: Vec<u64> = data.verifier_only.constants_sigmas_cap.0[0].elements.iter().map(|x| x.to_canonical_u64()).collect();
     println!("circuit_digest     plonky2 {:?}\n                   p2mt    {}", digest, v["circuit_digest"]);
     println!("cs_cap[0]          plonky2 {:?}\n                   p2mt    {}", cap0, v["constants_sigmas_cap_0"]);
-    let digest_ok = digest == v["circuit_digest"].as_array().unwrap().iter().map(u).collect::<Vec<_>>();
     let cap_ok = cap0 == v["constants_sigmas_cap_0"].as_array().unwrap().iter().map(u).collect::<Vec<_>>();
-    println!("=> circuit_digest {}  constants_sigmas_cap[0] {}", if digest_ok { "MATCH" } else { "DIFFER" }, if cap_ok { "MATCH" } else { "DIFFER" });
+    // The circuit digest was restated from recall and has plausible alternatives (oracle/circuit.py CONVENTIONS,
+    // csrc/circuit_types.h kDigestDomainSeparator): hash_pad([]) / hash_no_pad([]) / no domain-separator term.  The JSON carries the
+    // digest and a full proof under each; which one plonky2 computes is printed here, so ONE run localises the convention.
+    let variants = v["digest_domain_separator_variants"].as_object().unwrap();
+    let default_mode = v["digest_domain_separator_default"].as_str().unwrap();
+    let mut matching: Option<&str> = None;
+    for (name, val) in variants {
+        let d: Vec<u64> = val["circuit_digest"].as_array().unwrap().iter().map(u).collect();
+        let hit = d == digest;
+        println!("   digest under digest_domain_separator = {:<10} {:?}  {}", name, d, if hit { "<== plonky2's" } else { "" });
+        if hit { matching = Some(name.as_str()); }
+    }
+    println!("=> constants_sigmas_cap[0] {}", if cap_ok { "MATCH" } else { "DIFFER (gate layout / selectors / sigma / k_is / FFT or Merkle conventions: see the lines above)" });
+    match matching {
+        Some(m) if m == default_mode => println!("=> circuit_digest MATCH (the shipped convention, {m})"),
+        Some(m) => println!("=> circuit_digest matches the ALTERNATIVE convention `{m}`: set CONVENTIONS[\"digest_domain_separator\"] = \"{m}\" in oracle/circuit.py and kDigestDomainSeparator in csrc/circuit_types.h, regenerate the goldens, re-run the suite"),
+        None if cap_ok => println!("=> circuit_digest matches NO listed alternative although the cap matches: the digest formula itself differs"),
+        None => println!("=> circuit_digest cannot match while the cap differs: fix the cap first"),
+    }
 
-    // ---- (2) this repository's proof through plonky2's verifier
-    let words: Vec<u64> = v["proof_words"].as_array().unwrap().iter().map(u).collect();
+    // ---- (2) this repository's proof through plonky2's verifier: the proof made under the convention that matched (the transcript
+    // starts with the digest, so a proof made under another convention cannot verify)
+    let proof_src = matching.map(|m| &variants[m]["proof_words"]).unwrap_or(&v["proof_words"]);
+    let words: Vec<u64> = proof_src.as_array().unwrap().iter().map(u).collect();
     let mut w = Words { w: &words, at: 0 };
     let cfg = &common.config;
     let fri = &common.fri_params;
@@ -101,7 +120,11 @@ fn main() -> Result<()> {
     };
     match data.verify(proof) {
         Ok(()) => println!("=> plonky2's verify ACCEPTS the proof produced by this repository: prover conventions confirmed"),
-        Err(e) => println!("=> plonky2's verify REJECTS the proof: {e:?} (compare step (1) first; then the transcript order / FRI layout)"),
+        // plonky2's verifier fails with distinct messages, which localise the remaining recalled conventions: "Invalid proof-of-work
+        // witness" => the PoW rule (csrc/circuit_types.h kPowRule lists the four sites); a vanishing-polynomial mismatch ("Mismatch
+        // between evaluation and opening of quotient polynomial") => gate wire layouts / constraint order / alpha powers; a Merkle
+        // proof error => leaf order, cap or digest layout; "Final polynomial evaluation is invalid" => FRI folding / arity / betas.
+        Err(e) => println!("=> plonky2's verify REJECTS the proof: {e:?}\n   (the message names the failing check: see the comment above this line in main.rs)"),
     }
     Ok(())
 }
