@@ -824,11 +824,12 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
            "verify_outer_ms": verify_ms, "public_inputs": [int(x) for x in final_proof[-4:]],
            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                         "note": "dependency chains (witness levels, transcript, Merkle levels), not bandwidth: per-kernel split in "
-                                "profiles/r02_prove_timeline_recursion.txt"}}
-    if getattr(args, "workload", "") == "recursion":
+                                "profiles/r03_prove_timeline_recursion.txt"}}
+    if getattr(args, "workload", "") in ("recursion", "mmr"):
         # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks per thread at B = 32; two threads so
-        # that one pass's one-workgroup witness interpreter overlaps the other's hashing)
-        out["throughput"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", "4", "2"])
+        # that one pass's one-workgroup witness interpreter overlaps the other's hashing).  A shorter probe in the default line.
+        secs = "4" if args.workload == "recursion" else "2"
+        out["throughput"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", secs, "2"])
         if "error" not in out["throughput"]:
             out["throughput"]["note"] = ("p2mt_batch_prover on the inner and on the outer circuit, two host threads; proofs "
                                          "bit-identical to the one-at-a-time path's; `value` above stays the single-proof latency")

@@ -109,8 +109,10 @@ __global__ __launch_bounds__(kBlock) void k_mmr_tile(const u64* __restrict__ lea
 // ONE inlined permutation.  Pending left siblings (at most one per height) live in a per-lane LDS stack; the control
 // flow is the binary-counter carry chain and is identical in all lanes.  A lane's 2^(LV+1)-1 nodes are a contiguous
 // post-order span, written node by node.  HBM traffic is the same algorithmic minimum as k_mmr_tile.
-template <unsigned LV, int BLK, int PR = 0>
-__global__ __launch_bounds__(BLK) void k_mmr_subtree(const u64* __restrict__ leaves, size_t leaf_base,
+// (the shipped instantiation asks for four waves per SIMD, i.e. <= 128 VGPRs: a shard of 2^22 / 2^23 leaves is 4 / 8 waves per SIMD
+// and ran as 3 + 1 / 3 + 3 + 2 at the three waves the allocator settles for on its own; at 2^24 it makes no difference)
+template <unsigned LV, int BLK, int PR = 0, int OCC = 1>
+__global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict__ leaves, size_t leaf_base,
                                                      u64* __restrict__ elements, size_t block0, size_t n_blocks,
                                                      PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
@@ -500,7 +502,24 @@ extern "C" int p2mt_mmr_flush(p2mt_mmr* m) {
 // lane per node otherwise
 constexpr size_t kWavePerNodeMax = (size_t)1 << 12;  // measured crossover vs the lane-per-node kernel: ~2^13 nodes
 constexpr size_t kMinTilesPerStage = 2048;
-constexpr size_t kQuadPerNodeMax = (size_t)1 << 16;   // four lanes per node: latency path for 2^12 < nodes <= 2^16           // a fused stage needs enough workgroups to fill 256 CUs
+// stage 1 at four waves per SIMD (<= 128 VGPRs, 28 bytes of scratch) instead of the three the allocator settles for on its own
+// (136 VGPRs); env P2MT_SUBTREE_OCC=3 selects the latter, for A/B
+static bool subtree_occ4() {
+  static const bool v = [] {
+    const char* e = getenv("P2MT_SUBTREE_OCC");
+    return e ? atoi(e) == 4 : true;
+  }();
+  return v;
+}
+// four lanes per node: the latency path for 2^12 < nodes <= 2^kQuadLog.  (env P2MT_QUAD_MAX_LOG overrides, for A/B.)
+static size_t quad_per_node_max() {
+  static const size_t v = [] {
+    const char* e = getenv("P2MT_QUAD_MAX_LOG");
+    const int lg = e ? atoi(e) : 16;
+    return (size_t)1 << (lg >= 12 && lg <= 24 ? lg : 16);
+  }();
+  return v;
+}
 
 static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
   if (j1 <= j0) return P2MT_OK;
@@ -512,7 +531,7 @@ static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
-  if (cnt <= kQuadPerNodeMax && rt().mds == 2 && rt().use_quad) {
+  if (cnt <= quad_per_node_max() && rt().mds == 2 && rt().use_quad) {
     hipLaunchKernelGGL(k_mmr_level_quad, dim3(grid_for(4 * cnt)), dim3(kBlock), 0, rt().stream, m->elements, h, j0, j1,
                        p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
@@ -583,7 +602,12 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       else if (rt().partial == 2 && sb == 256) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
       else if (rt().partial == 3 && sb == 256) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
       else if (rt().partial == 1 && sb == 256) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
-      else { if (sb == 64) P2MT_SUB(4, 64, 0); else if (sb == 128) P2MT_SUB(4, 128, 0); else P2MT_SUB(4, 256, 0); }
+      else if (sb == 64) P2MT_SUB(4, 64, 0);
+      else if (sb == 128) P2MT_SUB(4, 128, 0);
+      else if (subtree_occ4()) {
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 0, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
+                           p2mt::perm_ctx());
+      } else P2MT_SUB(4, 256, 0);
 #undef P2MT_SUB
       P2MT_LAUNCH_CHECK();
       p2mt::prof_end(prof_slot);
@@ -864,19 +888,23 @@ extern "C" int p2mt_mmr_proof_batch(const p2mt_mmr* m, const uint64_t* mmr_indic
   if (count == 0) return P2MT_OK;
   if (!mmr_indices || !siblings_out || !lefts_out || !n_siblings_out || max_siblings == 0)
     return p2mt::fail(P2MT_EINVAL, "null pointer");
-  DevBuf bi, bs, bl, bn;
-  P2MT_TRY(bi.alloc(count * 8));
-  P2MT_TRY(bs.alloc(count * max_siblings * 32));
-  P2MT_TRY(bl.alloc(count * max_siblings));
-  P2MT_TRY(bn.alloc(count * 4));
+  // staging comes from the thread's grow-only scratch (one carve-up): a hipMalloc / hipFree pair per buffer cost more than the
+  // whole call for the reference's one-proof-at-a-time use (config 2: four proofs took 5 ms)
+  const size_t o_idx = 0, o_sib = (count * 8 + 255) & ~(size_t)255, o_left = o_sib + ((count * max_siblings * 32 + 255) & ~(size_t)255);
+  const size_t o_n = o_left + ((count * max_siblings + 255) & ~(size_t)255), total = o_n + count * 4;
+  char* base = nullptr;
+  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchPing, total, (void**)&base));
+  u64* d_idx = reinterpret_cast<u64*>(base + o_idx);
+  u64* d_sib = reinterpret_cast<u64*>(base + o_sib);
+  uint8_t* d_left = reinterpret_cast<uint8_t*>(base + o_left);
+  int32_t* d_n = reinterpret_cast<int32_t*>(base + o_n);
   hipStream_t st = rt().stream;
-  P2MT_HIP(hipMemcpyAsync(bi.p, mmr_indices, count * 8, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemsetAsync(bs.p, 0, count * max_siblings * 32, st));
-  P2MT_HIP(hipMemsetAsync(bl.p, 0, count * max_siblings, st));
-  P2MT_TRY(p2mt_mmr_proof_batch_dev(m, bi.as<u64>(), count, max_siblings, bs.as<u64>(), bl.as<uint8_t>(), bn.as<int32_t>()));
-  P2MT_HIP(hipMemcpyAsync(siblings_out, bs.p, count * max_siblings * 32, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipMemcpyAsync(lefts_out, bl.p, count * max_siblings, hipMemcpyDeviceToHost, st));
-  P2MT_HIP(hipMemcpyAsync(n_siblings_out, bn.p, count * 4, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(d_idx, mmr_indices, count * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemsetAsync(base + o_sib, 0, o_n - o_sib, st));
+  P2MT_TRY(p2mt_mmr_proof_batch_dev(m, d_idx, count, max_siblings, d_sib, d_left, d_n));
+  P2MT_HIP(hipMemcpyAsync(siblings_out, d_sib, count * max_siblings * 32, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(lefts_out, d_left, count * max_siblings, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(n_siblings_out, d_n, count * 4, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   for (size_t i = 0; i < count; ++i) {
     if (n_siblings_out[i] < 0) return p2mt::fail(P2MT_EINVAL, "get_proof: mmr_index out of bounds");
@@ -933,27 +961,26 @@ extern "C" int p2mt_mmr_proof_verify_batch(const uint64_t* siblings, const uint8
   if (max_siblings && (!siblings || !lefts)) return p2mt::fail(P2MT_EINVAL, "null pointer");
   for (size_t i = 0; i < m; ++i)
     if (n_siblings[i] < 0 || (size_t)n_siblings[i] > max_siblings) return p2mt::fail(P2MT_EINVAL, "n_siblings out of range");
-  DevBuf bs, bl, bn, bp, bv, br, bo;
   const size_t ms = max_siblings ? max_siblings : 1;
-  P2MT_TRY(bs.alloc(m * ms * 32));
-  P2MT_TRY(bl.alloc(m * ms));
-  P2MT_TRY(bn.alloc(m * 4));
-  P2MT_TRY(bp.alloc((size_t)n_peaks * 32));
-  P2MT_TRY(bv.alloc(m * 8));
-  P2MT_TRY(br.alloc(32));
-  P2MT_TRY(bo.alloc(m));
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_sib = 0, o_left = up(m * ms * 32), o_n = o_left + up(m * ms), o_peaks = o_n + up(m * 4);
+  const size_t o_leaf = o_peaks + up((size_t)n_peaks * 32), o_root = o_leaf + up(m * 8), o_out = o_root + 256, total = o_out + up(m);
+  char* base = nullptr;  // the thread's grow-only scratch instead of seven hipMalloc / hipFree pairs per call
+  P2MT_TRY(p2mt::scratch_get(p2mt::kScratchPing, total, (void**)&base));
   hipStream_t st = rt().stream;
   if (max_siblings) {
-    P2MT_HIP(hipMemcpyAsync(bs.p, siblings, m * ms * 32, hipMemcpyHostToDevice, st));
-    P2MT_HIP(hipMemcpyAsync(bl.p, lefts, m * ms, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(base + o_sib, siblings, m * ms * 32, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(base + o_left, lefts, m * ms, hipMemcpyHostToDevice, st));
   }
-  P2MT_HIP(hipMemcpyAsync(bn.p, n_siblings, m * 4, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(bp.p, peaks, (size_t)n_peaks * 32, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(bv.p, leaves, m * 8, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(br.p, root, 32, hipMemcpyHostToDevice, st));
-  P2MT_TRY(p2mt_mmr_proof_verify_batch_dev(bs.as<u64>(), bl.as<uint8_t>(), bn.as<int32_t>(), max_siblings, bp.as<u64>(),
-                                           n_peaks, bv.as<u64>(), br.as<u64>(), m, bo.as<int8_t>()));
-  P2MT_HIP(hipMemcpyAsync(status_out, bo.p, m, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(base + o_n, n_siblings, m * 4, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(base + o_peaks, peaks, (size_t)n_peaks * 32, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(base + o_leaf, leaves, m * 8, hipMemcpyHostToDevice, st));
+  P2MT_HIP(hipMemcpyAsync(base + o_root, root, 32, hipMemcpyHostToDevice, st));
+  P2MT_TRY(p2mt_mmr_proof_verify_batch_dev(reinterpret_cast<u64*>(base + o_sib), reinterpret_cast<uint8_t*>(base + o_left),
+                                           reinterpret_cast<int32_t*>(base + o_n), max_siblings, reinterpret_cast<u64*>(base + o_peaks),
+                                           n_peaks, reinterpret_cast<u64*>(base + o_leaf), reinterpret_cast<u64*>(base + o_root), m,
+                                           reinterpret_cast<int8_t*>(base + o_out)));
+  P2MT_HIP(hipMemcpyAsync(status_out, base + o_out, m, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   return P2MT_OK;
   });
