@@ -300,7 +300,7 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
         return None
     mds, partial = C.c_int(), C.c_int()
     lib.p2mt_get_variant(C.byref(mds), C.byref(partial))
-    info = pkg.stage1_info()
+    info = pkg.stage1_info(n)
     fused_levels = info["levels"]
     # (hashes are split evenly over the stage-1 launches of a step)
     launches_per_step = max(kern_n.value, 1) / float(args.steps)

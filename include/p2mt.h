@@ -72,6 +72,11 @@ int p2mt_get_variant(int *mds, int *partial);
  * builds levels 1..subtree_levels of its own leaves), 0 -> k_mmr_tile over 2^tile_log-leaf tiles.  (bench.py labels its roofline
  * with it.) */
 int p2mt_get_build_config(int *subtree_levels, int *tile_log, int *subtree_block);
+/* Levels the stage-1 launch of a build of n_leaves (from an empty MMR) fuses: with per-lane subtrees (the default) the subtree size
+ * adapts to the build -- 2^4 leaves per lane from 2^22 leaves up, 2^3 / 2^2 for smaller builds, so that the launch still puts ~4
+ * wavefronts on every SIMD (a 2^21-leaf shard of an 8-GPU strong-scaling run is otherwise two wavefronts per SIMD running 15
+ * dependent hashes each) -- unless the environment pins it (P2MT_SUBTREE=2|3|4|5).  0 = fused tiles. */
+int p2mt_mmr_stage1_levels(size_t n_leaves);
 /* Debug/test knob: make every wave of the mds=2 path take its exact fallback (results must not change). */
 int p2mt_debug_force_fallback(int on);
 /* Test hook: the next `n` device allocations made while growing an MMR handle report P2MT_ENOMEM (fault injection: a failed

@@ -35,14 +35,16 @@ def device_count():
     return lib().p2mt_device_count()
 
 
-def stage1_info():
-    """The dominant launch of an MMR build under the current variant / environment knobs (for bench.py's roofline label)."""
+def stage1_info(n_leaves=1 << 24):
+    """The dominant launch of a build of n_leaves under the current variant / environment knobs (for bench.py's roofline label):
+    per-lane subtrees whose size adapts to the build (p2mt_mmr_stage1_levels), or fused tiles."""
     import ctypes as C
     sub, tile, blk = C.c_int(), C.c_int(), C.c_int()
     _native.check(lib().p2mt_get_build_config(C.byref(sub), C.byref(tile), C.byref(blk)))
-    if sub.value in (4, 5):
-        return {"key": "subtree%d" % sub.value, "levels": sub.value,
-                "kernel": "k_mmr_subtree (stage 1: each lane builds levels 1..%d of its own 2^%d leaves)" % (sub.value, sub.value)}
+    if sub.value:
+        lv = int(lib().p2mt_mmr_stage1_levels(n_leaves))
+        return {"key": "subtree%d" % lv, "levels": lv,
+                "kernel": "k_mmr_subtree (stage 1: each lane builds levels 1..%d of its own 2^%d leaves)" % (lv, lv)}
     lv = tile.value - 6
     return {"key": "tile%d" % tile.value, "levels": lv,
             "kernel": "k_mmr_tile (stage 1: levels 1..%d of every 2^%d-leaf tile)" % (lv, tile.value)}

@@ -35,6 +35,7 @@ SIGNATURES = {
     "p2mt_set_variant": (C.c_int, [C.c_int, C.c_int]),
     "p2mt_get_variant": (C.c_int, [intp, intp]),
     "p2mt_get_build_config": (C.c_int, [intp, intp, intp]),
+    "p2mt_mmr_stage1_levels": (C.c_int, [C.c_size_t]),
     "p2mt_debug_force_fallback": (C.c_int, [C.c_int]),
     "p2mt_debug_fail_allocs": (C.c_int, [C.c_int]),
     "p2mt_debug_field_op": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp, voidp]),

@@ -558,7 +558,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
     // levels this stage would fuse: stage 1 stops while every level fills whole waves; later stages also stop where
     // the quad/wave-per-node kernels take over
     unsigned n_lev = 0;
-    const unsigned sub_lv = (h0 == 0 && rt().mds == 2) ? rt().subtree_levels : 0;  // per-lane subtree stage 1
+    const unsigned sub_lv = (h0 == 0 && rt().mds == 2) ? p2mt::subtree_levels_for(n1 - n0) : 0;  // per-lane subtree stage 1
     if (h0 == 0) {
       n_lev = sub_lv ? sub_lv : kTileLog - 6;  // last fused level still has 64 nodes per tile
     } else {
@@ -598,10 +598,21 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
 #define P2MT_SUB(LVV, BB, PRR) \
   hipLaunchKernelGGL((k_mmr_subtree<LVV, BB, PRR>), dim3(sgrid), dim3(BB), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks, \
                      p2mt::perm_ctx())
+      // every branch launches the instantiation whose subtree size IS sub_lv (a mismatch would write out of bounds); the A/B
+      // variants exist for 2^4-leaf subtrees in 256-lane workgroups only, and subtree_levels_for() never asks for anything else
+      // while one of them is selected
+      const int variant = (sub_lv == 4 && sb == 256) ? rt().partial : 0;
       if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
-      else if (rt().partial == 2 && sb == 256) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
-      else if (rt().partial == 3 && sb == 256) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
-      else if (rt().partial == 1 && sb == 256) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
+      else if (sub_lv == 3) {
+        hipLaunchKernelGGL((k_mmr_subtree<3, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
+                           m->elements, block0, n_blocks, p2mt::perm_ctx());
+      } else if (sub_lv == 2) {
+        hipLaunchKernelGGL((k_mmr_subtree<2, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
+                           m->elements, block0, n_blocks, p2mt::perm_ctx());
+      } else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
+      else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
+      else if (variant == 3) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
+      else if (variant == 1) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
       else if (sb == 64) P2MT_SUB(4, 64, 0);
       else if (sb == 128) P2MT_SUB(4, 128, 0);
       else if (subtree_occ4()) {

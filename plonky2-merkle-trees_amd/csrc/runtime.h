@@ -38,7 +38,8 @@ struct Runtime {
   int force_fallback = 0;
   int use_quad = 1;          // four-lanes-per-hash kernels for 2^12 < items <= 2^16 (env P2MT_QUAD=0 disables)
   unsigned subtree_block = 256; // workgroup size of the per-lane subtree kernel (env P2MT_SUBTREE_BLOCK=64|128|256)
-  unsigned subtree_levels = 4;  // stage 1 as per-lane subtrees of 2^4 / 2^5 leaves (env P2MT_SUBTREE=4|5); 0 = fused tiles
+  unsigned subtree_levels = 4;  // stage 1 as per-lane subtrees of 2^L leaves (env P2MT_SUBTREE=2|3|4|5 pins L); 0 = fused tiles
+  bool subtree_auto = true;     // no P2MT_SUBTREE in the environment: L adapts to the size of the build (subtree_levels_for)
   int throughput = 0;        // p2mt_set_throughput_mode: prefer lane-efficient layouts over the latency-optimised ones
   int use_lde12 = 1;         // register-blocked 2^12 LDE kernel (env P2MT_LDE12=0 selects the generic radix-2 one)
   unsigned tile_log = 10;    // fused MMR stage: 2^tile_log inputs per workgroup (env P2MT_TILE_LOG = 9|10|11)
@@ -56,6 +57,9 @@ Runtime& rt();
 int fail_hip(hipError_t e, const char* what, const char* file, int line);
 int fail(int code, const char* msg);
 int ensure_init();
+// per-lane subtree size (log2 leaves) of the stage-1 launch over n_leaves leaves: the largest L in 2..4 that still gives every SIMD
+// of the chip ~4 wavefronts (n_leaves / 2^L lanes >= 4 x 1024 SIMDs x 64), the pinned value when the environment sets one
+unsigned subtree_levels_for(size_t n_leaves);
 // No exception crosses the C ABI: every `extern "C" int` body runs inside this guard.  std::bad_alloc (a std::vector
 // growing inside the builder, the batch prover's staging, a worker pool) becomes P2MT_ENOMEM, anything else P2MT_EINVAL with its
 // what() as the message.

@@ -184,6 +184,16 @@ void prof_end(int slot) {
   if (slot >= 0) (void)hipEventRecord(rt().prof_ev[2 * slot + 1], rt().stream);
 }
 
+unsigned subtree_levels_for(size_t n_leaves) {
+  const Runtime& r = rt();
+  if (!r.subtree_auto || r.subtree_levels == 0) return r.subtree_levels;
+  // the A/B instantiations (sparse partial rounds, matrix-pipe MDS, 64- / 128-lane workgroups) exist for 2^4-leaf subtrees only
+  if (r.partial != 0 || r.subtree_block != 256) return 4;
+  unsigned lv = 4;
+  while (lv > 2 && (n_leaves >> lv) < ((size_t)4 * 1024 * 64)) --lv;
+  return lv;
+}
+
 int ensure_init() {
   if (rt().initialised) return P2MT_OK;  // (set last, under the lock, by p2mt_init)
   return p2mt_init(rt().device);
@@ -268,7 +278,11 @@ extern "C" int p2mt_init(int device) {
   }
   if (const char* e = getenv("P2MT_SUBTREE")) {
     const int v = atoi(e);
-    rt().subtree_levels = (v == 4 || v == 5) ? (unsigned)v : 0;
+    rt().subtree_levels = (v >= 2 && v <= 5) ? (unsigned)v : 0;
+    rt().subtree_auto = false;
+  }
+  if ((rt().subtree_levels == 2 || rt().subtree_levels == 3) && rt().subtree_block != 256) {
+    rt().subtree_block = 256;  // the small subtrees are instantiated for 256-lane workgroups only
   }
   rt().initialised = true;
   return P2MT_OK;
@@ -346,6 +360,13 @@ extern "C" int p2mt_get_variant(int* mds, int* partial) {
   if (partial) *partial = rt().partial;
   return P2MT_OK;
   });
+}
+
+extern "C" int p2mt_mmr_stage1_levels(size_t n_leaves) {
+  if (p2mt::ensure_init() != P2MT_OK) return 0;
+  if (rt().mds != 2) return (int)rt().tile_log - 6;
+  const unsigned lv = p2mt::subtree_levels_for(n_leaves);
+  return lv ? (int)lv : (int)rt().tile_log - 6;
 }
 
 extern "C" int p2mt_get_build_config(int* subtree_levels, int* tile_log, int* subtree_block) {

@@ -294,6 +294,29 @@ def test_mfma_mds_variant(pkg, oracle):
         pkg.set_variant(*DEFAULT_VARIANT)
 
 
+@pytest.mark.parametrize("log_n,levels", [(18, 2), (20, 2), (21, 3), (22, 4)])
+def test_adaptive_subtree_size(pkg, oracle, log_n, levels):
+    """Round 3: the per-lane subtrees of the stage-1 launch shrink with the build (2^4 leaves per lane from 2^22 leaves up, 2^3 /
+    2^2 below, so that a small shard still puts ~4 wavefronts on every SIMD).  Every size class, full node array against the
+    oracle's level-order build, plus a ragged size in the same class."""
+    import hashlib
+    import torch
+    n = 1 << log_n
+    assert pkg.lib().p2mt_mmr_stage1_levels(n) == levels
+    leaves = splitmix_leaves(n + 77, 0x5EED0400 + log_n)
+    d = torch.from_numpy(leaves.view(np.int64)).cuda()
+    m = pkg.MMR()
+    m.extend_dev(d, n)
+    el, _ = oracle.mmr_build_pow2_parallel(leaves[:n], 8)
+    assert hashlib.sha256(m.elements.tobytes()).hexdigest() == hashlib.sha256(el.tobytes()).hexdigest()
+    m.extend_dev(d[n:], 77)                       # a ragged continuation on top (incremental extend, tiny subtrees)
+    r = pkg.MMR()
+    r.extend_dev(d, n + 77)                       # and the same leaves in one ragged build
+    assert np.array_equal(m.elements, r.elements)
+    if log_n <= 20:
+        assert np.array_equal(r.elements, oracle.mmr(leaves).elements)
+
+
 def test_mmr_checkpoint_roundtrip(pkg, oracle, tmp_path):
     """save -> load -> extend continues exactly where the saved MMR stopped; corrupted files are rejected."""
     leaves = splitmix_leaves(3000, 0x5EED0099)
@@ -610,6 +633,10 @@ def test_device_resident_proof_service(pkg, oracle):
     {"P2MT_SUBTREE": "0", "P2MT_TILE_LOG": "9"},
     {"P2MT_SUBTREE": "0", "P2MT_TILE_LOG": "11"},
     {"P2MT_SUBTREE": "5"},                              # 32-leaf per-lane subtrees
+    {"P2MT_SUBTREE": "4"},                              # 16-leaf subtrees pinned (the default adapts the size to the build)
+    {"P2MT_SUBTREE": "3"},
+    {"P2MT_SUBTREE": "2", "P2MT_SUBTREE_BLOCK": "64"},  # (small subtrees exist for 256-lane workgroups: the block knob yields)
+    {"P2MT_SUBTREE_OCC": "3"},                          # stage 1 at the allocator's own three waves per SIMD
     {"P2MT_SUBTREE_BLOCK": "64"},
     {"P2MT_SUBTREE_BLOCK": "128"},
     {"P2MT_QUAD": "0", "P2MT_LDE12": "0"},              # no four-lane kernels, radix-2 LDE at 2^12
