@@ -117,7 +117,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
                                                      PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
   poseidon_fast::MfmaCtx mc;  // PR >= 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
-  if constexpr (PR >= 2) mc = poseidon_fast::mfma_ctx_init();
+  if constexpr (PR == 2 || PR == 3) mc = poseidon_fast::mfma_ctx_init();
   const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
   if (blk >= block0 + n_blocks) return;
   const size_t first_leaf = blk << LV;
@@ -613,6 +613,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
       else if (variant == 3) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
       else if (variant == 1) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
+      else if (variant == 4) P2MT_SUB(4, 256, 4);  // one MDS layer per partial round, round 2's form (A/B: p2mt_set_variant(2, 4))
       else if (sb == 64) P2MT_SUB(4, 64, 0);
       else if (sb == 128) P2MT_SUB(4, 128, 0);
       else if (subtree_occ4()) {

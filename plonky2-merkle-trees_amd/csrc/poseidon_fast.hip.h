@@ -319,6 +319,11 @@ constexpr int kSpV = 404;                      // 22 x 11: FAST_PARTIAL_ROUND_VS
 constexpr int kSpW = 646;                      // 22 x 11 x {limb0, limb1, limb2, 0} as u32: FAST_PARTIAL_ROUND_W_HATS
 constexpr int kSpInit = kSpW + 22 * 11 * 2;    // 11 x 11 x {limb0, limb1, limb2, 0}: FAST_PARTIAL_ROUND_INITIAL_MATRIX
 constexpr int kSpTableWords = kSpInit + 121 * 2;
+// behind those: the tables of the batched partial rounds (partial_rounds3 below; runtime.hip builds them)
+constexpr int kP3Tab = kSpTableWords;          // u32[168]: M^3 row-major [0, 144), row 0 of M^2 [144, 156), (M m0)[r] [156, 168)
+constexpr int kP3K = kP3Tab + 84;              // per group of three rounds 14 u64: c1[0], K2, K3[0..12)
+constexpr int kP3Groups = 7;                   // rounds 4..24 in threes; round 25 stays a single dense round
+constexpr int kTableWords = kP3K + 14 * kP3Groups;
 
 struct Dot {
   u64 a0l, a0h, a1l, a1h, a2l, a2h;
@@ -358,6 +363,101 @@ GL_DEV u64 mul_add_flag(u64 x, u64 k, u64 c, u64& sticky) {
   return reduce128(l, hi, sticky);
 }
 
+// ------------------------------------------------------------------ three partial rounds per MDS application (round 3)
+// In a partial round only word 0 goes through the S-box: with y = the state after that S-box, c1, c2, c3 the next three rounds'
+// constant vectors, m0 the first column of M and d1, d2 = S(x) - x of the two later rounds' word 0,
+//     v1 = M y + c1
+//     v2 = M v1 + d1 m0 + c2 = M^2 y + d1 m0 + (M c1 + c2)
+//     v3 = M v2 + d2 m0 + c3 = M^3 y + d1 (M m0) + d2 m0 + (M^2 c1 + M c2 + c3).
+// The two intermediate S-box inputs need only ROW 0 of M y and of M^2 y, and the entries of M^2 / M^3 are still small integers
+// (row sums 2^16 / 2^24, M's are 2^8), so a term of a row stays ONE v_mad_u64_u32 per 32-bit half and the accumulators stay below
+// 2^58.  Three rounds then cost 2 x 24 + 12 x 28 mads instead of 3 x 288: the one-hash-per-lane layout spends 58 % of its
+// instructions in MDS layers, two thirds of them in the partial rounds.  (plonky2's own "fast" partial rounds trade the MDS for ~22
+// full 64 x 64 multiplications per round -- right for a CPU, measured 2.3 % slower here, profiles/r02_sparse_flag_form_ab.txt.)
+// Folds are the exact form: the top word of a row reaches 2^26 here, too often for the flag.
+GL_DEV u64 sub_any(u64 a, u64 b) {  // a - b mod p for any u64 a, b; loose result
+  u64 d = a - b;
+  if (a < b) {  // wrapped by +2^64 == +EPS (mod p): take it back; a second time if that wraps too (d < EPS: b within 2^32 of 2^64)
+    const bool again = d < gl::EPS;
+    d -= gl::EPS;
+    if (again) d -= gl::EPS;
+  }
+  return d;
+}
+// acc += a * k, k wave-uniform (SGPR)
+GL_DEV void mac_s(u64& acc, u32 a, u32 k) {
+  u64 unused;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "s"(k));
+}
+template <typename Sbox>
+GL_DEV void partial_rounds3(u64 (&s)[12], const u64* __restrict__ rc, int g, Sbox&& sbox) {
+  const u32* T = reinterpret_cast<const u32*>(rc + kP3Tab);
+  // (opaque to the optimiser: the 168 table words are the same for every group, and hoisted out of the loop they would sit in
+  // SGPRs spilled to VGPR lanes -- 274 v_readlane per group; read where they are used they are plain scalar loads)
+  asm volatile("" : "+s"(T));
+  const u64* __restrict__ K = rc + kP3K + 14 * g;
+  auto finish = [](u64 al, u64 ah) -> u64 {  // (al + ah 2^32) mod p, loose; al, ah < 2^58
+    ah = add32((u32)(al >> 32), ah);
+    return exact::fold96((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al);
+  };
+  s[0] = sbox(s[0]);
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  // v1[0] = row 0 of M y + c1[0]
+  u64 x1;
+  {
+    const u64 c = K[0];
+    constexpr u32 k0 = poseidon::mds_entry(0, 0);
+    u64 al = mac_const_first<k0>(lo[0], (u64)(u32)c), ah = mac_const_first<k0>(hi[0], (u64)(u32)(c >> 32));
+    poseidon::static_for<1, 12>([&](auto cc) {
+      constexpr int c2 = decltype(cc)::value;
+      constexpr u32 k = poseidon::mds_entry(0, c2);
+      mac_const<k>(al, lo[c2]);
+      mac_const<k>(ah, hi[c2]);
+    });
+    x1 = finish(al, ah);
+  }
+  const u64 d1 = sub_any(sbox(x1), x1);
+  const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
+  // v2[0] = row 0 of M^2 y + d1 m0[0] + K2
+  u64 x2;
+  {
+    const u64 c = K[1];
+    constexpr u32 m00 = poseidon::mds_entry(0, 0);
+    u64 al = mac_const_first<m00>(d1l, (u64)(u32)c), ah = mac_const_first<m00>(d1h, (u64)(u32)(c >> 32));
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const u32 k = T[144 + j];
+      mac_s(al, lo[j], k);
+      mac_s(ah, hi[j], k);
+    }
+    x2 = finish(al, ah);
+  }
+  const u64 d2 = sub_any(sbox(x2), x2);
+  const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+  // v3 = M^3 y + d1 (M m0) + d2 m0 + K3
+  poseidon::static_for<0, 12>([&](auto rcst) {
+    constexpr int r = decltype(rcst)::value;
+    constexpr u32 m0r = poseidon::mds_entry(r, 0);
+    const u64 c = K[2 + r];
+    u64 al = mac_const_first<m0r>(d2l, (u64)(u32)c), ah = mac_const_first<m0r>(d2h, (u64)(u32)(c >> 32));
+    const u32 km = T[156 + r];
+    mac_s(al, d1l, km);
+    mac_s(ah, d1h, km);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const u32 k = T[12 * r + j];
+      mac_s(al, lo[j], k);
+      mac_s(ah, hi[j], k);
+    }
+    s[r] = finish(al, ah);
+  });
+}
+
 // Input: any u64 words.  Output: loose u64 words, valid iff the returned sticky mask is 0 for the whole wave.
 // `rc`: the 360 round constants in GLOBAL memory (kernel argument: base + immediate offsets let the compiler
 // fetch a whole round with wide s_load_dwordx8/x16; the __constant__ symbol would cost a PC-relative address
@@ -373,8 +473,11 @@ GL_DEV u64 mul_add_flag(u64 x, u64 k, u64 c, u64& sticky) {
 // SPARSE: the 22 partial rounds in the sparse form above (same function; the dense form is the default and the redo path).
 // MFMA: 1 = every dense MDS layer on the matrix pipe, 2 = only those of the 22 partial rounds (mds_layer_mfma; `mc` from
 //   mfma_ctx_init(), made while every lane of the wave was still active).  Same function, same flag semantics.
-template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0>
+// P3: the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round.
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0)>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
+  static_assert(!P3 || (!EXACT && !SPARSE && MFMA == 0), "partial_rounds3 belongs to the dense flag form");
   u64 sticky = 0;
   static_assert(!(MFMA && (EXACT || SPARSE)), "the matrix-pipe MDS exists in the flag form with dense partial rounds only");
   auto mds4 = [&](auto add_tag, auto rows_tag, const u64* add, auto in_partial_round) {
@@ -466,6 +569,15 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc =
     // the constants of the first full round of the second half (the dense form folds them into the previous MDS layer)
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[12 * (POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS) + i]);
+  } else if constexpr (P3) {
+    static_assert(POSEIDON_PARTIAL_ROUNDS == 3 * kP3Groups + 1, "7 groups of three + one round");
+#pragma unroll 1
+    for (int g = 0; g < kP3Groups; ++g) partial_rounds3(s, rc, g, sbox);
+    {
+      constexpr int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS - 1;
+      s[0] = sbox(s[0]);
+      mds4(T{}, R12{}, rc + 12 * (r + 1), T{});
+    }
   } else {
 #pragma unroll 1
     for (int r = POSEIDON_HALF_FULL_ROUNDS; r < POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS; ++r) {

@@ -242,8 +242,10 @@ extern "C" int p2mt_init(int device) {
      // capacity of two_to_one), [364..367) words 1..3 and [367..370) words 5..7 (two_to_one of two leaf digests [leaf, 0, 0, 0])
     // behind them the tables of the sparse partial rounds (poseidon_fast.hip.h kSp*: FIRST, K, V, then W_HAT and INIT as limbs of
     // 22 + 22 + 20 bits in four u32 per constant)
-    static uint64_t table[1372];
-    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2, "layout of poseidon_fast.hip.h");
+    // and the tables of the batched partial rounds (poseidon_fast.hip.h kP3Tab / kP3K): M^3, row 0 of M^2, M m0 as u32; per
+    // group of three rounds the constants c1[0], (M c1 + c2)[0] and M^2 c1 + M c2 + c3 (mod p)
+    static uint64_t table[1372 + 84 + 14 * 7];
+    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 + 98, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
     memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
     memcpy(table + 382, POSEIDON_FAST_K, sizeof(POSEIDON_FAST_K));
@@ -255,6 +257,50 @@ extern "C" int p2mt_init(int device) {
       };
       for (int i = 0; i < 242; ++i) limbs(POSEIDON_FAST_W_HAT[i], w + 4 * i);
       for (int i = 0; i < 121; ++i) limbs(POSEIDON_FAST_INIT[i], w + 4 * (242 + i));
+    }
+    {
+      typedef unsigned __int128 u128;
+      const u128 p = 0xFFFFFFFF00000001ULL;
+      const uint64_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+      uint64_t M[12][12], M2[12][12], M3[12][12];
+      for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) M[r][c] = circ[((c - r) % 12 + 12) % 12] + ((r == 0 && c == 0) ? 8 : 0);
+      for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) {
+          uint64_t a = 0;
+          for (int k = 0; k < 12; ++k) a += M[r][k] * M[k][c];
+          M2[r][c] = a;
+        }
+      for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) {
+          uint64_t a = 0;
+          for (int k = 0; k < 12; ++k) a += M2[r][k] * M[k][c];
+          M3[r][c] = a;  // < 2^25: every term of a row is one 32 x 32 multiply
+        }
+      uint32_t* t = reinterpret_cast<uint32_t*>(table + 1372);
+      for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) t[12 * r + c] = (uint32_t)M3[r][c];
+      for (int c = 0; c < 12; ++c) t[144 + c] = (uint32_t)M2[0][c];
+      for (int r = 0; r < 12; ++r) t[156 + r] = (uint32_t)M2[r][0];  // (M m0)[r] = sum_k M[r][k] M[k][0] = M^2[r][0]
+      auto matvec = [&](const uint64_t (&A)[12][12], const uint64_t* v, uint64_t* out) {
+        for (int r = 0; r < 12; ++r) {
+          u128 a = 0;
+          for (int c = 0; c < 12; ++c) a = (a + (u128)A[r][c] * v[c]) % p;
+          out[r] = (uint64_t)a;
+        }
+      };
+      for (int g = 0; g < 7; ++g) {
+        const int r0 = 4 + 3 * g;  // the group's first round; c1, c2, c3 = the constants of rounds r0+1, r0+2, r0+3
+        const uint64_t *c1 = POSEIDON_RC + 12 * (r0 + 1), *c2 = POSEIDON_RC + 12 * (r0 + 2), *c3 = POSEIDON_RC + 12 * (r0 + 3);
+        uint64_t mc1[12], m2c1[12], mc2[12];
+        matvec(M, c1, mc1);
+        matvec(M2, c1, m2c1);
+        matvec(M, c2, mc2);
+        uint64_t* k = table + 1372 + 84 + 14 * g;
+        k[0] = c1[0];
+        k[1] = (uint64_t)(((u128)mc1[0] + c2[0]) % p);
+        for (int r = 0; r < 12; ++r) k[2 + r] = (uint64_t)(((u128)m2c1[r] + mc2[r] + c3[r]) % p);
+      }
     }
     const int word_of[10] = {8, 9, 10, 11, 1, 2, 3, 5, 6, 7};
     for (int i = 0; i < 10; ++i) {
@@ -339,8 +385,9 @@ extern "C" const char* p2mt_last_error(void) { return p2mt::err_buf(); }
 
 extern "C" int p2mt_set_variant(int mds, int partial) {
   return p2mt::abi_guard([&]() -> int {
-  // partial: 0 dense, 1 sparse partial rounds; 2 / 3 (with mds == 2 only) = dense with all / only the partial rounds' MDS layers on the matrix pipe (stage-1 A/B)
-  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 3 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  // partial: 0 dense, 1 sparse partial rounds; 2 / 3 (with mds == 2 only) = dense with all / only the partial rounds' MDS layers on the matrix pipe, 4 = one MDS
+  // layer per partial round (round 2's form; the default batches three partial rounds per MDS application) -- stage-1 A/B
+  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 4 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
   return P2MT_OK;
