@@ -320,9 +320,9 @@ constexpr int kSpW = 646;                      // 22 x 11 x {limb0, limb1, limb2
 constexpr int kSpInit = kSpW + 22 * 11 * 2;    // 11 x 11 x {limb0, limb1, limb2, 0}: FAST_PARTIAL_ROUND_INITIAL_MATRIX
 constexpr int kSpTableWords = kSpInit + 121 * 2;
 // behind those: the tables of the batched partial rounds (partial_rounds3 below; runtime.hip builds them)
-constexpr int kP3Tab = kSpTableWords;          // u32[168]: M^3 row-major [0, 144), row 0 of M^2 [144, 156), (M m0)[r] [156, 168)
-constexpr int kP3K = kP3Tab + 84;              // per group of three rounds 14 u64: c1[0], K2, K3[0..12)
 constexpr int kP3Groups = 7;                   // rounds 4..24 in threes; round 25 stays a single dense round
+constexpr int kP3Tab = kSpTableWords;          // per group a copy of u32[168]: M^3 row-major [0, 144), row 0 of M^2 [144, 156), (M m0)[r] [156, 168)
+constexpr int kP3K = kP3Tab + 84 * kP3Groups;  // per group of three rounds 14 u64: c1[0], K2, K3[0..12)
 constexpr int kTableWords = kP3K + 14 * kP3Groups;
 
 struct Dot {
@@ -391,10 +391,10 @@ GL_DEV void mac_s(u64& acc, u32 a, u32 k) {
 }
 template <typename Sbox>
 GL_DEV void partial_rounds3(u64 (&s)[12], const u64* __restrict__ rc, int g, Sbox&& sbox) {
-  const u32* T = reinterpret_cast<const u32*>(rc + kP3Tab);
-  // (opaque to the optimiser: the 168 table words are the same for every group, and hoisted out of the loop they would sit in
-  // SGPRs spilled to VGPR lanes -- 274 v_readlane per group; read where they are used they are plain scalar loads)
-  asm volatile("" : "+s"(T));
+  // The 168 matrix words are the same for every group, but each group reads ITS OWN copy of them: hoisted out of the loop they
+  // would sit in SGPRs spilled to VGPR lanes (274 v_readlane per group), and behind an offset the optimiser cannot see through they
+  // become vector loads (no proof that the kernel's stores leave them alone); a copy per group is a plain loop-variant scalar load.
+  const u32* __restrict__ T = reinterpret_cast<const u32*>(rc + kP3Tab + 84 * g);
   const u64* __restrict__ K = rc + kP3K + 14 * g;
   auto finish = [](u64 al, u64 ah) -> u64 {  // (al + ah 2^32) mod p, loose; al, ah < 2^58
     ah = add32((u32)(al >> 32), ah);

@@ -244,8 +244,8 @@ extern "C" int p2mt_init(int device) {
     // 22 + 22 + 20 bits in four u32 per constant)
     // and the tables of the batched partial rounds (poseidon_fast.hip.h kP3Tab / kP3K): M^3, row 0 of M^2, M m0 as u32; per
     // group of three rounds the constants c1[0], (M c1 + c2)[0] and M^2 c1 + M c2 + c3 (mod p)
-    static uint64_t table[1372 + 84 + 14 * 7];
-    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 + 98, "layout of poseidon_fast.hip.h");
+    static uint64_t table[1372 + 84 * 7 + 14 * 7];
+    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
     memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
     memcpy(table + 382, POSEIDON_FAST_K, sizeof(POSEIDON_FAST_K));
@@ -277,11 +277,13 @@ extern "C" int p2mt_init(int device) {
           for (int k = 0; k < 12; ++k) a += M2[r][k] * M[k][c];
           M3[r][c] = a;  // < 2^25: every term of a row is one 32 x 32 multiply
         }
-      uint32_t* t = reinterpret_cast<uint32_t*>(table + 1372);
-      for (int r = 0; r < 12; ++r)
-        for (int c = 0; c < 12; ++c) t[12 * r + c] = (uint32_t)M3[r][c];
-      for (int c = 0; c < 12; ++c) t[144 + c] = (uint32_t)M2[0][c];
-      for (int r = 0; r < 12; ++r) t[156 + r] = (uint32_t)M2[r][0];  // (M m0)[r] = sum_k M[r][k] M[k][0] = M^2[r][0]
+      for (int g = 0; g < 7; ++g) {  // one copy per group (partial_rounds3 says why)
+        uint32_t* t = reinterpret_cast<uint32_t*>(table + 1372 + 84 * g);
+        for (int r = 0; r < 12; ++r)
+          for (int c = 0; c < 12; ++c) t[12 * r + c] = (uint32_t)M3[r][c];
+        for (int c = 0; c < 12; ++c) t[144 + c] = (uint32_t)M2[0][c];
+        for (int r = 0; r < 12; ++r) t[156 + r] = (uint32_t)M2[r][0];  // (M m0)[r] = sum_k M[r][k] M[k][0] = M^2[r][0]
+      }
       auto matvec = [&](const uint64_t (&A)[12][12], const uint64_t* v, uint64_t* out) {
         for (int r = 0; r < 12; ++r) {
           u128 a = 0;
@@ -296,7 +298,7 @@ extern "C" int p2mt_init(int device) {
         matvec(M, c1, mc1);
         matvec(M2, c1, m2c1);
         matvec(M, c2, mc2);
-        uint64_t* k = table + 1372 + 84 + 14 * g;
+        uint64_t* k = table + 1372 + 84 * 7 + 14 * g;
         k[0] = c1[0];
         k[1] = (uint64_t)(((u128)mc1[0] + c2[0]) % p);
         for (int r = 0; r < 12; ++r) k[2 + r] = (uint64_t)(((u128)m2c1[r] + mc2[r] + c3[r]) % p);
