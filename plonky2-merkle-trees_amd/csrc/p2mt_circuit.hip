@@ -846,7 +846,7 @@ __global__ __launch_bounds__(BLK) void k_witness_run(const WOp* __restrict__ ops
   vals = bp(vals, ba);
   set = bp(set, ba);
   err = bp(err, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   run_levels<GMem, BLK>(GMem{vals, set}, ops, lvl, n_levels, pslots, tab, args, err, ctx);
 }
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_grid(const WOp* __restrict__
                                                          u64* vals, u32* set, const u32* __restrict__ pslots,
                                                          const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
                                                          u32* sync, PermCtx ctx) {
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   __shared__ int abort_flag;
   ctx = stage_round_constants(rc_lds, ctx);
   const GMem m{vals, set};
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_flow(const WOp* __restrict__
                                                          u64* vals, u32* set, const u32* __restrict__ pslots,
                                                          const u32* __restrict__ tab, const u32* __restrict__ args, int* err,
                                                          u64* __restrict__ trace, PermCtx ctx) {
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   const FMem m{vals, set, err};
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves_per_block = kBlock / 64;
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_lds(const u64* __restrict__ 
   wires = bp(wires, ba);
   pi_out = bp(pi_out, ba);
   err = bp(err, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   extern __shared__ __attribute__((aligned(16))) u64 sh[];
   const LMem m{sh, reinterpret_cast<uint8_t*>(sh + n_slots)};
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(kBlock) void k_witness_scatter(const u64* __restric
 __global__ __launch_bounds__(kBlock) void k_poseidon_rows(const u32* __restrict__ rows, u32 n_rows, u64* __restrict__ wires,
                                                           u32 log_n, BatchArg ba, PermCtx ctx) {
   wires = bp(wires, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   const u32 k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (k >= n_rows) return;  // wave-uniform
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(kBlock) void k_verify_merkle(const u64* __restrict_
   words = bp(words, ba);
   items = bp(items, ba);
   bad = bp(bad, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   const u32 item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform

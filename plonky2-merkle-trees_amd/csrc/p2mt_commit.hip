@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restr
   in = bp(in, ba);
   digests = bp(digests, ba);
   leaves = bp(leaves, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[p2mt_dev::kWaveRcWords];
   ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
   const size_t col = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (col >= n_pts) return;  // wave-uniform
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_merkle_top(const u64* __restrict__ in,
   in = bp(in, ba);
   next = bp(next, ba);
   cap = bp(cap, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[p2mt_dev::kWaveRcWords];
   __shared__ u64 buf[2][16][4];
   ctx = p2mt_dev::stage_round_constants(rc_lds, ctx);
   const unsigned c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

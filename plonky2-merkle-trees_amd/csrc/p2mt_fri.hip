@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_challenger(ChState* __restrict__ st, con
   save_to = bp(save_to, ba);
   init_wit = bp(init_wit, ba);
   __shared__ u64 s_in[8], s_out[8];
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   const unsigned lane = threadIdx.x;
   // fresh: start from Challenger::new() (zero sponge, empty buffers) without a separate reset launch

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict
                                                            u64* __restrict__ out, BatchArg ba, PermCtx ctx) {
   in = bp(in, ba);
   out = bp(out, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   const size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= n) return;  // wave-uniform
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restr
                                                               BatchArg ba, PermCtx ctx) {
   in = bp(in, ba);
   out = bp(out, ba);
-  __shared__ u64 rc_lds[360];
+  __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
   const size_t j = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (j >= n_out) return;  // wave-uniform

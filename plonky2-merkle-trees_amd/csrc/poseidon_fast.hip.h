@@ -323,7 +323,10 @@ constexpr int kSpTableWords = kSpInit + 121 * 2;
 constexpr int kP3Groups = 7;                   // rounds 4..24 in threes; round 25 stays a single dense round
 constexpr int kP3Tab = kSpTableWords;          // per group a copy of u32[168]: M^3 row-major [0, 144), row 0 of M^2 [144, 156), (M m0)[r] [156, 168)
 constexpr int kP3K = kP3Tab + 84 * kP3Groups;  // per group of three rounds 14 u64: c1[0], K2, K3[0..12)
-constexpr int kTableWords = kP3K + 14 * kP3Groups;
+constexpr int kP3W = kP3K + 14 * kP3Groups;    // right behind the addends: u32[14][14] rows for the 12-lane layout -- lane 0: row 0 of M,
+                                               // lane 1: row 0 of M^2, lane 2 + r: row r of M^3; then the lane's d1 and d2 coefficients
+constexpr int kP3WaveWords = 14 * kP3Groups + 98;  // what stage_round_constants() copies behind the 360 round constants
+constexpr int kTableWords = kP3W + 98;
 
 struct Dot {
   u64 a0l, a0h, a1l, a1h, a2l, a2h;

@@ -18,6 +18,9 @@ namespace p2mt {
 struct PermCtx {
   const uint64_t* rc;
   uint64_t force_fallback;
+  // tables of the 12-lane layout's batched partial rounds (permute_wave_impl): [7][14] u64 addends, then [14][14] u32 per-lane rows
+  // (poseidon_fast.hip.h kP3K, kP3W); global memory, or the workgroup's LDS copy behind stage_round_constants()
+  const uint64_t* w3;
 };
 
 // The library stream is per host thread: a thread that called p2mt_thread_stream_create() (or p2mt_set_stream) enqueues on
@@ -78,7 +81,7 @@ inline int abi_guard(F&& f) noexcept {
 // record an event on the library stream if profiling is on (slot = 2*i for start, 2*i+1 for stop)
 int prof_begin();
 void prof_end(int slot);
-inline PermCtx perm_ctx() { return PermCtx{rt().d_rc, rt().force_fallback ? ~0ull : 0ull}; }
+PermCtx perm_ctx();  // (runtime.hip: needs the table layout of poseidon_fast.hip.h)
 
 // Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.

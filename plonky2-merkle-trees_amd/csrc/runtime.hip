@@ -194,6 +194,11 @@ unsigned subtree_levels_for(size_t n_leaves) {
   return lv;
 }
 
+PermCtx perm_ctx() {
+  const Runtime& r = rt();
+  return PermCtx{r.d_rc, r.force_fallback ? ~0ull : 0ull, r.d_rc + (646 + 22 * 11 * 2 + 121 * 2 + 84 * 7)};  // kP3K
+}
+
 int ensure_init() {
   if (rt().initialised) return P2MT_OK;  // (set last, under the lock, by p2mt_init)
   return p2mt_init(rt().device);
@@ -244,8 +249,8 @@ extern "C" int p2mt_init(int device) {
     // 22 + 22 + 20 bits in four u32 per constant)
     // and the tables of the batched partial rounds (poseidon_fast.hip.h kP3Tab / kP3K): M^3, row 0 of M^2, M m0 as u32; per
     // group of three rounds the constants c1[0], (M c1 + c2)[0] and M^2 c1 + M c2 + c3 (mod p)
-    static uint64_t table[1372 + 84 * 7 + 14 * 7];
-    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98, "layout of poseidon_fast.hip.h");
+    static uint64_t table[1372 + 84 * 7 + 14 * 7 + 98];
+    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98 + 98, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
     memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
     memcpy(table + 382, POSEIDON_FAST_K, sizeof(POSEIDON_FAST_K));
@@ -291,6 +296,17 @@ extern "C" int p2mt_init(int device) {
           out[r] = (uint64_t)a;
         }
       };
+      {  // per-lane rows of the 12-lane layout (kP3W): 12 matrix entries, then the coefficients of d1 and d2
+        uint32_t* w = reinterpret_cast<uint32_t*>(table + 1372 + 84 * 7 + 14 * 7);
+        for (int L = 0; L < 14; ++L)
+          for (int c = 0; c < 14; ++c) {
+            uint64_t v;
+            if (c < 12) v = L == 0 ? M[0][c] : (L == 1 ? M2[0][c] : M3[L - 2][c]);
+            else if (c == 12) v = L == 0 ? 0 : (L == 1 ? M[0][0] : M2[L - 2][0]);  // d1: m0[0] for v2[0], (M m0)[r] for v3[r]
+            else v = L < 2 ? 0 : M[L - 2][0];                                       // d2: m0[r] for v3[r]
+            w[14 * L + c] = (uint32_t)v;
+          }
+      }
       for (int g = 0; g < 7; ++g) {
         const int r0 = 4 + 3 * g;  // the group's first round; c1, c2, c3 = the constants of rounds r0+1, r0+2, r0+3
         const uint64_t *c1 = POSEIDON_RC + 12 * (r0 + 1), *c2 = POSEIDON_RC + 12 * (r0 + 2), *c3 = POSEIDON_RC + 12 * (r0 + 3);

@@ -135,10 +135,12 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 // Copy the 360 round constants into LDS (all threads of the workgroup must call it) and return a context that reads them
 // from there: a wave-permutation fetches one constant per round and lane, and an LDS round trip hides under one round
 // where an L2 one does not (measured: ~2 us of exposed load latency per 10.5 us permutation).
-GL_DEV PermCtx stage_round_constants(u64* lds /*[360]*/, const PermCtx& ctx) {
+constexpr int kWaveRcWords = 360 + poseidon_fast::kP3WaveWords;  // size of the LDS array behind stage_round_constants()
+GL_DEV PermCtx stage_round_constants(u64* lds /*[kWaveRcWords]*/, const PermCtx& ctx) {
   for (unsigned k = threadIdx.x; k < 360; k += blockDim.x) lds[k] = ctx.rc[k];
+  for (unsigned k = threadIdx.x; k < (unsigned)poseidon_fast::kP3WaveWords; k += blockDim.x) lds[360 + k] = ctx.w3[k];
   __syncthreads();
-  return PermCtx{lds, ctx.force_fallback};
+  return PermCtx{lds, ctx.force_fallback, lds + 360};
 }
 
 template <bool EXACT, typename Hook>
@@ -154,16 +156,29 @@ GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky
     kk[c] = (u32)((word >> (8 * (idx & 7))) & 0xFF) + ((w == 0 && c == 0) ? 8u : 0u);
   }
 
+  // Batched partial rounds (round 3; poseidon_fast::partial_rounds3 has the algebra): rounds 4..24 run as 7 groups of three with
+  // ONE broadcast-and-accumulate step each -- lane 0 accumulates row 0 of M y (the next S-box input), lane 1 row 0 of M^2 y, lanes
+  // 2..13 the rows of M^3 y, all in the same 24 mads; the two later S-box inputs are broadcast, so every lane holds d1 / d2 and adds
+  // its own multiple of them; the result slides from lanes 2..13 to lanes 0..11.  Per-lane rows and addends come from ctx.w3.
+  const unsigned L = lane < 14 ? lane : 0;
+  const u32* __restrict__ w3 = reinterpret_cast<const u32*>(ctx.w3 + 14 * poseidon_fast::kP3Groups) + 14 * L;
+  u32 k3[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) k3[c] = w3[c];
+  const u32 cf1 = w3[12], cf2 = w3[13];
+
   const u64* rcw = ctx.rc + w;     // this lane's column of the round-constant table
   u64 c_next = rcw[12];            // constant of round r+1, fetched one round ahead (hidden under the S-box)
   x = gl::add_c(x, rcw[0]);
+  auto sbox = [&](u64 v) -> u64 {
+    if constexpr (EXACT) return poseidon_fast::exact::pow7(v);
+    else return poseidon_fast::pow7(v, sticky);
+  };
   // one round: S-box (every lane in a full round, lane 0 in a partial one), then this lane's MDS row with the
   // next round's constant folded into the two mad chains
   auto round = [&](int r, bool full, bool add, u64 c_fold) {
     hook(r, x);
-    u64 y;
-    if constexpr (EXACT) y = poseidon_fast::exact::pow7(x);
-    else y = poseidon_fast::pow7(x, sticky);
+    const u64 y = sbox(x);
     if (full || lane == 0) x = y;
     const u32 xl = (u32)x, xh = (u32)(x >> 32);
     u64 al = add ? (u64)(u32)c_fold : 0, ah = add ? (u64)(u32)(c_fold >> 32) : 0;
@@ -183,12 +198,57 @@ GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky
       sticky |= cm;
     }
   };
+  auto fold = [](u64 al, u64 ah) -> u64 {  // (al + ah 2^32) mod p, loose; exact form (the top word reaches 2^26 here)
+    ah = poseidon_fast::add32((u32)(al >> 32), ah);
+    return poseidon_fast::exact::fold96((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al);
+  };
+  auto bcast = [](u64 v, int src) -> u64 {  // lane `src`'s value in every lane
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, src);
+  };
+  auto group = [&](int g) {  // rounds k = 4 + 3g, k + 1, k + 2
+    const int k = POSEIDON_HALF_FULL_ROUNDS + 3 * g;
+    const u64 init = ctx.w3[14 * g + L];
+    hook(k, x);
+    const u64 y = sbox(x);
+    if (lane == 0) x = y;
+    const u32 xl = (u32)x, xh = (u32)(x >> 32);
+    u64 al = (u64)(u32)init, ah = (u64)(u32)(init >> 32);
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const u32 sl = (u32)__builtin_amdgcn_readlane((int)xl, c), sh = (u32)__builtin_amdgcn_readlane((int)xh, c);
+      al += (u64)sl * k3[c];
+      ah += (u64)sh * k3[c];
+    }
+    const u64 x1 = bcast(fold(al, ah), 0);  // v1[0]
+    hook(k + 1, x1);
+    const u64 d1 = poseidon_fast::sub_any(sbox(x1), x1);
+    al += (u64)(u32)d1 * cf1;
+    ah += (u64)(u32)(d1 >> 32) * cf1;
+    const u64 x2 = bcast(fold(al, ah), 1);  // v2[0]
+    hook(k + 2, x2);
+    const u64 d2 = poseidon_fast::sub_any(sbox(x2), x2);
+    al += (u64)(u32)d2 * cf2;
+    ah += (u64)(u32)(d2 >> 32) * cf2;
+    const u64 v3 = fold(al, ah);            // lanes 2..13: words 0..11 of the state in front of round k + 3
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v3, 0x102, 0xF, 0xF, true);          // row_shl:2: lane i <- lane i + 2
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v3 >> 32), 0x102, 0xF, 0xF, true);
+    x = ((u64)hi << 32) | lo;
+  };
 #pragma unroll 1
-  for (int r = 0; r < POSEIDON_ROUNDS - 1; ++r) {
+  for (int r = 0; r < POSEIDON_HALF_FULL_ROUNDS; ++r) {
+    const u64 c_fold = c_next;
+    c_next = rcw[12 * (r + 2)];
+    round(r, true, true, c_fold);
+  }
+  static_assert(POSEIDON_PARTIAL_ROUNDS == 3 * poseidon_fast::kP3Groups + 1, "7 groups of three + one round");
+#pragma unroll 1
+  for (int g = 0; g < poseidon_fast::kP3Groups; ++g) group(g);
+  c_next = rcw[12 * (POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS)];
+#pragma unroll 1
+  for (int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS - 1; r < POSEIDON_ROUNDS - 1; ++r) {
     const u64 c_fold = c_next;
     if (r + 2 < POSEIDON_ROUNDS) c_next = rcw[12 * (r + 2)];
-    const bool full = r < POSEIDON_HALF_FULL_ROUNDS || r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS;
-    round(r, full, true, c_fold);
+    round(r, r >= POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS, true, c_fold);
   }
   round(POSEIDON_ROUNDS - 1, true, false, 0);
   return x;
