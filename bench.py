@@ -617,8 +617,8 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
            "public_inputs": [int(x) for x in proof[-4:]]}
     # Roofline of the chain's unit of work: one wave-permutation (k_challenger & co: ~180 of them are chained per proof).
     # Measured live with HIP events on the library stream: a transcript absorbing 8192 words = 1024 permutations in ONE launch.
-    # Bound: VALU issue of a single wavefront -- 30 rounds x (54 v_mad_u64_u32 at 8 cycles + 59 other VALU at 4 cycles) =
-    # 20 040 cycles at the 2.4 GHz peak engine clock (instruction mix from the ISA).
+    # Bound: VALU issue of a single wavefront -- v_mad_u64_u32 at 8 cycles, other VALU at 4 cycles, instruction mix from the ISA
+    # (DESIGN.md 4.3): 16 400 cycles at the 2.4 GHz peak engine clock (20 040 before the partial rounds were batched in threes).
     from plonky2_merkle_trees_amd import fri as F
     ch = F.Challenger()
     d_words = torch.arange(1, 8193, dtype=torch.int64, device="cuda")
@@ -629,7 +629,8 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
     t_ms = C.c_float(0)
     Nn.check(lib.p2mt_timer_stop(C.byref(t_ms)))
     perm_us = t_ms.value * 1e3 / 1024
-    peak_perms = 2.4e9 / (30 * (54 * 8 + 59 * 4))
+    # 9 rounds of (54 mads, 59 other VALU) + 7 groups of three partial rounds of (121 mads, 129 other) -- the batched form of round 3
+    peak_perms = 2.4e9 / (9 * (54 * 8 + 59 * 4) + 7 * (121 * 8 + 129 * 4))
     out["roofline"] = {"bound": "valu-issue (one wavefront; the chain is latency-bound, no HBM or MFMA roof applies)",
                        "achieved": 1e6 / perm_us, "peak": peak_perms, "unit": "wave-permutations/s per wavefront",
                        "frac": (1e6 / perm_us) / peak_perms, "traffic": None, "kernel": "k_challenger (permute_wave)",
