@@ -23,6 +23,17 @@ namespace poseidon_fast {
 using gl::u32;
 using gl::u64;
 
+// The constant table seen through the CONSTANT address space: a uniform load through such a pointer is a scalar load whatever else
+// the kernel does.  Through the plain (generic) pointer the compiler must prove that nothing in the kernel can write the table, and
+// it cannot when the kernel also stores through computed pointers or uses atomics (the batched proof-of-work queue read its round
+// constants and the 168 matrix words of every group of partial rounds with VECTOR loads: ~400 KB per wave-permutation).  Valid for the
+// global table only (written once at p2mt_init) -- never for the LDS copy the 12-lane layout keeps.
+typedef const u64 __attribute__((address_space(4))) * ctab;
+typedef const u32 __attribute__((address_space(4))) * ctab32;
+GL_DEV ctab as_const_table(const u64* global_table) { return (ctab)(unsigned long long)global_table; }
+GL_DEV const u32* as_u32(const u64* p) { return reinterpret_cast<const u32*>(p); }
+GL_DEV ctab32 as_u32(ctab p) { return (ctab32)p; }
+
 // d = a * b + c, carry-out as a lane mask (SGPR pair)
 GL_DEV u64 mad_carry(u32 a, u32 b, u64 c, u64& carry) {
   u64 d;
@@ -149,8 +160,8 @@ GL_DEV u64 fold96(u32 top, u64 val) {
 
 // out[r] = sum_c MDS[r][c] * s[c] + add[r] for r < ROWS  (add = next round's constants, canonical; ADD = false
 // for the last round).  Rows >= ROWS are left untouched (two_to_one only needs 4 output words of the last layer).
-template <bool ADD, int ROWS = 12, bool EXACT = false>
-GL_DEV void mds_layer(u64 (&s)[12], const u64* __restrict__ add, u64& sticky) {
+template <bool ADD, int ROWS = 12, bool EXACT = false, typename P = const u64*>
+GL_DEV void mds_layer(u64 (&s)[12], P add, u64& sticky) {
   u32 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
@@ -242,8 +253,8 @@ GL_DEV u64 mac_one_first0(u32 a) {
   asm("v_mad_u64_u32 %0, %1, %2, 1, 0" : "=v"(d), "=s"(unused) : "v"(a));
   return d;
 }
-template <bool ADD, int ROWS = 12>
-GL_DEV void mds_layer_mfma(u64 (&s)[12], const u64* __restrict__ add, u64& sticky, const MfmaCtx& mc) {
+template <bool ADD, int ROWS = 12, typename P = const u64*>
+GL_DEV void mds_layer_mfma(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) {
   // B operands: bt[jb][t] = (byte t of words 4jb .. 4jb+3) ^ 0x80, t = 0..7 over the 64-bit word
   u32 bt[3][8];
 #pragma unroll
@@ -392,13 +403,13 @@ GL_DEV void mac_s(u64& acc, u32 a, u32 k) {
   u64 unused;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "s"(k));
 }
-template <typename Sbox>
-GL_DEV void partial_rounds3(u64 (&s)[12], const u64* __restrict__ rc, int g, Sbox&& sbox) {
+template <typename P, typename Sbox>
+GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
   // The 168 matrix words are the same for every group, but each group reads ITS OWN copy of them: hoisted out of the loop they
   // would sit in SGPRs spilled to VGPR lanes (274 v_readlane per group), and behind an offset the optimiser cannot see through they
   // become vector loads (no proof that the kernel's stores leave them alone); a copy per group is a plain loop-variant scalar load.
-  const u32* __restrict__ T = reinterpret_cast<const u32*>(rc + kP3Tab + 84 * g);
-  const u64* __restrict__ K = rc + kP3K + 14 * g;
+  const auto T = as_u32(rc + kP3Tab + 84 * g);
+  const P K = rc + kP3K + 14 * g;
   auto finish = [](u64 al, u64 ah) -> u64 {  // (al + ah 2^32) mod p, loose; al, ah < 2^58
     ah = add32((u32)(al >> 32), ah);
     return exact::fold96((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al);
@@ -478,18 +489,18 @@ GL_DEV void partial_rounds3(u64 (&s)[12], const u64* __restrict__ rc, int g, Sbo
 //   mfma_ctx_init(), made while every lane of the wave was still active).  Same function, same flag semantics.
 // P3: the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0)>
-GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*>
+GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   static_assert(!P3 || (!EXACT && !SPARSE && MFMA == 0), "partial_rounds3 belongs to the dense flag form");
   u64 sticky = 0;
   static_assert(!(MFMA && (EXACT || SPARSE)), "the matrix-pipe MDS exists in the flag form with dense partial rounds only");
-  auto mds4 = [&](auto add_tag, auto rows_tag, const u64* add, auto in_partial_round) {
+  auto mds4 = [&](auto add_tag, auto rows_tag, RC add, auto in_partial_round) {
     constexpr bool kAdd = decltype(add_tag)::value;
     constexpr int kRows = decltype(rows_tag)::value;
     if constexpr (MFMA == 1 || (MFMA == 2 && decltype(in_partial_round)::value)) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
     else mds_layer<kAdd, kRows, EXACT>(s, add, sticky);
   };
-  auto mds = [&](auto add_tag, auto rows_tag, const u64* add) { mds4(add_tag, rows_tag, add, std::false_type{}); };
+  auto mds = [&](auto add_tag, auto rows_tag, RC add) { mds4(add_tag, rows_tag, add, std::false_type{}); };
   using T = std::true_type;
   using R12 = std::integral_constant<int, 12>;
   auto sbox = [&](u64 x) -> u64 {
@@ -596,8 +607,15 @@ GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc =
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
-  mds(std::false_type{}, std::integral_constant<int, OUT_ROWS>{}, nullptr);
+  mds(std::false_type{}, std::integral_constant<int, OUT_ROWS>{}, RC{});
   return sticky;
+}
+// `rc` = the GLOBAL constant table (p2mt::perm_ctx().rc), never the LDS copy of the 12-lane layout
+template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0)>
+GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
+  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*>(s, rc, mc);
+  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab>(s, as_const_table(rc), mc);
 }
 
 }  // namespace poseidon_fast
