@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libp2mt_hip.so")
+# (P2MT_LIB_PATH: the sanitizer leg points the binding at its own host-only AddressSanitizer build of the same sources,
+#  csrc/Makefile `asan`; there is still no fallback -- the named library is the one that must load)
+LIB_PATH = os.environ.get("P2MT_LIB_PATH") or os.path.join(PKG_DIR, "libp2mt_hip.so")
 
 P2MT_OK, P2MT_EINVAL, P2MT_ENOMEM, P2MT_EHIP, P2MT_ERANGE, P2MT_ENOTPEAK = 0, -1, -2, -3, -4, -5
 MAX_PROOF_LEN = 64
