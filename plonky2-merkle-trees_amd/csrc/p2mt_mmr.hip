@@ -118,6 +118,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
   poseidon_fast::MfmaCtx mc;  // PR >= 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
   if constexpr (PR == 2 || PR == 3) mc = poseidon_fast::mfma_ctx_init();
+  if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
   const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
   if (blk >= block0 + n_blocks) return;
   const size_t first_leaf = blk << LV;
@@ -643,6 +644,25 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       // variants exist for 2^4-leaf subtrees in 256-lane workgroups only, and subtree_levels_for() never asks for anything else
       // while one of them is selected
       const int variant = (sub_lv == 4 && sb == 256) ? rt().partial : 0;
+#ifdef P2MT_DEV_FEWER_VARIANTS  // developer builds: the shipped instantiations + variant 5 only (this file takes 5 min otherwise)
+      if (sub_lv == 3) {
+        hipLaunchKernelGGL((k_mmr_subtree<3, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
+                           m->elements, block0, n_blocks, p2mt::perm_ctx());
+      } else if (sub_lv == 2) {
+        hipLaunchKernelGGL((k_mmr_subtree<2, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
+                           m->elements, block0, n_blocks, p2mt::perm_ctx());
+      } else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
+      else if (variant == 5) {
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 5, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
+                           p2mt::perm_ctx());
+      } else if (variant == 6) {
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 6, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
+                           p2mt::perm_ctx());
+      } else {
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 0, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
+                           p2mt::perm_ctx());
+      }
+#else
       if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
       else if (sub_lv == 3) {
         hipLaunchKernelGGL((k_mmr_subtree<3, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
@@ -654,6 +674,10 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
       else if (variant == 3) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
       else if (variant == 1) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
+      else if (variant == 5) {  // full rounds' MDS layers as one 32x32x32 MFMA per limb (A/B: p2mt_set_variant(2, 5))
+        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 5, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
+                           p2mt::perm_ctx());
+      }
       else if (variant == 4) P2MT_SUB(4, 256, 4);  // one MDS layer per partial round, round 2's form (A/B: p2mt_set_variant(2, 4))
       else if (sb == 64) P2MT_SUB(4, 64, 0);
       else if (sb == 128) P2MT_SUB(4, 128, 0);
@@ -661,6 +685,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
         hipLaunchKernelGGL((k_mmr_subtree<4, 256, 0, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
                            p2mt::perm_ctx());
       } else P2MT_SUB(4, 256, 0);
+#endif
 #undef P2MT_SUB
       P2MT_LAUNCH_CHECK();
       p2mt::prof_end(prof_slot);

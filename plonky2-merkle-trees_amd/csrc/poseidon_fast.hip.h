@@ -109,18 +109,62 @@ GL_DEV void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
   lo = (t2 << 32) | (u32)t0;
   hi = t3;
 }
+// The same product in four mads and nothing else: the second cross term is added to the WHOLE first one (a1 b0 + t1, 65 bits), its
+// carry-out stays a lane mask `c` of weight 2^96 == -1 (mod p), and the reduction below takes it as the borrow-in of its "- hh".
+// Against mul_wide: no x*1 mad, and one pair assembly (v_mov) fewer -- gfx90a+ wants 64-bit operands in even-aligned pairs, so every
+// (word, 0) addend costs a v_mov.  a b = lo + (hi + c 2^32) 2^64.
+GL_DEV void mul_wide_c(u64 a, u64 b, u64& lo, u64& hi, u64& c) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 t0 = (u64)a0 * b0;
+  const u64 t1 = (u64)a0 * b1 + (t0 >> 32);        // <= 2^64 - 2^32: no carry
+  const u64 t2 = mad_carry(a1, b0, t1, c);
+  hi = (u64)a1 * b1 + (t2 >> 32);                  // < 2^64
+  lo = (t2 << 32) | (u32)t0;
+}
+// (hi:lo) - h - (cin ? 1 : 0), borrow-out as a lane mask
+GL_DEV u64 sub32_borrow_in(u64 x, u32 h, u64 cin, u64& borrow) {
+  u32 lo, hi;
+  asm("v_subb_co_u32_e64 %0, %2, %3, %5, %6\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
+      : "=&v"(lo), "=v"(hi), "=&s"(borrow)
+      : "v"((u32)x), "v"((u32)(x >> 32)), "v"(h), "s"(cin));
+  return ((u64)hi << 32) | lo;
+}
+// x = lo + hl 2^64 + (hh + c) 2^96 == lo + hl EPS - hh - c.  Loose result; the rare borrow goes to `sticky`.
+GL_DEV u64 reduce128_c(u64 lo, u64 hi, u64 c, u64& sticky) {
+  const u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 c1, b;
+  const u64 d1 = mad_eps_carry(hl, lo, c1);
+  const u64 d2 = add32(eps_if(c1), d1);
+  const u64 d3 = sub32_borrow_in(d2, hh, c, b);    // hh + c < 2^32 (the product is < 2^128): borrows only if d2 < 2^32
+  sticky |= b;
+  return d3;
+}
 
 GL_DEV u64 mul(u64 a, u64 b, u64& sticky) {
+  u64 lo, hi, c;
+  mul_wide_c(a, b, lo, hi, c);
+  return reduce128_c(lo, hi, c, sticky);
+}
+
+// the previous form (x*1 mad for the last high-word accumulation), kept for the A/B (p2mt_set_variant(2, 6))
+GL_DEV u64 mul_v0(u64 a, u64 b, u64& sticky) {
   u64 lo, hi;
   mul_wide(a, b, lo, hi);
   return reduce128(lo, hi, sticky);
 }
-
+template <int MULV = 0>
 GL_DEV u64 pow7(u64 x, u64& sticky) {
-  const u64 x2 = mul(x, x, sticky);
-  const u64 x4 = mul(x2, x2, sticky);
-  const u64 x3 = mul(x2, x, sticky);
-  return mul(x4, x3, sticky);
+  if constexpr (MULV == 1) {
+    const u64 x2 = mul_v0(x, x, sticky);
+    const u64 x4 = mul_v0(x2, x2, sticky);
+    const u64 x3 = mul_v0(x2, x, sticky);
+    return mul_v0(x4, x3, sticky);
+  } else {
+    const u64 x2 = mul(x, x, sticky);
+    const u64 x4 = mul(x2, x2, sticky);
+    const u64 x3 = mul(x2, x, sticky);
+    return mul(x4, x3, sticky);
+  }
 }
 
 // ------------------------------------------------------------------ exact forms (no sticky flag)
@@ -138,10 +182,18 @@ GL_DEV u64 reduce128(u64 lo, u64 hi) {
   const u64 d3 = sub32_borrow(d2, hh, b);                  // wrapped by +2^64 == +EPS in lanes of b ...
   return sub32_borrow(d3, eps_if(b), b2);                  // ... take it back (d3 >= 2^64 - 2^32 there: no 2nd borrow)
 }
+GL_DEV u64 reduce128_c(u64 lo, u64 hi, u64 c) {
+  const u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 c1, b, b2;
+  const u64 d1 = mad_eps_carry(hl, lo, c1);
+  const u64 d2 = add32(eps_if(c1), d1);
+  const u64 d3 = sub32_borrow_in(d2, hh, c, b);            // wrapped by +2^64 == +EPS in lanes of b ...
+  return sub32_borrow(d3, eps_if(b), b2);                  // ... take it back (d3 >= 2^64 - 2^32 there: no 2nd borrow)
+}
 GL_DEV u64 mul(u64 a, u64 b) {
-  u64 lo, hi;
-  mul_wide(a, b, lo, hi);
-  return reduce128(lo, hi);
+  u64 lo, hi, c;
+  mul_wide_c(a, b, lo, hi, c);
+  return reduce128_c(lo, hi, c);
 }
 GL_DEV u64 pow7(u64 x) {
   const u64 x2 = mul(x, x);
@@ -211,6 +263,7 @@ typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 struct MfmaCtx {
   u32 a[3][3];       // a[rb][jb]: bytes k = 0..3 = MDS[4 rb + (lane & 3)][4 jb + k]
   mfma_v4i cinit[2]; // 128 * rowsum of rows 0..3 / of any other four rows
+  mfma_v4i a32;      // mds_layer_mfma32: the lane's 16 K slots of its row of the block-structured 32 x 32 A operand (below)
 };
 constexpr u32 mds_rowsum(int r) {
   u32 t = 0;
@@ -312,6 +365,96 @@ GL_DEV void mds_layer_mfma(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) 
         sticky |= cm;
       }
     });
+  });
+}
+
+// ------------------------------------------------------------------ MDS layer on ONE large MFMA per 8-bit limb (round 3, second A/B)
+// The 4x4x4 form above is a wash because the matrix pipe's cost to the VALU is per INSTRUCTION (72 per layer x ~1.1 mad slots).
+// v_mfma_i32_32x32x32_i8 costs ~4 mad slots (tools/ubench_mfma32.hip: 8.4-11 ns of VALU time at four waves per SIMD) and, with a
+// block-structured A operand, does a whole limb of the layer for all 64 hashes of the wave without cross-lane movement:
+//   * lanes 0..31 feed K slots 0..15 of column n = lane, lanes 32..63 feed K slots 16..31 of column n = lane - 32;
+//   * result register v of lane (n, half) is row 8 (v / 4) + 4 half + v % 4 of column n;
+//   * so rows {0-3, 8-11, 16-19} of A carry M in K slots 0..11 only and rows {4-7, 12-15, 20-23} carry M in K slots 16..27 only:
+//     register v < 12 of EVERY lane = sum_j M[v][j] * (byte l of word j of the lane's own hash)   (probe: tools/ubench_mfma32.hip).
+// Per layer: 24 v_xor (bytes -> signed) + 48 v_perm_b32 (six 4x4 byte transposes, as above) + 8 MFMAs (srcC = inline 0) + per row
+// two chains of four v_mad_i64_i32 (signed 18-bit limb sums x 2^(8l); the chain starts at 128 rowsum 0x01010101 + the next round's
+// constant half, which undoes the signed-byte offset and makes the sum non-negative) + the same 96 -> 64 bit fold: 120 mads
+// against 312 in the VALU form.
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+GL_DEV void mfma32_ctx_init(MfmaCtx& c) {
+  const unsigned l = threadIdx.x & 63, i = l & 31, half = l >> 5, sub = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3);
+  mfma_v4i a = {0, 0, 0, 0};
+  poseidon::static_for<0, 12>([&](auto rc_) {
+    constexpr int r = decltype(rc_)::value;
+    auto pack = [](int jb) constexpr -> u32 {
+      return poseidon::mds_entry(r, 4 * jb) | (poseidon::mds_entry(r, 4 * jb + 1) << 8) | (poseidon::mds_entry(r, 4 * jb + 2) << 16) |
+             (poseidon::mds_entry(r, 4 * jb + 3) << 24);
+    };
+    constexpr u32 p0 = pack(0), p1 = pack(1), p2 = pack(2);
+    if (sub == half && v == (unsigned)r) a = mfma_v4i{(int)p0, (int)p1, (int)p2, 0};
+  });
+  c.a32 = a;
+}
+// d = a * 1 + init (a signed), init a wave-uniform 64-bit value (SGPR pair)
+GL_DEV u64 mad_i_first(int a, u64 init_uniform) {
+  u64 d, unused;
+  asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(unused) : "v"(a), "s"(init_uniform));
+  return d;
+}
+// acc += a * k (a signed), k wave-uniform (SGPR)
+GL_DEV void mac_i_sgpr(u64& acc, int a, u32 k) {
+  u64 unused;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "s"(k));
+}
+template <bool ADD, int ROWS = 12, typename P = const u64*>
+GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) {
+  u64 acc[2][12];
+  poseidon::static_for<0, 2>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    u32 t[3][4];  // t[g][b] = (byte b of the halves of words 4g .. 4g+3) ^ 0x80
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      u32 w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = (u32)(s[4 * g + k] >> (32 * h)) ^ 0x80808080u;
+      const u32 p01l = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), p01h = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+      const u32 p23l = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), p23h = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+      t[g][0] = __builtin_amdgcn_perm(p23l, p01l, 0x05040100u);
+      t[g][1] = __builtin_amdgcn_perm(p23l, p01l, 0x07060302u);
+      t[g][2] = __builtin_amdgcn_perm(p23h, p01h, 0x05040100u);
+      t[g][3] = __builtin_amdgcn_perm(p23h, p01h, 0x07060302u);
+    }
+    mfma_v16i c[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      mfma_v4i bop;  // K slots 12..15 meet zeros in A: the fourth register is left as it is
+      bop[0] = (int)t[0][b], bop[1] = (int)t[1][b], bop[2] = (int)t[2][b], bop[3] = __builtin_nondeterministic_value(bop[3]);
+      c[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(mc.a32, bop, mfma_v16i{}, 0, 0, 0);
+    }
+    // The results are consumed by inline-asm mads, which the compiler's hazard recogniser does not look into: a VALU read of the
+    // result of an 8-pass XDL op needs 11 wait states.  This statement depends on all four results, so it sits behind the last MFMA
+    // and in front of every consumer.
+    asm volatile("s_nop 15" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+    poseidon::static_for<0, ROWS>([&](auto rcst) {
+      constexpr int r = decltype(rcst)::value;
+      constexpr u64 k_off = (u64)(128u * mds_rowsum(r)) * 0x01010101ull;  // sum_l 128 rowsum 2^(8l), l < 4
+      u64 a;
+      if constexpr (ADD) a = mad_i_first(c[0][r], (u64)(u32)(add[r] >> (32 * h)) + k_off);
+      else a = mad_i_first(c[0][r], k_off);
+      mac_i_sgpr(a, c[1][r], 1u << 8);
+      mac_i_sgpr(a, c[2][r], 1u << 16);
+      mac_i_sgpr(a, c[3][r], 1u << 24);
+      acc[h][r] = a;  // in [0, 2^43)
+    });
+  });
+  poseidon::static_for<0, ROWS>([&](auto rcst) {
+    constexpr int r = decltype(rcst)::value;
+    const u64 al = acc[0][r];
+    const u64 ah = add32((u32)(al >> 32), acc[1][r]);
+    const u64 val = ((u64)(u32)ah << 32) | (u32)al;
+    u64 cm;
+    s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);
+    sticky |= cm;
   });
 }
 
@@ -487,17 +630,20 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
 // SPARSE: the 22 partial rounds in the sparse form above (same function; the dense form is the default and the redo path).
 // MFMA: 1 = every dense MDS layer on the matrix pipe, 2 = only those of the 22 partial rounds (mds_layer_mfma; `mc` from
 //   mfma_ctx_init(), made while every lane of the wave was still active).  Same function, same flag semantics.
+//   3 = the MDS layers of the 8 FULL rounds as one v_mfma_i32_32x32x32_i8 per limb (mds_layer_mfma32; `mc` from mfma32_ctx_init()),
+//   the partial rounds batched as in P3.
 // P3: the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*>
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0>
 GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
-  static_assert(!P3 || (!EXACT && !SPARSE && MFMA == 0), "partial_rounds3 belongs to the dense flag form");
+  static_assert(!P3 || (!EXACT && !SPARSE && (MFMA == 0 || MFMA == 3)), "partial_rounds3 belongs to the dense flag form");
   u64 sticky = 0;
   static_assert(!(MFMA && (EXACT || SPARSE)), "the matrix-pipe MDS exists in the flag form with dense partial rounds only");
   auto mds4 = [&](auto add_tag, auto rows_tag, RC add, auto in_partial_round) {
     constexpr bool kAdd = decltype(add_tag)::value;
     constexpr int kRows = decltype(rows_tag)::value;
     if constexpr (MFMA == 1 || (MFMA == 2 && decltype(in_partial_round)::value)) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
+    else if constexpr (MFMA == 3 && !decltype(in_partial_round)::value) mds_layer_mfma32<kAdd, kRows>(s, add, sticky, *mc);
     else mds_layer<kAdd, kRows, EXACT>(s, add, sticky);
   };
   auto mds = [&](auto add_tag, auto rows_tag, RC add) { mds4(add_tag, rows_tag, add, std::false_type{}); };
@@ -505,7 +651,7 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   using R12 = std::integral_constant<int, 12>;
   auto sbox = [&](u64 x) -> u64 {
     if constexpr (EXACT) return exact::pow7(x);
-    else return pow7(x, sticky);
+    else return pow7<MULV>(x, sticky);
   };
   static_assert(!LEAF_PAIR || CAP_ZERO, "LEAF_PAIR implies zero capacity words");
   constexpr int kVar = CAP_ZERO ? 8 : 12;
@@ -612,10 +758,10 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
 }
 // `rc` = the GLOBAL constant table (p2mt::perm_ctx().rc), never the LDS copy of the 12-lane layout
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0)>
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
-  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*>(s, rc, mc);
-  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab>(s, as_const_table(rc), mc);
+  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*, MULV>(s, rc, mc);
+  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab, MULV>(s, as_const_table(rc), mc);
 }
 
 }  // namespace poseidon_fast
