@@ -34,16 +34,22 @@ __global__ __launch_bounds__(kBlock) void k_mmr_leaves(const u64* __restrict__ l
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_mmr_level(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
                                                       PermCtx ctx) {
-  const size_t j = j0 + (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (j >= j1) return;
+  // PR == 5 (matrix-pipe MDS, the default of the fast path): an MFMA ignores EXEC and every lane's A operand serves the whole wave,
+  // so no lane may leave before the permutation -- lanes past the end redo the last node and skip the store
+  poseidon_fast::MfmaCtx mc;
+  if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
+  size_t j = j0 + (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = j < j1;
+  if constexpr (PR == 5) j = live ? j : j1 - 1;
+  else if (!live) return;
   const size_t last_leaf = ((j + 1) << h) - 1;
   const size_t pos = node_pos(last_leaf, h);
   u64 o[4];
   two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
     load_hash(elements + 4 * (pos - ((size_t)1 << h)), l);
     load_hash(elements + 4 * (pos - 1), r);
-  });
-  store_hash(elements + 4 * pos, o);
+  }, &mc);
+  if (live) store_hash(elements + 4 * pos, o);
 }
 
 // Fused multi-level build of aligned tiles: one workgroup takes 2^kTileLog consecutive nodes of height h0 (raw
@@ -119,8 +125,12 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
   poseidon_fast::MfmaCtx mc;  // PR >= 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
   if constexpr (PR == 2 || PR == 3) mc = poseidon_fast::mfma_ctx_init();
   if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
-  const size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
-  if (blk >= block0 + n_blocks) return;
+  // no lane leaves before the loop (PR == 5: an MFMA ignores EXEC and every lane's A operand serves the whole wave; a copy or spill
+  // of it made under a partial EXEC would lose the idle lanes' rows): lanes past the end rebuild the last subtree and store nothing
+  size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
+  const bool live = blk < block0 + n_blocks;
+  if constexpr (PR == 5) blk = live ? blk : block0 + n_blocks - 1;
+  else if (!live) return;
   const size_t first_leaf = blk << LV;
   const u64* lp = leaves + (first_leaf - leaf_base);
   u64 cur[4] = {0, 0, 0, 0};
@@ -134,8 +144,10 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
       const u64 a = gl::canon(lp[2 * pairs_done]), b = gl::canon(lp[2 * pairs_done + 1]);
       const size_t pos = node_pos(first_leaf + 2 * pairs_done + 1, 1);
       const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
-      store_hash(elements + 4 * (pos - 2), la);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
-      store_hash(elements + 4 * (pos - 1), lb);
+      if (live) {
+        store_hash(elements + 4 * (pos - 2), la);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
+        store_hash(elements + 4 * (pos - 1), lb);
+      }
       two_to_one_r<IMPL_FAST, PR, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {  // leaf pair: 10 of the 12 first S-boxes are constants
         ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
         rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
       merges = (unsigned)__builtin_ctz(~pairs_done);  // trailing ones: carries of the binary counter
       pairs_done += 1;
       h = 1;
-      store_hash(elements + 4 * pos, o);
+      if (live) store_hash(elements + 4 * pos, o);
     } else {  // merge the pending left sibling of height h with cur
       const u64* sp = &stack[h - 1][threadIdx.x * 4];
       two_to_one_r<IMPL_FAST, PR>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
       }, &mc);
       merges -= 1;
       h += 1;
-      store_hash(elements + 4 * node_pos(first_leaf + 2 * pairs_done - 1, h), o);
+      if (live) store_hash(elements + 4 * node_pos(first_leaf + 2 * pairs_done - 1, h), o);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) cur[k] = o[k];
@@ -579,6 +591,11 @@ static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
+  if (rt().mds == 2 && rt().partial == 0) {  // default: dense MDS layers on the matrix pipe (poseidon_fast::mds_layer_mfma32)
+    hipLaunchKernelGGL((k_mmr_level<2, 5>), dim3(grid_for(cnt)), dim3(kBlock), 0, rt().stream, m->elements, h, j0, j1, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
   P2MT_DISPATCH(k_mmr_level, grid_for(cnt), kBlock, m->elements, h, j0, j1);
   return P2MT_OK;
 }
@@ -644,48 +661,30 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       // variants exist for 2^4-leaf subtrees in 256-lane workgroups only, and subtree_levels_for() never asks for anything else
       // while one of them is selected
       const int variant = (sub_lv == 4 && sb == 256) ? rt().partial : 0;
-#ifdef P2MT_DEV_FEWER_VARIANTS  // developer builds: the shipped instantiations + variant 5 only (this file takes 5 min otherwise)
-      if (sub_lv == 3) {
-        hipLaunchKernelGGL((k_mmr_subtree<3, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
-                           m->elements, block0, n_blocks, p2mt::perm_ctx());
-      } else if (sub_lv == 2) {
-        hipLaunchKernelGGL((k_mmr_subtree<2, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
-                           m->elements, block0, n_blocks, p2mt::perm_ctx());
-      } else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
-      else if (variant == 5) {
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 5, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
-                           p2mt::perm_ctx());
-      } else if (variant == 6) {
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 6, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
-                           p2mt::perm_ctx());
-      } else {
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 0, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
-                           p2mt::perm_ctx());
-      }
-#else
-      if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
-      else if (sub_lv == 3) {
-        hipLaunchKernelGGL((k_mmr_subtree<3, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
-                           m->elements, block0, n_blocks, p2mt::perm_ctx());
-      } else if (sub_lv == 2) {
-        hipLaunchKernelGGL((k_mmr_subtree<2, 256, 0, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base,
-                           m->elements, block0, n_blocks, p2mt::perm_ctx());
-      } else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
-      else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers on the matrix pipe (A/B: p2mt_set_variant(2, 2))
+      // template PR of the fast path: 5 = the default (dense MDS layers on the matrix pipe), 0 = VALU MDS (variant 5), 6 = VALU MDS
+      // with the previous field multiply (variant 6), 1..4 = the older A/B forms (variants 1..4)
+#define P2MT_SUB4(LVV, PRR)                                                                                                          \
+  hipLaunchKernelGGL((k_mmr_subtree<LVV, 256, PRR, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base, \
+                     m->elements, block0, n_blocks, p2mt::perm_ctx())
+      if (sub_lv == 3) P2MT_SUB4(3, 5);
+      else if (sub_lv == 2) P2MT_SUB4(2, 5);
+#ifndef P2MT_DEV_FEWER_VARIANTS  // (developer builds leave the rarely used instantiations out: this file takes 5 min otherwise)
+      else if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
+#endif
+      else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
+      else if (variant == 5) P2MT_SUB4(4, 0);      // VALU MDS in the full rounds too (A/B: p2mt_set_variant(2, 5))
+      else if (variant == 6) P2MT_SUB4(4, 6);      // ... and the previous field multiply (A/B: p2mt_set_variant(2, 6))
+#ifndef P2MT_DEV_FEWER_VARIANTS
+      else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers as 4x4x4 MFMAs (A/B: p2mt_set_variant(2, 2))
       else if (variant == 3) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))
       else if (variant == 1) P2MT_SUB(4, 256, 1);  // sparse partial rounds (A/B: p2mt_set_variant(2, 1))
-      else if (variant == 5) {  // full rounds' MDS layers as one 32x32x32 MFMA per limb (A/B: p2mt_set_variant(2, 5))
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 5, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
-                           p2mt::perm_ctx());
-      }
       else if (variant == 4) P2MT_SUB(4, 256, 4);  // one MDS layer per partial round, round 2's form (A/B: p2mt_set_variant(2, 4))
       else if (sb == 64) P2MT_SUB(4, 64, 0);
       else if (sb == 128) P2MT_SUB(4, 128, 0);
-      else if (subtree_occ4()) {
-        hipLaunchKernelGGL((k_mmr_subtree<4, 256, 0, 4>), dim3(sgrid), dim3(256), 0, st, d_leaves, leaf_base, m->elements, block0, n_blocks,
-                           p2mt::perm_ctx());
-      } else P2MT_SUB(4, 256, 0);
+      else if (!subtree_occ4()) P2MT_SUB(4, 256, 5);
 #endif
+      else P2MT_SUB4(4, 5);
+#undef P2MT_SUB4
 #undef P2MT_SUB
       P2MT_LAUNCH_CHECK();
       p2mt::prof_end(prof_slot);

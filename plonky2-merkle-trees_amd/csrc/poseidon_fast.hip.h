@@ -376,10 +376,10 @@ GL_DEV void mds_layer_mfma(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) 
 //   * result register v of lane (n, half) is row 8 (v / 4) + 4 half + v % 4 of column n;
 //   * so rows {0-3, 8-11, 16-19} of A carry M in K slots 0..11 only and rows {4-7, 12-15, 20-23} carry M in K slots 16..27 only:
 //     register v < 12 of EVERY lane = sum_j M[v][j] * (byte l of word j of the lane's own hash)   (probe: tools/ubench_mfma32.hip).
-// Per layer: 24 v_xor (bytes -> signed) + 48 v_perm_b32 (six 4x4 byte transposes, as above) + 8 MFMAs (srcC = inline 0) + per row
-// two chains of four v_mad_i64_i32 (signed 18-bit limb sums x 2^(8l); the chain starts at 128 rowsum 0x01010101 + the next round's
-// constant half, which undoes the signed-byte offset and makes the sum non-negative) + the same 96 -> 64 bit fold: 120 mads
-// against 312 in the VALU form.
+// K slots 12..15 carry the signed-byte offset: the byte -128 in B against -rowsum / 4 in A adds 128 rowsum, so the results are the
+// unsigned limb sums.  Per layer: 24 v_xor (bytes -> signed) + 48 v_perm_b32 (six 4x4 byte transposes, as above) + 8 MFMAs (srcC =
+// inline 0) + per row two chains of four v_mad_u64_u32 (18-bit limb sums x 2^(8l), starting at the next round's constant half) + the
+// same 96 -> 64 bit fold: 120 mads against 312 in the VALU form.
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 GL_DEV void mfma32_ctx_init(MfmaCtx& c) {
   const unsigned l = threadIdx.x & 63, i = l & 31, half = l >> 5, sub = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3);
@@ -391,20 +391,12 @@ GL_DEV void mfma32_ctx_init(MfmaCtx& c) {
              (poseidon::mds_entry(r, 4 * jb + 3) << 24);
     };
     constexpr u32 p0 = pack(0), p1 = pack(1), p2 = pack(2);
-    if (sub == half && v == (unsigned)r) a = mfma_v4i{(int)p0, (int)p1, (int)p2, 0};
+    // K slots 12..15 meet the constant byte -128 in B: 4 x (-rowsum / 4) x (-128) = 128 rowsum undoes the signed-byte offset
+    static_assert(mds_rowsum(r) % 4 == 0 && mds_rowsum(r) / 4 <= 128, "offset term fits four signed bytes");
+    constexpr u32 p3 = 0x01010101u * (u32)(256 - mds_rowsum(r) / 4);
+    if (sub == half && v == (unsigned)r) a = mfma_v4i{(int)p0, (int)p1, (int)p2, (int)p3};
   });
   c.a32 = a;
-}
-// d = a * 1 + init (a signed), init a wave-uniform 64-bit value (SGPR pair)
-GL_DEV u64 mad_i_first(int a, u64 init_uniform) {
-  u64 d, unused;
-  asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(unused) : "v"(a), "s"(init_uniform));
-  return d;
-}
-// acc += a * k (a signed), k wave-uniform (SGPR)
-GL_DEV void mac_i_sgpr(u64& acc, int a, u32 k) {
-  u64 unused;
-  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "s"(k));
 }
 template <bool ADD, int ROWS = 12, typename P = const u64*>
 GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) {
@@ -427,8 +419,8 @@ GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc
     mfma_v16i c[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      mfma_v4i bop;  // K slots 12..15 meet zeros in A: the fourth register is left as it is
-      bop[0] = (int)t[0][b], bop[1] = (int)t[1][b], bop[2] = (int)t[2][b], bop[3] = __builtin_nondeterministic_value(bop[3]);
+      mfma_v4i bop;  // K slots 12..15: the byte -128 against -rowsum / 4 in A, i.e. + 128 rowsum: the results are the UNSIGNED limb sums
+      bop[0] = (int)t[0][b], bop[1] = (int)t[1][b], bop[2] = (int)t[2][b], bop[3] = (int)0x80808080u;
       c[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(mc.a32, bop, mfma_v16i{}, 0, 0, 0);
     }
     // The results are consumed by inline-asm mads, which the compiler's hazard recogniser does not look into: a VALU read of the
@@ -437,14 +429,13 @@ GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc
     asm volatile("s_nop 15" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
     poseidon::static_for<0, ROWS>([&](auto rcst) {
       constexpr int r = decltype(rcst)::value;
-      constexpr u64 k_off = (u64)(128u * mds_rowsum(r)) * 0x01010101ull;  // sum_l 128 rowsum 2^(8l), l < 4
-      u64 a;
-      if constexpr (ADD) a = mad_i_first(c[0][r], (u64)(u32)(add[r] >> (32 * h)) + k_off);
-      else a = mad_i_first(c[0][r], k_off);
-      mac_i_sgpr(a, c[1][r], 1u << 8);
-      mac_i_sgpr(a, c[2][r], 1u << 16);
-      mac_i_sgpr(a, c[3][r], 1u << 24);
-      acc[h][r] = a;  // in [0, 2^43)
+      u64 a;  // sum_l c_l 2^(8l) over this half, every c_l in [0, 2^18)
+      if constexpr (ADD) a = mac_one_first((u32)c[0][r], (u64)(u32)(add[r] >> (32 * h)));
+      else a = mac_one_first0((u32)c[0][r]);
+      mac_sgpr(a, (u32)c[1][r], 1u << 8);
+      mac_sgpr(a, (u32)c[2][r], 1u << 16);
+      mac_sgpr(a, (u32)c[3][r], 1u << 24);
+      acc[h][r] = a;  // < 2^43
     });
   });
   poseidon::static_for<0, ROWS>([&](auto rcst) {
@@ -630,8 +621,8 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
 // SPARSE: the 22 partial rounds in the sparse form above (same function; the dense form is the default and the redo path).
 // MFMA: 1 = every dense MDS layer on the matrix pipe, 2 = only those of the 22 partial rounds (mds_layer_mfma; `mc` from
 //   mfma_ctx_init(), made while every lane of the wave was still active).  Same function, same flag semantics.
-//   3 = the MDS layers of the 8 FULL rounds as one v_mfma_i32_32x32x32_i8 per limb (mds_layer_mfma32; `mc` from mfma32_ctx_init()),
-//   the partial rounds batched as in P3.
+//   3 = every 12-row dense MDS layer (seven of the 8 full rounds + the last partial round) as one v_mfma_i32_32x32x32_i8 per limb
+//   (mds_layer_mfma32; `mc` from mfma32_ctx_init()), the other partial rounds batched as in P3.
 // P3: the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
           bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0>
@@ -643,7 +634,7 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
     constexpr bool kAdd = decltype(add_tag)::value;
     constexpr int kRows = decltype(rows_tag)::value;
     if constexpr (MFMA == 1 || (MFMA == 2 && decltype(in_partial_round)::value)) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
-    else if constexpr (MFMA == 3 && !decltype(in_partial_round)::value) mds_layer_mfma32<kAdd, kRows>(s, add, sticky, *mc);
+    else if constexpr (MFMA == 3 && kRows == 12) mds_layer_mfma32<kAdd, kRows>(s, add, sticky, *mc);  // (4 rows: 104 mads beat it)
     else mds_layer<kAdd, kRows, EXACT>(s, add, sticky);
   };
   auto mds = [&](auto add_tag, auto rows_tag, RC add) { mds4(add_tag, rows_tag, add, std::false_type{}); };

@@ -294,6 +294,36 @@ def test_mfma_mds_variant(pkg, oracle):
         pkg.set_variant(*DEFAULT_VARIANT)
 
 
+@pytest.mark.parametrize("variant", [(2, 0), (2, 5), (2, 6)])
+def test_mfma32_default_and_valu_forms(pkg, oracle, variant):
+    """The default of the fast path puts every 12-row dense MDS layer on ONE v_mfma_i32_32x32x32_i8 per 8-bit limb (block-structured A
+    operand, one hash per lane, no cross-lane movement: poseidon_fast::mds_layer_mfma32) and multiplies in four mads with the
+    carry folded into the reduction; variant (2, 5) keeps the MDS on the VALU, (2, 6) additionally the previous multiply.  All
+    three are the same function: every node equals the oracle's on a ragged size (partial waves: an MFMA ignores EXEC, so the
+    kernels keep every lane in the permutation and only predicate the stores), on limb patterns that stress the signed-byte
+    offset carried in the spare K slots (all-0x00 / 0x7F / 0x80 / 0xFF bytes, p - 1), and with the exact redo forced."""
+    n = (1 << 16) + 4099
+    leaves = splitmix_leaves(n, 0x5EED0532)
+    pat = [0, 1, P - 1, 0x7F7F7F7F7F7F7F7F, 0x8080808080808080, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF, 0x80FF7F0001FE807F,
+           0xFEFEFEFEFEFEFEFE, 0x0101010101010101, 0xFFFFFFFFFFFFFFFF]
+    leaves[:1024] = np.array([pat[i % len(pat)] for i in range(1024)], dtype=np.uint64)
+    om = oracle.mmr(leaves)
+    try:
+        pkg.set_variant(*variant)
+        a = pkg.MMR.from_leaves(leaves)
+        assert np.array_equal(a.elements, om.elements)
+        assert np.array_equal(a.bagging_the_peaks(), om.bagging_the_peaks())
+        for small in (1, 2, 3, 17, 63, 64, 65, 255, 1025):  # fewer nodes than lanes: level kernels with idle lanes
+            c = pkg.MMR.from_leaves(leaves[:small])
+            assert np.array_equal(c.elements, oracle.mmr(leaves[:small]).elements)
+        pkg.lib().p2mt_debug_force_fallback(1)
+        b = pkg.MMR.from_leaves(leaves[:1 << 12])
+        assert np.array_equal(b.elements, oracle.mmr(leaves[:1 << 12]).elements)
+    finally:
+        pkg.lib().p2mt_debug_force_fallback(0)
+        pkg.set_variant(*DEFAULT_VARIANT)
+
+
 @pytest.mark.parametrize("log_n,levels", [(18, 2), (20, 2), (21, 3), (22, 4)])
 def test_adaptive_subtree_size(pkg, oracle, log_n, levels):
     """Round 3: the per-lane subtrees of the stage-1 launch shrink with the build (2^4 leaves per lane from 2^22 leaves up, 2^3 /
