@@ -206,6 +206,8 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
                                                           u32 B, BatchArg ba, PermCtx ctx) {
   __shared__ u32 s_dist, s_blk;
   unsigned p = blockIdx.x % B;
+  poseidon_fast::MfmaCtx mc;  // PR == 5: the permutation below runs with every lane of the workgroup active (its guard is workgroup-uniform)
+  if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
 #pragma unroll 1
   for (;;) {
     if (threadIdx.x == 0) s_dist = ~0u;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
           }
           t[k] = v;
         }
-      });
+      }, &mc);
       const u64 resp = gl::canon(s[7]);
       if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
     }
@@ -1051,6 +1053,13 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
         P2MT_TRY(p2mt::batch_fill(ws + o_cnt, 0, 8));
         const u32 max_blocks = (u32)(batch_chunk / kBlock);
         const u64 wgs = std::min<u64>((u64)B * max_blocks, 2048);
+        if (rt().mds == 2 && rt().partial == 0) {  // default: dense MDS layers on the matrix pipe
+          hipLaunchKernelGGL((k_fri_pow_queue<2, 5>), dim3((unsigned)wgs), dim3(kBlock), 0, st, (const ChState*)ch->d,
+                             (u32)p->proof_of_work_bits, base, max_blocks, d_wit, reinterpret_cast<u32*>(ws + o_cnt), B, barg(),
+                             p2mt::perm_ctx());
+          P2MT_LAUNCH_CHECK();
+          return P2MT_OK;
+        }
         P2MT_DISPATCH(k_fri_pow_queue, dim3((unsigned)wgs), kBlock, (const ChState*)ch->d, (u32)p->proof_of_work_bits, base, max_blocks,
                       d_wit, reinterpret_cast<u32*>(ws + o_cnt), B, barg());
         return P2MT_OK;

@@ -31,8 +31,10 @@ __global__ __launch_bounds__(kBlock) void k_mmr_leaves(const u64* __restrict__ l
 }
 
 // the carry chain of add_leaf (:106-119), level-synchronous: all height-h nodes j in [j0, j1)
+// (four waves per SIMD asked for: without the hint the scheduler of the PR == 5 form spills SGPRs to VGPR lanes -- 93 v_readlane /
+// v_writelane per full round -- and settles at 131 VGPRs = three waves)
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_mmr_level(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
+__global__ __launch_bounds__(kBlock, 4) void k_mmr_level(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
                                                       PermCtx ctx) {
   // PR == 5 (matrix-pipe MDS, the default of the fast path): an MFMA ignores EXEC and every lane's A operand serves the whole wave,
   // so no lane may leave before the permutation -- lanes past the end redo the last node and skip the store
@@ -614,6 +616,9 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
   unsigned h0 = h_from;
   for (;;) {
     if (h0 > 0 && (h0 >= cap || (n1 >> (h0 + 1)) <= (n0 >> (h0 + 1)))) break;  // no node above h0 (or not ours)
+    // (A second per-lane stage -- two levels per lane over the roots stage 1 left, 2^18 lanes at 2^24 leaves, k_mmr_upper -- was built
+    // in round 3, bit-exact, and measured: 5.56 / 5.64 ms against 5.58 / 5.58 ms per build without it.  The level launches it replaces
+    // do the same work at the same occupancy; what they lose is not launch overhead.  Removed.)
     // levels this stage would fuse: stage 1 stops while every level fills whole waves; later stages also stop where
     // the quad/wave-per-node kernels take over
     unsigned n_lev = 0;

@@ -41,10 +41,10 @@ constexpr int IMPL_FAST = 2;  // M == 2: poseidon_fast with exact fallback; M in
 // One permutation whose input can be re-materialised: `load` fills the state (it is called again if the fast
 // path raised its sticky flag, so that no copy of the input has to stay live in VGPRs).
 template <int M, int PR, typename Load>
-GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load) {
+GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load, const poseidon_fast::MfmaCtx* mc = nullptr) {
   load(s);
-  if constexpr (M == IMPL_FAST) {  // PR == 1: sparse partial rounds
-    const u64 sticky = poseidon_fast::permute<false, 12, false, false, PR == 1>(s, ctx.rc) | ctx.force_fallback;
+  if constexpr (M == IMPL_FAST) {  // PR == 1: sparse partial rounds; PR == 5: dense MDS layers on the matrix pipe (`mc`, every lane of the wave active)
+    const u64 sticky = poseidon_fast::permute<false, 12, false, false, PR == 1, (PR == 5 ? 3 : 0), PR == 0 || PR == 5>(s, ctx.rc, mc) | ctx.force_fallback;
     if (__builtin_expect(sticky != 0, 0)) {
       load(s);
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);

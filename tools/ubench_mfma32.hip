@@ -3,7 +3,8 @@
 // Round 3's first matrix-pipe experiment (tools/ubench_mfma.hip, profiles/r03_mds_mfma_ab.txt) used the 4x4x4 16-block form: 72 MFMAs
 // per MDS layer, each keeping the SIMD's VALU port for 4.4 cycles -- a wash.  The port cost is per INSTRUCTION, not per MAC, so the
 // question here is whether ONE large MFMA per 8-bit limb (8 per layer) can stay lane-local.  It can, with a block-structured A:
-//   * B (16 bytes per lane) = byte l of the 12 state words of the lane's OWN hash (bytes 12..15 don't care: A is zero there);
+//   * B (16 bytes per lane) = byte l of the 12 state words of the lane's OWN hash, xor 0x80 (signed bytes); bytes 12..15 = -128 against
+//     -rowsum / 4 in A's K slots 12..15, which adds 128 rowsum back: the result registers hold the UNSIGNED limb sums;
 //   * lanes 0..31 feed the first 16 K slots of column n = lane, lanes 32..63 the other 16 K slots of column n = lane - 32;
 //   * result register v of lane (n, half) is row 8*(v/4) + 4*half + v%4 of column n.  So rows {0-3, 8-11, 16-19} (v = 0..11 of half 0)
 //     carry M in the FIRST 16 K slots only and rows {4-7, 12-15, 20-23} carry M in the SECOND 16 K slots only:
@@ -125,9 +126,14 @@ int main() {
     for (auto& x : B) x = (int8_t)(rand() % 256 - 128);
     for (int l = 0; l < 64; ++l) {
       const int i = l % 32, half = l / 32, sub = (i / 4) % 2, v = 4 * (i / 8) + i % 4;
-      if (sub == half && v < 12)
-        for (int j = 0; j < 12; ++j) A[l * 16 + j] = (int8_t)mds(v, j);
+      if (sub == half && v < 12) {
+        int rowsum = 0;
+        for (int j = 0; j < 12; ++j) A[l * 16 + j] = (int8_t)mds(v, j), rowsum += mds(v, j);
+        for (int j = 12; j < 16; ++j) A[l * 16 + j] = (int8_t)(-rowsum / 4);  // x the constant byte -128 in B: + 128 rowsum (the shipped layout)
+      }
     }
+    for (int l = 0; l < 64; ++l)
+      for (int j = 12; j < 16; ++j) B[l * 16 + j] = (int8_t)-128;
     v4i *da, *db;
     v16i* dd;
     CHECK(hipMalloc(&da, 1024));
@@ -142,11 +148,11 @@ int main() {
     for (int l = 0; l < 64; ++l)
       for (int v = 0; v < 16; ++v) {
         int ref = 0;
-        if (v < 12)
-          for (int j = 0; j < 12; ++j) ref += mds(v, j) * (int)B[l * 16 + j];
+        if (v < 12)  // the UNSIGNED limb sum: bytes were xor-ed with 0x80 (b - 128 as a signed byte), K slots 12..15 add 128 rowsum back
+          for (int j = 0; j < 12; ++j) ref += mds(v, j) * ((int)B[l * 16 + j] + 128);
         if (ref != d[l * 16 + v]) { if (v < 12) ++bad; else ++bad_spare; }
       }
-    printf("lane-local layout probe (register v < 12 of lane n = row v of M x bytes of lane n's own B; registers 12..15 = 0): %s (%d mismatches, %d in the spare registers)\n",
+    printf("lane-local layout probe (register v < 12 of lane n = row v of M x UNSIGNED bytes of lane n's own B, offset via K slots 12..15; registers 12..15 = 0): %s (%d mismatches, %d in the spare registers)\n",
            (bad || bad_spare) ? "WRONG" : "confirmed", bad, bad_spare);
     if (bad) {
       for (int l = 0; l < 64; l += 9) {
