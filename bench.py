@@ -331,13 +331,19 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                      "kernel": info["kernel"],
                      "launch_ms": launch_ms, "launches_timed": kern_n.value,
                      "algorithmic_bytes_per_launch": algo_bytes, "hashes_per_launch": hashes_in_launch,
-                     "note": "Poseidon is integer-issue bound (see `valu`): ~15-16k VALU instructions per 72 algorithmic "
-                             "bytes, so the HBM fraction is ~2 % by construction (SURVEY.md 8d)"},
+                     "note": "Poseidon is integer-issue bound (see `valu`): ~11k VALU + 64 matrix-pipe instructions per 72 "
+                             "algorithmic bytes, so the HBM fraction is ~3 % by construction (SURVEY.md 8d)"},
         # counter evidence for "compute-bound, the right way": share of SIMD issue cycles spent on VALU instructions and VALU
         # instructions per hash, from the committed PMC passes (null when this configuration was not profiled)
         "valu": {"simd_cycles_per_valu_instr": pmc.get("simd_cycles_per_valu_instr"),
                  "valu_instr_per_hash": pmc.get("valu_instr_per_hash"), "effective_clock_ghz": pmc.get("effective_clock_ghz"),
                  "ubench_simd_cycles_per_valu_instr": pmc.get("ubench_simd_cycles_per_valu_instr"),
+                 # the dense MDS layers run on the matrix pipe (one v_mfma_i32_32x32x32_i8 per 8-bit limb): instructions per hash,
+                 # pipe cycles per instruction, share of them during which the VALU co-executes, pipe-busy share of the launch
+                 "mfma": {"instr_per_hash": pmc.get("mfma_instr_per_hash"),
+                          "busy_cycles_per_instr": pmc.get("mfma_busy_cycles_per_instr"),
+                          "valu_coexec_frac": pmc.get("mfma_valu_coexec_frac"),
+                          "busy_frac_of_simd_cycles": pmc.get("mfma_busy_frac_of_simd_cycles")},
                  "source": pmc.get("source"), "in_kernel_hashes_per_s": in_kernel_rate,
                  "note": "simd_cycles_per_valu_instr = (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) / SQ_INSTS_VALU, both counters from "
                          "the same dispatches: how many SIMD cycles the launch spends per VALU instruction it issues.  The "

@@ -63,9 +63,12 @@ int p2mt_set_throughput_mode(int on);
 int p2mt_sync(void);                    /* hipStreamSynchronize on the library stream */
 const char *p2mt_last_error(void);
 /* Kernel variant for the Poseidon permutation.  mds 2 (default) = issue-optimised path (constants folded into the
- * MDS mad chains, carry-mask reduction, sticky rare-event flag + exact fallback); mds 0 / 1 = exact reference
- * variants (v_mad_u64_u32 / v_dot2_u32_u16 MDS) with partial 0 = spec-form, 1 = sparse partial rounds.
- * All variants are bit-identical. */
+ * MDS mad chains, carry-mask reduction, sticky rare-event flag + exact fallback; with partial 0, the default, the dense
+ * MDS layers of the tree-build kernels run on the matrix pipe and three partial rounds share one MDS application);
+ * mds 0 / 1 = exact reference variants (v_mad_u64_u32 / v_dot2_u32_u16 MDS) with partial 0 = spec-form, 1 = sparse
+ * partial rounds.  With mds 2, partial 1..6 select older forms of the stage-1 MMR kernel for A/B measurements
+ * (1 sparse partial rounds, 2 / 3 MDS as 4x4x4 MFMAs in all / the partial rounds, 4 one MDS layer per partial round,
+ * 5 VALU MDS everywhere, 6 = 5 with the previous field multiply).  All variants are bit-identical. */
 int p2mt_set_variant(int mds, int partial);
 int p2mt_get_variant(int *mds, int *partial);
 /* Which stage-1 kernel an MMR build uses with the current variant / environment: subtree_levels = 4|5 -> k_mmr_subtree (each lane

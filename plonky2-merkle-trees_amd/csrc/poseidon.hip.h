@@ -133,7 +133,7 @@ GL_DEV void mds_layer(u64 (&s)[12]) {
 template <int MDS>
 GL_DEV void full_round(u64 (&s)[12], const u64* __restrict__ rc) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = gl::pow7(gl::add_c(s[i], rc[i]));
+  for (int i = 0; i < 12; ++i) s[i] = gl::pow7_ref(gl::add_c(s[i], rc[i]));
   mds_layer<MDS>(s);
 }
 
@@ -144,7 +144,7 @@ GL_DEV void partial_rounds_naive(u64 (&s)[12]) {
     const u64* rc = kRC + 12 * r;
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[i]);
-    s[0] = gl::pow7(s[0]);
+    s[0] = gl::pow7_ref(s[0]);
     mds_layer<MDS>(s);
   }
 }
@@ -188,7 +188,7 @@ GL_DEV void partial_rounds_fast(u64 (&s)[12]) {
   }
 #pragma unroll 1
   for (int i = 0; i < POSEIDON_PARTIAL_ROUNDS; ++i) {
-    const u64 s0 = gl::add_c(gl::pow7(s[0]), kFastK[i]);
+    const u64 s0 = gl::add_c(gl::pow7_ref(s[0]), kFastK[i]);
     Acc192 d = {0, 0, 0};
     acc_mul(d, s0, (u64)POSEIDON_M00);
     const u64* wh = kFastWHat + 11 * i;

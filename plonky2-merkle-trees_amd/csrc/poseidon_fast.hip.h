@@ -34,24 +34,13 @@ GL_DEV ctab as_const_table(const u64* global_table) { return (ctab)(unsigned lon
 GL_DEV const u32* as_u32(const u64* p) { return reinterpret_cast<const u32*>(p); }
 GL_DEV ctab32 as_u32(ctab p) { return (ctab32)p; }
 
-// d = a * b + c, carry-out as a lane mask (SGPR pair)
-GL_DEV u64 mad_carry(u32 a, u32 b, u64 c, u64& carry) {
-  u64 d;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-// d = a * 0xFFFFFFFF + c   (a * 2^64 folded: 2^64 = 2^32 - 1 mod p), carry-out as a lane mask
-GL_DEV u64 mad_eps_carry(u32 a, u64 c, u64& carry) {
-  u64 d;
-  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(d), "=s"(carry) : "v"(a), "v"(c));
-  return d;
-}
-// d = a + c (32-bit a into a 64-bit pair) as one mad; caller guarantees no overflow
-GL_DEV u64 add32(u32 a, u64 c) {
-  u64 d, unused;
-  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(unused) : "v"(a), "v"(c));
-  return d;
-}
+using gl::add32;
+using gl::eps_if;
+using gl::mad_carry;
+using gl::mad_eps_carry;
+using gl::mul_wide_c;
+using gl::sub32_borrow;
+using gl::sub32_borrow_in;
 // acc += a * K, K an inline constant (all MDS entries are <= 41 < 64); forced mad: the compiler would otherwise
 // strength-reduce small constants into v_mov + v_lshl_add_u64 (3 issue units instead of 2)
 template <u32 K>
@@ -72,21 +61,6 @@ GL_DEV u64 mac_const_first0(u32 a) {
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(unused) : "v"(a), "n"(K));
   return d;
 }
-// mask ? 0xFFFFFFFF : 0
-GL_DEV u32 eps_if(u64 mask) {
-  u32 m;
-  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(mask));
-  return m;
-}
-// (hi:lo) - h, borrow-out as a lane mask
-GL_DEV u64 sub32_borrow(u64 x, u32 h, u64& borrow) {
-  u32 lo, hi;
-  asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
-      : "=&v"(lo), "=v"(hi), "=&s"(borrow)
-      : "v"((u32)x), "v"((u32)(x >> 32)), "v"(h));
-  return ((u64)hi << 32) | lo;
-}
-
 // x = lo + hl*2^64 + hh*2^96 == lo + hl*EPS - hh.  Loose result; the rare borrow of "- hh" goes to `sticky`.
 GL_DEV u64 reduce128(u64 lo, u64 hi, u64& sticky) {
   const u32 hl = (u32)hi, hh = (u32)(hi >> 32);
@@ -108,26 +82,6 @@ GL_DEV void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
   const u64 t3 = add32((u32)(t2 >> 32), (u64)a1 * b1 + (t1 >> 32));
   lo = (t2 << 32) | (u32)t0;
   hi = t3;
-}
-// The same product in four mads and nothing else: the second cross term is added to the WHOLE first one (a1 b0 + t1, 65 bits), its
-// carry-out stays a lane mask `c` of weight 2^96 == -1 (mod p), and the reduction below takes it as the borrow-in of its "- hh".
-// Against mul_wide: no x*1 mad, and one pair assembly (v_mov) fewer -- gfx90a+ wants 64-bit operands in even-aligned pairs, so every
-// (word, 0) addend costs a v_mov.  a b = lo + (hi + c 2^32) 2^64.
-GL_DEV void mul_wide_c(u64 a, u64 b, u64& lo, u64& hi, u64& c) {
-  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  const u64 t0 = (u64)a0 * b0;
-  const u64 t1 = (u64)a0 * b1 + (t0 >> 32);        // <= 2^64 - 2^32: no carry
-  const u64 t2 = mad_carry(a1, b0, t1, c);
-  hi = (u64)a1 * b1 + (t2 >> 32);                  // < 2^64
-  lo = (t2 << 32) | (u32)t0;
-}
-// (hi:lo) - h - (cin ? 1 : 0), borrow-out as a lane mask
-GL_DEV u64 sub32_borrow_in(u64 x, u32 h, u64 cin, u64& borrow) {
-  u32 lo, hi;
-  asm("v_subb_co_u32_e64 %0, %2, %3, %5, %6\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
-      : "=&v"(lo), "=v"(hi), "=&s"(borrow)
-      : "v"((u32)x), "v"((u32)(x >> 32)), "v"(h), "s"(cin));
-  return ((u64)hi << 32) | lo;
 }
 // x = lo + hl 2^64 + (hh + c) 2^96 == lo + hl EPS - hh - c.  Loose result; the rare borrow goes to `sticky`.
 GL_DEV u64 reduce128_c(u64 lo, u64 hi, u64 c, u64& sticky) {
@@ -182,18 +136,10 @@ GL_DEV u64 reduce128(u64 lo, u64 hi) {
   const u64 d3 = sub32_borrow(d2, hh, b);                  // wrapped by +2^64 == +EPS in lanes of b ...
   return sub32_borrow(d3, eps_if(b), b2);                  // ... take it back (d3 >= 2^64 - 2^32 there: no 2nd borrow)
 }
-GL_DEV u64 reduce128_c(u64 lo, u64 hi, u64 c) {
-  const u32 hl = (u32)hi, hh = (u32)(hi >> 32);
-  u64 c1, b, b2;
-  const u64 d1 = mad_eps_carry(hl, lo, c1);
-  const u64 d2 = add32(eps_if(c1), d1);
-  const u64 d3 = sub32_borrow_in(d2, hh, c, b);            // wrapped by +2^64 == +EPS in lanes of b ...
-  return sub32_borrow(d3, eps_if(b), b2);                  // ... take it back (d3 >= 2^64 - 2^32 there: no 2nd borrow)
-}
-GL_DEV u64 mul(u64 a, u64 b) {
+GL_DEV u64 mul(u64 a, u64 b) {  // gl::mul without the constant-folding detour
   u64 lo, hi, c;
   mul_wide_c(a, b, lo, hi, c);
-  return reduce128_c(lo, hi, c);
+  return gl::reduce128_c(lo, hi, c);
 }
 GL_DEV u64 pow7(u64 x) {
   const u64 x2 = mul(x, x);

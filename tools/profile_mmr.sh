@@ -17,6 +17,9 @@ echo "sq done" >> "$OUT/progress.log"
 # 8 XCDs) from the SAME dispatches (GRBM slots are independent of the SQ ones)
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_grbm.log" 2>&1
 echo "grbm done" >> "$OUT/progress.log"
+# the matrix pipe (the dense MDS layers run as v_mfma_i32_32x32x32_i8 since the end of round 3): instructions, busy and co-execution cycles
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_mfma.log" 2>&1
+echo "mfma done" >> "$OUT/progress.log"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_fetch.log" 2>&1
 echo "fetch done" >> "$OUT/progress.log"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write/runc" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --no-prove > "$OUT/pmc_write.log" 2>&1
