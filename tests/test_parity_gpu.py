@@ -537,6 +537,14 @@ def test_field_primitives_rare_paths(pkg):
     exp = [(x + (y << 64)) % P for x, y in zip(A, B)]
     assert all(o == e for o, e, f in zip(out, exp, flag) if not f)
     assert flag.sum() > 0, "crafted operands must drive the flagged path"
+    out, _ = run(6)
+    assert out == [x * y % P for x, y in zip(A, B)]                                # gl::mul (four mads, carry folded into the reduce)
+    out, _ = run(7)
+    rotl = lambda x: ((x << 17) | (x >> 47)) & M64
+    assert out == [(x * y + (rotl(x) ^ y)) % P for x, y in zip(A, B)]              # gl::mul_add
+    out, flag = run(8)                                                             # flag-form multiply of the permutation
+    assert all(o == x * y % P for o, x, y, f in zip(out, A, B, flag) if not f)
+    assert flag.sum() < len(A) // 4
     for op, fn in ((4, lambda x, y: (x + y) % P), (5, lambda x, y: (x - y) % P)):  # loose add / sub of the LDE kernel
         out, flag = run(op)
         assert all(o == fn(x, y) for o, x, y, f in zip(out, A, B, flag) if not f)
