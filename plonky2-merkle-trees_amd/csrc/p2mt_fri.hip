@@ -204,7 +204,7 @@ template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restrict__ st0, u32 pow_bits, u64 base, u32 max_blocks,
                                                           unsigned long long* __restrict__ result0, u32* __restrict__ counter0,
                                                           u32 B, BatchArg ba, PermCtx ctx) {
-  __shared__ u32 s_dist, s_blk;
+  __shared__ u32 s_dist, s_blk, s_go;
   unsigned p = blockIdx.x % B;
   poseidon_fast::MfmaCtx mc;  // PR == 5: the permutation below runs with every lane of the workgroup active (its guard is workgroup-uniform)
   if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
@@ -225,16 +225,20 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
     const u32 dist = s_dist;
     if (dist == ~0u) return;  // workgroup-uniform
     const u32 q = (p + dist) % B;
-    if (threadIdx.x == 0) s_blk = atomicAdd(bp_at(counter0, ba, q), 1u);
+    unsigned long long* result = bp_at(result0, ba, q);
+    if (threadIdx.x == 0) {  // ONE lane decides for the workgroup: other workgroups lower *result concurrently, and the block below
+                             // holds barriers and MFMAs (every lane must take the same side)
+      const u32 b = atomicAdd(bp_at(counter0, ba, q), 1u);
+      s_blk = b;
+      s_go = b < max_blocks && base + (u64)b * kBlock < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const u32 blk = s_blk;
-    unsigned long long* result = bp_at(result0, ba, q);
-    if (blk < max_blocks && base + (u64)blk * kBlock < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (s_go) {
       const ChState* st = bp_at(st0, ba, q);
       const u64 cand = base + (u64)blk * kBlock + threadIdx.x;
       const u32 n_in = st->n_in;
-      u64 s[12];
-      permute_reloadable<M, PR>(s, ctx, [&](u64 (&t)[12]) {
+      auto load = [&](u64 (&t)[12]) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           u64 v = st->state[k];
@@ -244,7 +248,57 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
           }
           t[k] = v;
         }
-      }, &mc);
+      };
+      u64 s[12];
+      if constexpr (PR == 5) {
+        // All 256 candidates of the block share eleven of the twelve input words, hence eleven of round 0's S-boxes and their
+        // share of its MDS layer: twelve lanes form base[r] = sum_{k != n_in} M[r][k] (t[k] + rc[k])^7 + rc[12 + r] once per block;
+        // a candidate then costs ONE first-round S-box and twelve two-mad rows, and of the last layer only row 7.
+        __shared__ u64 s_y[12], s_base[12];
+        if (threadIdx.x < 12) {
+          const u32 k = threadIdx.x;
+          u64 v = st->state[k];
+          if (k < 8 && k < n_in) v = st->in[k];
+          s_y[k] = k == n_in ? 0 : gl::canon(gl::pow7(gl::add_c(v, ctx.rc[k])));
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+          const u32 r = threadIdx.x;
+          u64 acc = ctx.rc[12 + r];
+#pragma unroll
+          for (u32 k = 0; k < 12; ++k) {
+            const u32 idx = k >= r ? k - r : k + 12 - r;  // MDS[r][k] = CIRC[(k - r) mod 12] (+ 8 at [0][0])
+            const u64 word = idx < 8 ? 0x0D0D1C0210290F11ull : 0x14221227ull;
+            const u64 m = ((word >> (8 * (idx & 7))) & 0xFF) + ((r == 0 && k == 0) ? 8u : 0u);
+            acc = gl::canon(gl::mul_add(s_y[k], m, acc));
+          }
+          s_base[r] = acc;
+        }
+        __syncthreads();
+        u64 sticky = ctx.force_fallback;
+        const u64 y = poseidon_fast::pow7(gl::add_c(cand, ctx.rc[n_in]), sticky);
+        const u32 yl = (u32)y, yh = (u32)(y >> 32);
+#pragma unroll
+        for (u32 r = 0; r < 12; ++r) {
+          const u32 idx = n_in >= r ? n_in - r : n_in + 12 - r;
+          const u64 word = idx < 8 ? 0x0D0D1C0210290F11ull : 0x14221227ull;
+          const u32 m = (u32)((word >> (8 * (idx & 7))) & 0xFF) + ((r == 0 && n_in == 0) ? 8u : 0u);  // wave-uniform
+          const u64 b = s_base[r];
+          const u64 al = (u64)yl * m + (u32)b;
+          u64 ah = (u64)yh * m + (u32)(b >> 32);
+          ah = poseidon_fast::add32((u32)(al >> 32), ah);
+          u64 cm;
+          s[r] = poseidon_fast::mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
+          sticky |= cm;
+        }
+        sticky |= poseidon_fast::permute<false, 12, false, false, false, 3, true, 0, true, 7>(s, ctx.rc, &mc);
+        if (__builtin_expect(sticky != 0, 0)) {  // flagged wave: the exact reference permutation from the full input
+          load(s);
+          poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+        }
+      } else {
+        permute_reloadable<M, PR>(s, ctx, load, &mc);
+      }
       const u64 resp = gl::canon(s[7]);
       if (pow_bits == 0 || (resp >> (64 - pow_bits)) == 0) atomicMin(result, (unsigned long long)cand);
     }

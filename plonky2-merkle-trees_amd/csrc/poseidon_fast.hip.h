@@ -196,6 +196,24 @@ GL_DEV void mds_layer(u64 (&s)[12], P add, u64& sticky) {
   });
 }
 
+// one row of the last layer (no constants): the proof-of-work grind looks at word 7 only
+template <int ROW>
+GL_DEV u64 mds_row(const u64 (&s)[12], u64& sticky) {
+  constexpr u32 k0 = poseidon::mds_entry(ROW, 0);
+  u64 al = mac_const_first0<k0>((u32)s[0]), ah = mac_const_first0<k0>((u32)(s[0] >> 32));
+  poseidon::static_for<1, 12>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    constexpr u32 k = poseidon::mds_entry(ROW, c);
+    mac_const<k>(al, (u32)s[c]);
+    mac_const<k>(ah, (u32)(s[c] >> 32));
+  });
+  ah = add32((u32)(al >> 32), ah);
+  u64 cm;
+  const u64 r = mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
+  sticky |= cm;
+  return r;
+}
+
 // ------------------------------------------------------------------ MDS layer on the matrix pipe (round 3 A/B)
 // The MDS is a 12 x 12 contraction with 6-bit constants.  On 8-bit limbs of the state words it fits
 // v_mfma_i32_4x4x4_16b_i8, whose 16 blocks are independent 4x4x4 products over the lanes 4b..4b+3: with one hash per lane the B
@@ -570,8 +588,10 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
 //   3 = every 12-row dense MDS layer (seven of the 8 full rounds + the last partial round) as one v_mfma_i32_32x32x32_i8 per limb
 //   (mds_layer_mfma32; `mc` from mfma32_ctx_init()), the other partial rounds batched as in P3.
 // P3: the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round.
+// FIRST_DONE: the caller passes the state in front of round 1's S-boxes (it did round 0 itself: the proof-of-work grind shares eleven of
+//   the twelve first-round S-boxes between all candidates of a proof).  LAST_ROW >= 0: only that word of the result is computed.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0>
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
 GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   static_assert(!P3 || (!EXACT && !SPARSE && (MFMA == 0 || MFMA == 3)), "partial_rounds3 belongs to the dense flag form");
   u64 sticky = 0;
@@ -592,7 +612,9 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   };
   static_assert(!LEAF_PAIR || CAP_ZERO, "LEAF_PAIR implies zero capacity words");
   constexpr int kVar = CAP_ZERO ? 8 : 12;
-  if constexpr (LEAF_PAIR) {  // round 0: words 0 and 4 only
+  static_assert(!FIRST_DONE || (!CAP_ZERO && !LEAF_PAIR), "FIRST_DONE: the caller did round 0 itself");
+  if constexpr (FIRST_DONE) {  // s = the state in front of round 1's S-boxes (round 0's MDS layer with round 1's constants in)
+  } else if constexpr (LEAF_PAIR) {  // round 0: words 0 and 4 only
     s[0] = sbox(gl::add_c(s[0], rc[0]));
     s[4] = sbox(gl::add_c(s[4], rc[4]));
 #pragma unroll
@@ -690,15 +712,16 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
-  mds(std::false_type{}, std::integral_constant<int, OUT_ROWS>{}, RC{});
+  if constexpr (LAST_ROW >= 0) s[LAST_ROW] = mds_row<LAST_ROW>(s, sticky);  // only this word of the result is valid
+  else mds(std::false_type{}, std::integral_constant<int, OUT_ROWS>{}, RC{});
   return sticky;
 }
 // `rc` = the GLOBAL constant table (p2mt::perm_ctx().rc), never the LDS copy of the 12-lane layout
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0>
+          bool P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
-  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*, MULV>(s, rc, mc);
-  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab, MULV>(s, as_const_table(rc), mc);
+  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*, MULV, FIRST_DONE, LAST_ROW>(s, rc, mc);
+  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab, MULV, FIRST_DONE, LAST_ROW>(s, as_const_table(rc), mc);
 }
 
 }  // namespace poseidon_fast

@@ -48,6 +48,26 @@ def test_batch_equals_sequential(pkg, oracle, batch):
         assert np.array_equal(g, w)
 
 
+def test_batch_grind_shared_first_round_and_forced_redo(pkg, oracle):
+    """The batch's proof-of-work queue shares eleven of the twelve first-round S-boxes between the candidates of a proof and computes
+    only word 7 of the last layer (k_fri_pow_queue<2, 5>): the witnesses -- hence every proof word -- must stay those of the sequential
+    prove, also with every wave forced onto the exact redo path (the reference permutation from the full input)."""
+    cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, range(560, 566))
+    want = [cd.prove(pw) for pw in pws]
+    bp = pkg.BatchProver(cd, 4)
+    lib = pkg.lib()
+    got = bp.prove(pws)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    try:
+        lib.p2mt_debug_force_fallback(1)
+        got = bp.prove(pws[:4])
+    finally:
+        lib.p2mt_debug_force_fallback(0)
+    for g, w in zip(got, want[:4]):
+        assert np.array_equal(g, w)
+
+
 def test_batch_layouts_agree(pkg, oracle):
     """Throughput mode switches the leaf sponges / Merkle levels to the lane-per-hash layouts; the words do not change."""
     cd, _, _, pws = circuit_and_witnesses(pkg, oracle, 20, range(540, 548))
