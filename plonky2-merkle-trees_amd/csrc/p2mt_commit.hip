@@ -340,8 +340,12 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__
                                                          u64* __restrict__ digests, BatchArg ba, p2mt::PermCtx ctx) {
   in = bp(in, ba);
   digests = bp(digests, ba);
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_pts) return;
+  poseidon_fast::MfmaCtx mc;  // PR == 5: dense MDS layers on the matrix pipe; every lane stays in the sponge (an MFMA ignores EXEC),
+  if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);  // lanes past the end redo the last column and store nothing
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < n_pts;
+  if constexpr (PR == 5) i = live ? i : n_pts - 1;
+  else if (!live) return;
   u64 s[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) s[k] = 0;
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (off + k < w) s[k] = in[(off + k) * n_pts + i];
-        if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute(s, ctx.rc);
+        if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), true>(s, ctx.rc, &mc);
         else if constexpr (M == 2) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
         else poseidon::permute<M, PR>(s);
       }
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__
       run(std::false_type{});
     }
   }
+  if (!live) return;
   ulonglong2* q = reinterpret_cast<ulonglong2*>(digests + 4 * i);
   q[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
   q[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
@@ -938,7 +943,13 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
                        d_level0, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
   } else {
-    P2MT_DISPATCH(k_hash_columns, bgrid(grid_for(big)), kBlock, (const u64*)lde, n_polys, big, d_level0, barg());
+    if (rt().mds == 2 && rt().partial == 0) {  // default: dense MDS layers on the matrix pipe
+      hipLaunchKernelGGL((k_hash_columns<2, 5>), bgrid(grid_for(big)), dim3(kBlock), 0, st, (const u64*)lde, n_polys, big, d_level0, barg(),
+                         p2mt::perm_ctx());
+      P2MT_LAUNCH_CHECK();
+    } else {
+      P2MT_DISPATCH(k_hash_columns, bgrid(grid_for(big)), kBlock, (const u64*)lde, n_polys, big, d_level0, barg());
+    }
   }
   return merkle_levels_to_cap(d_level0, big, cap_height, cap_is_leaves ? nullptr : d_digests_out, d_cap_out);
 }
