@@ -175,6 +175,38 @@ def transfer_times(torch, host_leaves, mmr):
                     "D2H includes allocating and faulting in the destination (what MMR.elements costs a caller)"}
 
 
+def run_merkle_tree(torch, pkg, lib, log_n=24):
+    """simple_merkle_tree::MerkleTree::build (/root/reference/src/simple_merkle_tree/simple_merkle_tree.rs:28-51) at the headline size,
+    device-resident leaves -> device-resident level-major tree + root (p2mt_merkle_build_pow2_dev): stage 1 as per-lane subtrees like the
+    MMR's, level kernels above.  The same 2^24 - 1 hashes as the MMR build of the same leaves, in the reference's other layout."""
+    n = 1 << log_n
+    leaves = pkg.synthetic.bench_leaves(log_n, 0)
+    d_leaves = torch.from_numpy(leaves.view(np.int64)).cuda()
+    d_levels = torch.empty(4 * (2 * n - 2), dtype=torch.int64, device="cuda")
+    d_root = torch.empty(4, dtype=torch.int64, device="cuda")
+
+    def build():
+        pkg._native.check(lib.p2mt_merkle_build_pow2_dev(d_leaves.data_ptr(), n, d_levels.data_ptr(), d_root.data_ptr()))
+        pkg._native.check(lib.p2mt_sync())
+        return d_root.cpu().numpy().view(np.uint64)
+
+    for _ in range(3):
+        root = build()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        root = build()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    # the tree's top two levels hash the same pairs as the MMR of the same leaves: its root is the MMR's single peak
+    m = pkg.MMR()
+    m.reserve(n)
+    m.extend_dev(d_leaves, n)
+    peaks = m.get_peaks()
+    return {"workload": "simple_merkle_tree MerkleTree::build, 2^%d leaves, device-resident leaves and tree" % log_n,
+            "build_ms": float(np.median(ts)), "build_ms_min": float(np.min(ts)), "hashes_per_s": (n - 1) / (float(np.median(ts)) * 1e-3),
+            "root": [int(x) for x in root], "root_equals_mmr_peak": bool(np.array_equal(root, np.asarray(peaks).reshape(-1, 4)[0]))}
+
+
 def run_config2(torch, pkg, lib, cpu_baseline=True):
     """BASELINE.md B3 / BASELINE.json config 2: mmr::merkle_mountain_ranges build + get_proof, 2^20 leaves, 1 GPU -- build from
     device-resident leaves, get_proof + MMR_proof::verify for the four fixed leaves {0, 1, 777 777, 2^20 - 1}
@@ -382,6 +414,11 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
             out["config2_mmr_2pow20"] = run_config2(torch, pkg, lib, cpu_baseline=not args.no_cpu_baseline)
         except Exception as e:  # the headline line must survive a failure of a secondary leg
             out["config2_mmr_2pow20"] = {"error": repr(e)}
+    if world == 1 and not args.no_prove:
+        try:
+            out["simple_merkle_tree_2pow24"] = run_merkle_tree(torch, pkg, lib, 24)
+        except Exception as e:
+            out["simple_merkle_tree_2pow24"] = {"error": repr(e)}
     if world == 1 and not args.no_prove:
         # BASELINE.json's second metric (ms/proof), measured after and outside the timed region above
         import copy

@@ -149,14 +149,75 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__
                                                          BatchArg ba, PermCtx ctx) {
   in = bp(in, ba);
   out = bp(out, ba);
-  const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (j >= n_out) return;
+  // PR == 5 (matrix-pipe MDS, the default of the fast path): an MFMA ignores EXEC and every lane's A operand serves the whole wave,
+  // so no lane leaves before the permutation -- lanes past the end redo the last node and skip the store
+  poseidon_fast::MfmaCtx mc;
+  if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
+  size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = j < n_out;
+  if constexpr (PR == 5) j = live ? j : n_out - 1;
+  else if (!live) return;
   u64 o[4];
   two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
     load_hash(in + 8 * j, l);
     load_hash(in + 8 * j + 4, r);
-  });
-  store_hash(out + 4 * j, o);
+  }, &mc);
+  if (live) store_hash(out + 4 * j, o);
+}
+
+// Stage 1 of a large MerkleTree::build, the level-major twin of k_mmr_subtree (p2mt_mmr.hip): each LANE builds the perfect subtree
+// over its own 2^LV consecutive leaves depth-first -- 2^LV - 1 chained permutations, no barrier, pending left siblings in a per-lane LDS
+// stack -- and writes the leaf digests and every node to their level-major slots (level l of an n-leaf tree starts 2n - (2n >> l)
+// digests into `levels`; a lane's nodes of one level are contiguous).  Matrix-pipe MDS: lanes past the end rebuild the last subtree
+// and store nothing.
+template <unsigned LV>
+__global__ __launch_bounds__(256, 4) void k_merkle_subtree(const u64* __restrict__ leaves, u64* __restrict__ levels, size_t n, PermCtx ctx) {
+  __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][256 * 4];
+  poseidon_fast::MfmaCtx mc;
+  poseidon_fast::mfma32_ctx_init(mc);
+  const size_t n_blocks = n >> LV;
+  size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = blk < n_blocks;
+  blk = live ? blk : n_blocks - 1;
+  const size_t first_leaf = blk << LV;
+  const u64* lp = leaves + first_leaf;
+  auto level_at = [&](unsigned h) -> u64* { return levels + 4 * (2 * n - ((2 * n) >> h)); };
+  u64 cur[4] = {0, 0, 0, 0};
+  unsigned pairs_done = 0, h = 0, merges = 0;
+#pragma unroll 1
+  for (unsigned step = 0; step < (1u << LV) - 1; ++step) {
+    u64 o[4];
+    if (merges == 0) {  // hash the next leaf pair
+      const u64 a = gl::canon(lp[2 * pairs_done]), b = gl::canon(lp[2 * pairs_done + 1]);
+      const size_t leaf = first_leaf + 2 * pairs_done;
+      if (live) {
+        const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
+        store_hash(levels + 4 * leaf, la);  // hash_or_noop([leaf]) = [leaf, 0, 0, 0]
+        store_hash(levels + 4 * (leaf + 1), lb);
+      }
+      two_to_one_r<IMPL_FAST, 5, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+        ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
+        rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
+      }, &mc);
+      merges = (unsigned)__builtin_ctz(~pairs_done);
+      pairs_done += 1;
+      h = 1;
+      if (live) store_hash(level_at(1) + 4 * (leaf >> 1), o);
+    } else {  // merge the pending left sibling of height h with cur
+      const u64* sp = &stack[h - 1][threadIdx.x * 4];
+      two_to_one_r<IMPL_FAST, 5>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
+        load_hash(sp, ll);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rr[k] = cur[k];
+      }, &mc);
+      merges -= 1;
+      h += 1;
+      if (live) store_hash(level_at(h) + 4 * (((first_leaf + 2 * pairs_done) >> h) - 1), o);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = o[k];
+    if (merges == 0 && h < LV) store_hash(&stack[h - 1][threadIdx.x * 4], cur);
+  }
 }
 
 // verify_merkle_proof (:91-109), one proof per lane
@@ -250,6 +311,12 @@ int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
   if (n_all <= ((size_t)1 << 16) && rt().mds == 2 && rt().use_quad) {
     hipLaunchKernelGGL(k_merkle_level_quad, bgrid(grid_for(4 * n_out)), dim3(kBlock), 0, rt().stream, d_in, d_out, n_out,
                        barg(), p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
+  if (rt().mds == 2 && rt().partial == 0) {  // default: dense MDS layers on the matrix pipe
+    hipLaunchKernelGGL((k_merkle_level<2, 5>), bgrid(grid_for(n_out)), dim3(kBlock), 0, rt().stream, d_in, d_out, n_out, barg(),
+                       p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
     return P2MT_OK;
   }
@@ -396,11 +463,28 @@ extern "C" int p2mt_merkle_build_pow2_dev(const uint64_t* d_leaves, size_t n, ui
   const int k = log2_strict(n);
   if (k < 1) return p2mt::fail(P2MT_EINVAL, "MerkleTree::build: leaf count must be a power of two >= 2");
   if (!d_leaves || !d_levels || !d_root) return p2mt::fail(P2MT_EINVAL, "null pointer");
-  hipLaunchKernelGGL(k_leaf_digests, dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_leaves, d_levels, n);
-  P2MT_LAUNCH_CHECK();
   u64* cur = d_levels;
   size_t cur_n = n;
-  for (int i = 0; i < k - 1; ++i) {  // levels 1 .. k-1
+  int i0 = 0;
+  // large trees (the sizes at which the MMR build uses it too): stage 1 as per-lane subtrees -- leaf digests and levels 1..lv in one
+  // barrier-free launch; the level-by-level loop continues above it.  The subtree size adapts to the tree like the MMR's.
+  const unsigned lv = (rt().mds == 2 && rt().partial == 0 && rt().subtree_auto && k >= 18) ? p2mt::subtree_levels_for(n) : 0;
+  if (lv >= 2 && lv <= 4 && (unsigned)k > lv) {
+    const unsigned grid = (unsigned)(((n >> lv) + 255) / 256);
+    if (lv == 4) hipLaunchKernelGGL((k_merkle_subtree<4>), dim3(grid), dim3(256), 0, rt().stream, d_leaves, d_levels, n, p2mt::perm_ctx());
+    else if (lv == 3) hipLaunchKernelGGL((k_merkle_subtree<3>), dim3(grid), dim3(256), 0, rt().stream, d_leaves, d_levels, n, p2mt::perm_ctx());
+    else hipLaunchKernelGGL((k_merkle_subtree<2>), dim3(grid), dim3(256), 0, rt().stream, d_leaves, d_levels, n, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    for (unsigned l = 0; l < lv; ++l) {
+      cur += 4 * cur_n;
+      cur_n /= 2;
+    }
+    i0 = (int)lv;
+  } else {
+    hipLaunchKernelGGL(k_leaf_digests, dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_leaves, d_levels, n);
+    P2MT_LAUNCH_CHECK();
+  }
+  for (int i = i0; i < k - 1; ++i) {  // levels i0 + 1 .. k-1
     u64* next = cur + 4 * cur_n;
     P2MT_TRY(p2mt::launch_merkle_level_dev(cur, next, cur_n / 2));
     cur = next;

@@ -143,6 +143,24 @@ def test_merkle_tree_vs_oracle(pkg, oracle, log_n):
         assert not pkg.verify_merkle_proof(leaves[i], i, t.tree[0][0], pr)           # wrong root
 
 
+@pytest.mark.parametrize("log_n,levels", [(18, 2), (21, 3), (22, 4)])
+def test_merkle_tree_large_subtree_stage(pkg, oracle, log_n, levels):
+    """Large MerkleTree::build: stage 1 as per-lane subtrees of 2^levels leaves (k_merkle_subtree: leaf digests and levels 1..levels in
+    one barrier-free launch, level-major slots, matrix-pipe MDS), the level kernels above it.  Every level and the root against the oracle,
+    proofs for the corner leaves."""
+    n = 1 << log_n
+    leaves = splitmix_leaves(n, 0x5EED0600 + log_n)
+    t = pkg.MerkleTree.build(leaves)
+    k, lv, root = oracle.merkle_build(leaves)
+    assert t.count_levels == k
+    assert np.array_equal(t._flat[:2 * n - 2], lv[:2 * n - 2])
+    assert np.array_equal(t.root, root)
+    for i in (0, 1, n // 2 + 5, n - 1):
+        pr = t.get_merkle_proof(i)
+        assert np.array_equal(pr, oracle.merkle_get_proof(lv, n, i))
+        assert pkg.verify_merkle_proof(leaves[i], i, t.root, pr)
+
+
 def test_merkle_tree_1024_golden(pkg):
     t = pkg.MerkleTree.build(np.arange(1024, dtype=np.uint64))
     assert [int(x) for x in t.root] == [14342627526773219473, 1605964016051269283, 13081912992221981033,
