@@ -34,14 +34,18 @@ __global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict_
 template <int M, int PR>
 __global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
                                                              PermCtx ctx) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+  poseidon_fast::MfmaCtx mc;  // PR == 5: matrix-pipe MDS; every lane stays in the permutation, lanes past the end redo the last pair
+  if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < n;
+  if constexpr (PR == 5) i = live ? i : n - 1;
+  else if (!live) return;
   u64 o[4];
   two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
     load_hash(in + 8 * i, l);
     load_hash(in + 8 * i + 4, r);
-  });
-  store_hash(out + 4 * i, o);
+  }, &mc);
+  if (live) store_hash(out + 4 * i, o);
 }
 
 template <int M, int PR>
@@ -361,6 +365,11 @@ extern "C" int p2mt_two_to_one_batch_dev(const uint64_t* d_in, uint64_t* d_out, 
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
   if (!d_in || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (rt().mds == 2 && rt().partial == 0 && n >= 4096) {  // default, once a launch fills whole waves: dense MDS layers on the matrix pipe
+    hipLaunchKernelGGL((k_two_to_one_batch<2, 5>), dim3(grid_for(n)), dim3(kBlock), 0, rt().stream, d_in, d_out, n, p2mt::perm_ctx());
+    P2MT_LAUNCH_CHECK();
+    return P2MT_OK;
+  }
   P2MT_DISPATCH(k_two_to_one_batch, grid_for(n), kBlock, d_in, d_out, n);
   return P2MT_OK;
   });

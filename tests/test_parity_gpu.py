@@ -110,6 +110,10 @@ def test_two_to_one_and_hash_modes(pkg, oracle):
     got = pkg.two_to_one_batch(pairs)
     for i in range(0, 300, 7):
         assert np.array_equal(got[i], oracle.two_to_one(pairs[i, :4], pairs[i, 4:]))
+    big = rng.integers(0, 1 << 64, size=(4096 + 77, 8), dtype=np.uint64)  # >= 4096 pairs: the matrix-pipe kernel, ragged last wave
+    got = pkg.two_to_one_batch(big)
+    for i in list(range(0, 4096, 97)) + list(range(4096, 4096 + 77)):
+        assert np.array_equal(got[i], oracle.two_to_one(big[i, :4], big[i, 4:]))
     assert [int(x) for x in pkg.two_to_one([2890852870, 0, 0, 0], [156728478, 0, 0, 0])] == [
         6678006133445961348, 15827935749738443865, 6295652393730592048, 1546515167911236130]  # reference :138
     for length in (1, 2, 4, 5, 7, 8, 9, 12, 16, 17, 20, 64, 135):
