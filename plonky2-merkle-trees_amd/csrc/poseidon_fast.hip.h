@@ -345,6 +345,8 @@ GL_DEV void mds_layer_mfma(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) 
 // inline 0) + per row two chains of four v_mad_u64_u32 (18-bit limb sums x 2^(8l), starting at the next round's constant half) + the
 // same 96 -> 64 bit fold: 120 mads against 312 in the VALU form.
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+// Call at kernel entry, with EVERY lane of the wave active (1-D workgroups of whole 64-lane wavefronts): the operand is a function of the
+// lane id, and an MFMA reads it from all 64 lanes whatever EXEC says later.
 GL_DEV void mfma32_ctx_init(MfmaCtx& c) {
   const unsigned l = threadIdx.x & 63, i = l & 31, half = l >> 5, sub = (i >> 2) & 1, v = 4 * (i >> 3) + (i & 3);
   mfma_v4i a = {0, 0, 0, 0};
