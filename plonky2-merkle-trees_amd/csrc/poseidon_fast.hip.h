@@ -437,7 +437,8 @@ constexpr int kP3K = kP3Tab + 84 * kP3Groups;  // per group of three rounds 14 u
 constexpr int kP3W = kP3K + 14 * kP3Groups;    // right behind the addends: u32[14][14] rows for the 12-lane layout -- lane 0: row 0 of M,
                                                // lane 1: row 0 of M^2, lane 2 + r: row r of M^3; then the lane's d1 and d2 coefficients
 constexpr int kP3WaveWords = 14 * kP3Groups + 98;  // what stage_round_constants() copies behind the 360 round constants
-constexpr int kTableWords = kP3W + 98;
+constexpr int kLeafPairK0 = kP3W + 98;         // 12 u64: sum_{k not in {0, 4}} MDS[r][k] (rc[k])^7 + rc[12 + r] (two_to_one of two leaf digests)
+constexpr int kTableWords = kLeafPairK0 + 12;
 
 struct Dot {
   u64 a0l, a0h, a1l, a1h, a2l, a2h;
@@ -616,6 +617,21 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   constexpr int kVar = CAP_ZERO ? 8 : 12;
   static_assert(!FIRST_DONE || (!CAP_ZERO && !LEAF_PAIR), "FIRST_DONE: the caller did round 0 itself");
   if constexpr (FIRST_DONE) {  // s = the state in front of round 1's S-boxes (round 0's MDS layer with round 1's constants in)
+  } else if constexpr (LEAF_PAIR && MFMA == 3) {  // round 0: words 0 and 4 only, and of its MDS layer only their two columns --
+    const u64 y0 = sbox(gl::add_c(s[0], rc[0])), y4 = sbox(gl::add_c(s[4], rc[4]));  // the other ten S-box outputs are constants,
+    const u32 y0l = (u32)y0, y0h = (u32)(y0 >> 32), y4l = (u32)y4, y4h = (u32)(y4 >> 32);  // their share sits in the table
+    poseidon::static_for<0, 12>([&](auto rcst) {
+      constexpr int r = decltype(rcst)::value;
+      constexpr u32 m0 = poseidon::mds_entry(r, 0), m4 = poseidon::mds_entry(r, 4);
+      const u64 c = rc[kLeafPairK0 + r];
+      u64 al = mac_const_first<m0>(y0l, (u64)(u32)c), ah = mac_const_first<m0>(y0h, (u64)(u32)(c >> 32));
+      mac_const<m4>(al, y4l);
+      mac_const<m4>(ah, y4h);
+      ah = add32((u32)(al >> 32), ah);
+      u64 cm;
+      s[r] = mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
+      sticky |= cm;
+    });
   } else if constexpr (LEAF_PAIR) {  // round 0: words 0 and 4 only
     s[0] = sbox(gl::add_c(s[0], rc[0]));
     s[4] = sbox(gl::add_c(s[4], rc[4]));

@@ -249,8 +249,10 @@ extern "C" int p2mt_init(int device) {
     // 22 + 22 + 20 bits in four u32 per constant)
     // and the tables of the batched partial rounds (poseidon_fast.hip.h kP3Tab / kP3K): M^3, row 0 of M^2, M m0 as u32; per
     // group of three rounds the constants c1[0], (M c1 + c2)[0] and M^2 c1 + M c2 + c3 (mod p)
-    static uint64_t table[1372 + 84 * 7 + 14 * 7 + 98];
-    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98 + 98, "layout of poseidon_fast.hip.h");
+    // and, last, for two_to_one of two leaf digests the share of the ten constant first-round S-box outputs in round 0's MDS layer,
+    // with round 1's constants in (poseidon_fast.hip.h kLeafPairK0): 12 words
+    static uint64_t table[1372 + 84 * 7 + 14 * 7 + 98 + 12];
+    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98 + 98 + 12, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
     memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
     memcpy(table + 382, POSEIDON_FAST_K, sizeof(POSEIDON_FAST_K));
@@ -325,6 +327,22 @@ extern "C" int p2mt_init(int device) {
       const unsigned __int128 p = 0xFFFFFFFF00000001ULL;
       unsigned __int128 x = POSEIDON_RC[word_of[i]], x2 = x * x % p, x4 = x2 * x2 % p, x3 = x2 * x % p;
       table[360 + i] = (uint64_t)(x4 * x3 % p);
+    }
+    {  // kLeafPairK0[r] = sum_{k not in {0, 4}} MDS[r][k] (rc[k])^7 + rc[12 + r]  (mod p)
+      typedef unsigned __int128 u128;
+      const u128 p = 0xFFFFFFFF00000001ULL;
+      const uint64_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+      uint64_t y[12] = {0};
+      for (int i = 0; i < 10; ++i) y[word_of[i]] = table[360 + i];
+      for (int r = 0; r < 12; ++r) {
+        u128 a = POSEIDON_RC[12 + r];
+        for (int k = 0; k < 12; ++k) {
+          if (k == 0 || k == 4) continue;
+          const uint64_t m = circ[((k - r) % 12 + 12) % 12] + ((r == 0 && k == 0) ? 8 : 0);
+          a = (a + (u128)m * y[k]) % p;
+        }
+        table[1372 + 84 * 7 + 14 * 7 + 98 + r] = (uint64_t)a;
+      }
     }
     P2MT_HIP(hipMalloc((void**)&rt().d_rc, sizeof(table)));
     P2MT_HIP(hipMemcpy(rt().d_rc, table, sizeof(table), hipMemcpyHostToDevice));
