@@ -673,9 +673,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
                      m->elements, block0, n_blocks, p2mt::perm_ctx())
       if (sub_lv == 3) P2MT_SUB4(3, 5);
       else if (sub_lv == 2) P2MT_SUB4(2, 5);
-#ifndef P2MT_DEV_FEWER_VARIANTS  // (developer builds leave the rarely used instantiations out: this file takes 5 min otherwise)
-      else if (sub_lv == 5) { if (sb == 64) P2MT_SUB(5, 64, 0); else P2MT_SUB(5, 256, 0); }
-#endif
+      else if (sub_lv == 5) P2MT_SUB4(5, 5);
       else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
       else if (variant == 5) P2MT_SUB4(4, 0);      // VALU MDS in the full rounds too (A/B: p2mt_set_variant(2, 5))
       else if (variant == 6) P2MT_SUB4(4, 6);      // ... and the previous field multiply (A/B: p2mt_set_variant(2, 6))
