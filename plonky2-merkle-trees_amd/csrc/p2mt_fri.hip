@@ -1102,7 +1102,21 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     qa.per_query = p->num_query_rounds ? (off_final - p->num_reductions * cap_words) / p->num_query_rounds : 0;
     const bool quad_grind = rt().mds == 2 && rt().use_quad && !rt().force_fallback && !rt().throughput && B == 1;
     const u64 batch_chunk = std::max<u64>(chunk, (u64)1 << (p->proof_of_work_bits + 4 < 32 ? p->proof_of_work_bits + 4 : 32));
+    // A single proof's chunk of 2^17 candidates on the same queue kernel: 512 workgroups, one block each = two wavefronts per SIMD of the
+    // one-hash-per-lane permutation (shared first round, matrix-pipe MDS, one word of the last layer) instead of eight of the
+    // four-lanes-per-hash one.  (env P2MT_GRIND_QUEUE=0: the four-lane kernel, for A/B.)
+    static const bool queue_knob = [] { const char* e = getenv("P2MT_GRIND_QUEUE"); return e ? atoi(e) != 0 : true; }();
+    const bool single_queue = B == 1 && queue_knob && rt().mds == 2 && rt().partial == 0 && !rt().throughput;
     auto grind = [&](u64 base) -> int {
+      if (single_queue) {
+        P2MT_TRY(p2mt::batch_fill(ws + o_cnt, 0, 8));
+        const u32 max_blocks = (u32)(chunk / kBlock);
+        hipLaunchKernelGGL((k_fri_pow_queue<2, 5>), dim3(max_blocks), dim3(kBlock), 0, st, (const ChState*)ch->d,
+                           (u32)p->proof_of_work_bits, base, max_blocks, d_wit, reinterpret_cast<u32*>(ws + o_cnt), 1u, barg(),
+                           p2mt::perm_ctx());
+        P2MT_LAUNCH_CHECK();
+        return P2MT_OK;
+      }
       if (B > 1) {  // one resident grid serves every proof of the batch (k_fri_pow_queue)
         P2MT_TRY(p2mt::batch_fill(ws + o_cnt, 0, 8));
         const u32 max_blocks = (u32)(batch_chunk / kBlock);

@@ -699,6 +699,7 @@ def test_device_resident_proof_service(pkg, oracle):
     {"P2MT_SUBTREE_OCC": "3"},                          # stage 1 at the allocator's own three waves per SIMD
     {"P2MT_SUBTREE_BLOCK": "64"},
     {"P2MT_SUBTREE_BLOCK": "128"},
+    {"P2MT_GRIND_QUEUE": "0"},                          # single-proof proof-of-work on the four-lane kernel instead of the queue kernel
     {"P2MT_QUAD": "0", "P2MT_LDE12": "0"},              # no four-lane kernels, radix-2 LDE at 2^12
     {"P2MT_THROUGHPUT": "1"},                           # lane-efficient layouts instead of the latency-optimised ones
     {"P2MT_WITNESS_LDS": "0"},                          # witness value table in global memory (dataflow interpreter)
