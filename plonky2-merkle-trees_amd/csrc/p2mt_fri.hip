@@ -208,27 +208,36 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
   unsigned p = blockIdx.x % B;
   poseidon_fast::MfmaCtx mc;  // PR == 5: the permutation below runs with every lane of the workgroup active (its guard is workgroup-uniform)
   if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
+  // counter0 == nullptr: one proof, one block per workgroup (block = blockIdx.x), no queue -- a single proof's chunk needs no counter
+  const bool oneshot = counter0 == nullptr;
+  bool first = true;
 #pragma unroll 1
   for (;;) {
-    if (threadIdx.x == 0) s_dist = ~0u;
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < B; k += kBlock) {  // distance to the next proof with unassigned candidates below its witness
-      const u32 q = (p + k) % B;
-      const u64 r = __hip_atomic_load(bp_at(result0, ba, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u32 nb = __hip_atomic_load(bp_at(counter0, ba, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (nb < max_blocks && base + (u64)nb * kBlock < r) {
-        atomicMin(&s_dist, k);
-        break;
+    u32 dist = 0;
+    if (oneshot) {
+      if (!first) return;
+      first = false;
+    } else {
+      if (threadIdx.x == 0) s_dist = ~0u;
+      __syncthreads();
+      for (u32 k = threadIdx.x; k < B; k += kBlock) {  // distance to the next proof with unassigned candidates below its witness
+        const u32 q = (p + k) % B;
+        const u64 r = __hip_atomic_load(bp_at(result0, ba, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 nb = __hip_atomic_load(bp_at(counter0, ba, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nb < max_blocks && base + (u64)nb * kBlock < r) {
+          atomicMin(&s_dist, k);
+          break;
+        }
       }
+      __syncthreads();
+      dist = s_dist;
+      if (dist == ~0u) return;  // workgroup-uniform
     }
-    __syncthreads();
-    const u32 dist = s_dist;
-    if (dist == ~0u) return;  // workgroup-uniform
-    const u32 q = (p + dist) % B;
+    const u32 q = oneshot ? 0 : (p + dist) % B;
     unsigned long long* result = bp_at(result0, ba, q);
     if (threadIdx.x == 0) {  // ONE lane decides for the workgroup: other workgroups lower *result concurrently, and the block below
                              // holds barriers and MFMAs (every lane must take the same side)
-      const u32 b = atomicAdd(bp_at(counter0, ba, q), 1u);
+      const u32 b = oneshot ? blockIdx.x : atomicAdd(bp_at(counter0, ba, q), 1u);
       s_blk = b;
       s_go = b < max_blocks && base + (u64)b * kBlock < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1109,11 +1118,9 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     const bool single_queue = B == 1 && queue_knob && rt().mds == 2 && rt().partial == 0 && !rt().throughput;
     auto grind = [&](u64 base) -> int {
       if (single_queue) {
-        P2MT_TRY(p2mt::batch_fill(ws + o_cnt, 0, 8));
         const u32 max_blocks = (u32)(chunk / kBlock);
         hipLaunchKernelGGL((k_fri_pow_queue<2, 5>), dim3(max_blocks), dim3(kBlock), 0, st, (const ChState*)ch->d,
-                           (u32)p->proof_of_work_bits, base, max_blocks, d_wit, reinterpret_cast<u32*>(ws + o_cnt), 1u, barg(),
-                           p2mt::perm_ctx());
+                           (u32)p->proof_of_work_bits, base, max_blocks, d_wit, (u32*)nullptr, 1u, barg(), p2mt::perm_ctx());
         P2MT_LAUNCH_CHECK();
         return P2MT_OK;
       }
