@@ -603,7 +603,9 @@ __global__ __launch_bounds__(kBlock) void k_debug_field_op(int op, const u64* __
     case 5: r = lde12::sub_l(a[i], b[i], sticky); break;
     case 6: r = gl::mul(a[i], b[i]); break;                                                // the generic multiply of every prover kernel
     case 7: r = gl::mul_add(a[i], b[i], ((a[i] << 17) | (a[i] >> 47)) ^ b[i]); break;      // a b + c, c = rotl(a, 17) ^ b
-    default: r = poseidon_fast::mul(a[i], b[i], sticky); break;                            // flag form: right unless flagged
+    case 8: r = poseidon_fast::mul(a[i], b[i], sticky); break;                             // flag form: right unless flagged
+    case 9: r = poseidon_fast::sub_any(a[i], b[i]); break;                                 // a - b mod p, any operands, exact
+    default: r = poseidon_fast::sub_flag(a[i], b[i], sticky); break;                       // ... the second wrap left to the flag
   }
   out[i] = gl::canon(r);
   flag[i] = (uint8_t)((sticky >> lane) & 1);
@@ -614,7 +616,7 @@ extern "C" int p2mt_debug_field_op(int op, const uint64_t* a, const uint64_t* b,
   return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
-  if (!a || !b || !out || !flag_out || op < 0 || op > 8) return p2mt::fail(P2MT_EINVAL, "bad argument");
+  if (!a || !b || !out || !flag_out || op < 0 || op > 10) return p2mt::fail(P2MT_EINVAL, "bad argument");
   DevBuf ba, bb, bo, bf;
   P2MT_TRY(ba.alloc(n * 8));
   P2MT_TRY(bb.alloc(n * 8));

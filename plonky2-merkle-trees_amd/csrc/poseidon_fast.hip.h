@@ -490,14 +490,27 @@ GL_DEV u64 mul_add_flag(u64 x, u64 k, u64 c, u64& sticky) {
 // instructions in MDS layers, two thirds of them in the partial rounds.  (plonky2's own "fast" partial rounds trade the MDS for ~22
 // full 64 x 64 multiplications per round -- right for a CPU, measured 2.3 % slower here, profiles/r02_sparse_flag_form_ab.txt.)
 // Folds are the exact form: the top word of a row reaches 2^26 here, too often for the flag.
+// (hi:lo) = a - b as two words, borrow-out as a lane mask
+GL_DEV u64 sub64_borrow(u64 a, u64 b, u64& borrow) {
+  u32 lo, hi;
+  asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\tv_subb_co_u32_e64 %1, %2, %4, %6, %2"
+      : "=&v"(lo), "=v"(hi), "=&s"(borrow)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)));
+  return ((u64)hi << 32) | lo;
+}
 GL_DEV u64 sub_any(u64 a, u64 b) {  // a - b mod p for any u64 a, b; loose result
-  u64 d = a - b;
-  if (a < b) {  // wrapped by +2^64 == +EPS (mod p): take it back; a second time if that wraps too (d < EPS: b within 2^32 of 2^64)
-    const bool again = d < gl::EPS;
-    d -= gl::EPS;
-    if (again) d -= gl::EPS;
-  }
-  return d;
+  u64 m, m2, m3;
+  const u64 d = sub64_borrow(a, b, m);                 // wrapped by +2^64 == +EPS (mod p) in lanes of m: take it back ...
+  const u64 d2 = sub32_borrow(d, eps_if(m), m2);       // ... a second time if that wraps too (d < EPS: b within 2^32 of 2^64)
+  return sub32_borrow(d2, eps_if(m2), m3);
+}
+// the same with the second wrap (probability 2^-32) left to the sticky flag
+GL_DEV u64 sub_flag(u64 a, u64 b, u64& sticky) {
+  u64 m, m2;
+  const u64 d = sub64_borrow(a, b, m);
+  const u64 d2 = sub32_borrow(d, eps_if(m), m2);
+  sticky |= m2;
+  return d2;
 }
 // acc += a * k, k wave-uniform (SGPR)
 GL_DEV void mac_s(u64& acc, u32 a, u32 k) {
@@ -505,7 +518,7 @@ GL_DEV void mac_s(u64& acc, u32 a, u32 k) {
   asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(unused) : "v"(a), "s"(k));
 }
 template <typename P, typename Sbox>
-GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
+GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox, u64& sticky) {
   // The 168 matrix words are the same for every group, but each group reads ITS OWN copy of them: hoisted out of the loop they
   // would sit in SGPRs spilled to VGPR lanes (274 v_readlane per group), and behind an offset the optimiser cannot see through they
   // become vector loads (no proof that the kernel's stores leave them alone); a copy per group is a plain loop-variant scalar load.
@@ -536,7 +549,7 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
     });
     x1 = finish(al, ah);
   }
-  const u64 d1 = sub_any(sbox(x1), x1);
+  const u64 d1 = sub_flag(sbox(x1), x1, sticky);
   const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
   // v2[0] = row 0 of M^2 y + d1 m0[0] + K2
   u64 x2;
@@ -552,7 +565,7 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox) {
     }
     x2 = finish(al, ah);
   }
-  const u64 d2 = sub_any(sbox(x2), x2);
+  const u64 d2 = sub_flag(sbox(x2), x2, sticky);
   const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
   // v3 = M^3 y + d1 (M m0) + d2 m0 + K3
   poseidon::static_for<0, 12>([&](auto rcst) {
@@ -709,7 +722,7 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   } else if constexpr (P3) {
     static_assert(POSEIDON_PARTIAL_ROUNDS == 3 * kP3Groups + 1, "7 groups of three + one round");
 #pragma unroll 1
-    for (int g = 0; g < kP3Groups; ++g) partial_rounds3(s, rc, g, sbox);
+    for (int g = 0; g < kP3Groups; ++g) partial_rounds3(s, rc, g, sbox, sticky);
     {
       constexpr int r = POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS - 1;
       s[0] = sbox(s[0]);

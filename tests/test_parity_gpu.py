@@ -567,6 +567,11 @@ def test_field_primitives_rare_paths(pkg):
     out, flag = run(8)                                                             # flag-form multiply of the permutation
     assert all(o == x * y % P for o, x, y, f in zip(out, A, B, flag) if not f)
     assert flag.sum() < len(A) // 4
+    out, _ = run(9)
+    assert out == [(x - y) % P for x, y in zip(A, B)]                              # a - b for any operands (both wraps taken back)
+    out, flag = run(10)                                                            # ... the second wrap left to the flag
+    assert all(o == (x - y) % P for o, x, y, f in zip(out, A, B, flag) if not f)
+    assert 0 < flag.sum() < len(A) // 8
     for op, fn in ((4, lambda x, y: (x + y) % P), (5, lambda x, y: (x - y) % P)):  # loose add / sub of the LDE kernel
         out, flag = run(op)
         assert all(o == fn(x, y) for o, x, y, f in zip(out, A, B, flag) if not f)
