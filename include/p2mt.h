@@ -236,6 +236,11 @@ int p2mt_coset_lde_batch(const uint64_t *coeffs /*[n_polys][2^log_n]*/, unsigned
                          uint64_t shift, size_t n_polys, uint64_t *out /*[n_polys][2^(log_n+rate_bits)]*/);
 int p2mt_coset_lde_batch_dev(const uint64_t *d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
                              size_t n_polys, uint64_t *d_out);
+/* The same LDE in the order PolynomialBatch keeps it (and the one the kernel produces in a single pass over HBM, 8 B read +
+ * 8 * 2^rate_bits B written per coefficient): d_out[j][brev(i)] = f_j(shift * w^i), i.e. the point index bit-reversed over
+ * log_n + rate_bits bits, polynomial-major.  Enqueues on the library stream and returns (no synchronisation). */
+int p2mt_coset_lde_leaf_order_dev(const uint64_t *d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                                  size_t n_polys, uint64_t *d_out);
 /* MerkleTree::new(leaves, cap_height): n = 2^k leaves of `width` elements (row-major n x width).
  * digests_out: level-major, level 0 = leaf digests, levels 0..k-cap_height-1; may be NULL.  cap_out: 2^cap_height. */
 int p2mt_merkle_cap_commit(const uint64_t *leaves, size_t n, size_t width, unsigned cap_height,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "p2mt_ntt_batch_dev": (C.c_int, [voidp, C.c_uint, C.c_size_t, C.c_int]),
     "p2mt_coset_lde_batch": (C.c_int, [voidp, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t, voidp]),
     "p2mt_coset_lde_batch_dev": (C.c_int, [voidp, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t, voidp]),
+    "p2mt_coset_lde_leaf_order_dev": (C.c_int, [voidp, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t, voidp]),
     "p2mt_merkle_cap_commit": (C.c_int, [voidp, C.c_size_t, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_merkle_cap_commit_dev": (C.c_int, [voidp, C.c_size_t, C.c_size_t, C.c_uint, voidp, voidp]),
     "p2mt_merkle_digests_to_plonky2_layout": (C.c_int, [voidp, C.c_size_t, C.c_uint, voidp]),

@@ -21,6 +21,7 @@
 //     plonky2's leaf-major `leaves` is only produced when the caller asks for it.
 //   All of it is HBM/LDS-bound integer work: no MFMA.
 #include "tree_common.hip.h"
+#include "ntt_arith.hip.h"
 
 #include <map>
 #include <mutex>
@@ -318,6 +319,125 @@ __global__ __launch_bounds__(kBlock) void k_coset_lde12(const u64* __restrict__ 
   }
 }
 
+// Round-4 form of the same kernel: identical data flow and LDS layouts, but
+//   * the radix-16 butterflies use no multiplier: plonky2's w_16 is 2^156 = -2^60, so all their twiddles are +-2^(12 e) and
+//     cost a shift + fold (5-7 issue slots instead of 12; ntt_arith.hip.h);
+//   * every field operation is one asm block that keeps its carries to itself (no SGPR spills: the round-3 kernel spent a
+//     quarter of its VALU instructions on v_readlane / v_writelane of spilled carry masks);
+//   * the pass twiddles come from tables laid out in access order -- TA[r][t] = w^(t brev4(r)), TB[r][u] = w^(16 u brev4(r)) -- so a
+//     wave's load is 512 contiguous bytes (round 3 gathered w^(t brev4(r)) from the natural-order table: up to 60 cache lines per
+//     wave-load, 30 such loads per thread, which is what the kernel actually waited for);
+//   * the eight cosets of a polynomial go to the SAME XCD (blocks b, b + 8, ... share an L2 under the round-robin dispatch), so
+//     its 32 KB of coefficients leave HBM / the fabric once instead of once per coset.  Placement is for speed only;
+//   * global (not flat) loads and stores, 16 bytes per lane on the way out.
+typedef const u64 __attribute__((address_space(1)))* gcptr;
+typedef u64 __attribute__((address_space(1)))* gptr;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef u64x2 __attribute__((address_space(1)))* gptr2;
+GL_DEV gcptr as_global(const u64* p) { return (gcptr)(unsigned long long)p; }
+GL_DEV gptr as_global(u64* p) { return (gptr)(unsigned long long)p; }
+
+// ta[(r - 1) * 256 + t] = w_4096^(t brev4(r)), tb[(r - 1) * 16 + u] = w_4096^(16 u brev4(r)), r = 1..15
+__global__ __launch_bounds__(kBlock) void k_lde12_tables(const u64* __restrict__ tw_full, u64* __restrict__ ta, u64* __restrict__ tb) {
+  const unsigned t = threadIdx.x, r = blockIdx.x + 1;
+  ta[(r - 1) * 256 + t] = tw_full[(t * lde12::brev4(r)) & 4095];
+  if (t < 16) tb[(r - 1) * 16 + t] = tw_full[(16 * t * lde12::brev4(r)) & 4095];
+}
+
+__global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restrict__ coeffs_, unsigned rate_bits, unsigned n_polys,
+                                                              const u64* __restrict__ coset_pow, const u64* __restrict__ ta_,
+                                                              const u64* __restrict__ tb_, const u64* __restrict__ tw_half,
+                                                              u64* __restrict__ out_, BatchArg ba) {
+  using namespace lde12;
+  __shared__ __attribute__((aligned(16))) u64 buf[16 * kRowA];
+  const unsigned t = threadIdx.x;
+  // block -> (poly, coset): groups of 8 polynomials x 2^rate_bits cosets; inside a group block g = j * 8 + (poly % 8), so the
+  // cosets of one polynomial are 8 blocks apart.  The last (partial) group keeps the plain order.
+  unsigned poly, j;
+  {
+    const unsigned cosets = 1u << rate_bits, group = 8u << rate_bits;
+    const unsigned g0 = (blockIdx.x / group) * 8, r = blockIdx.x % group;
+    if (g0 + 8 <= n_polys) {
+      poly = g0 + (r & 7);
+      j = r >> 3;
+    } else {
+      poly = g0 + r / cosets;
+      j = r % cosets;
+    }
+  }
+  const gcptr c = as_global(bp(coeffs_, ba)) + ((size_t)poly << 12);
+  const gcptr cp = as_global(coset_pow) + ((size_t)j << 12);
+  const gcptr ta = as_global(ta_), tb = as_global(tb_);
+  const gptr o = as_global(bp(out_, ba)) + ((size_t)poly << (12 + rate_bits)) + ((size_t)brev32(j, rate_bits) << 12);
+  u64 sticky = 0;
+  u64 x[16];
+  // ---- pass A.  All loads of a pass are issued before its arithmetic (the field operations are ordered asm blocks: left to
+  // itself the scheduler sinks each load to its use and the wave pays one memory round trip per coefficient).
+  u64 tw[16];
+  {
+    u64 pw[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      x[k] = c[t + 256 * k];
+      pw[k] = cp[t + 256 * k];
+    }
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tw[r] = ta[(r - 1) * 256 + t];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ntt::mul(x[k], pw[k], sticky);
+  }
+  ntt::dif16<156>(x, sticky);
+  poseidon::static_for<1, 16>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    x[r] = ntt::mul(x[r], tw[r], sticky);
+  });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[r * kRowA + t] = x[r];
+  __syncthreads();
+  // ---- pass B: thread (r, u)
+  const unsigned rr = t >> 4, u = t & 15;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) x[v] = buf[rr * kRowA + u + 16 * v];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) tw[r] = tb[(r - 1) * 16 + u];
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  ntt::dif16<156>(x, sticky);
+  poseidon::static_for<1, 16>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    x[r] = ntt::mul(x[r], tw[r], sticky);
+  });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[((rr * 16 + r) * kRowC) + u] = x[r];  // [r][r'][u], rows of 17
+  __syncthreads();
+  // ---- pass C: thread (r, r') = t
+#pragma unroll
+  for (int v = 0; v < 16; ++v) x[v] = buf[t * kRowC + v];
+  __syncthreads();
+  ntt::dif16<156>(x, sticky);
+  // results of thread t are DIF positions 16 t + r'': transpose through LDS for contiguous stores
+#pragma unroll
+  for (int r = 0; r < 16; ++r) buf[t * kRowC + r] = gl::canon(x[r]);
+  __syncthreads();
+  if (__builtin_expect(__syncthreads_or(sticky != 0), 0)) {  // rare: the whole workgroup redoes it exactly
+    for (unsigned m = t; m < 4096; m += kBlock) buf[m] = cmul(c[m], cp[m]);
+    __syncthreads();
+    lds_dif(buf, 12, 0, tw_half);
+    for (unsigned q = t; q < 4096; q += kBlock) o[q] = buf[q];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned q = i * 512 + 2 * t;  // q even: q and q + 1 sit in the same padded row of 16
+    const u64* src = &buf[(q >> 4) * kRowC + (q & 15)];
+    u64x2 v;
+    v.x = src[0];
+    v.y = src[1];
+    *(gptr2)(o + q) = v;
+  }
+}
+
 // ---------------------------------------------------------------- leaves
 // Poly-major [w][n_pts] -> leaf-major [n_pts][w] through a 32x32 LDS tile (+1 pad: conflict-free column reads).
 __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in, u64* __restrict__ out, size_t w,
@@ -541,6 +661,23 @@ int get_full_twiddles(unsigned log_n, const u64** out) {
   return P2MT_OK;
 }
 
+// the pass twiddles of k_coset_lde12_v2 in access order (built once from the natural-order table)
+int get_lde12_tables(const u64* tw_full, const u64** ta, const u64** tb) {
+  std::lock_guard<std::mutex> lock(tables_mutex());
+  static u64* d = nullptr;
+  if (!d) {
+    u64* p = nullptr;
+    if (hipMalloc((void**)&p, (15 * 256 + 15 * 16) * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
+    hipLaunchKernelGGL(k_lde12_tables, dim3(15), dim3(kBlock), 0, p2mt::rt().stream, tw_full, p, p + 15 * 256);
+    P2MT_LAUNCH_CHECK();
+    P2MT_HIP(hipStreamSynchronize(p2mt::rt().stream));
+    d = p;
+  }
+  *ta = d;
+  *tb = d + 15 * 256;
+  return P2MT_OK;
+}
+
 int get_coset_pows(unsigned log_n, unsigned rate_bits, u64 shift, const u64** out) {
   std::lock_guard<std::mutex> lock(tables_mutex());
   auto key = std::make_tuple(log_n, rate_bits, shift);
@@ -683,8 +820,15 @@ int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned
   if (log_n == 12 && rt().use_lde12) {
     const u64* twf;
     P2MT_TRY(get_full_twiddles(12, &twf));
-    hipLaunchKernelGGL(k_coset_lde12, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
-                       rate_bits, cp, twf, tw, d_out, barg());
+    if (rt().use_lde12 == 1) {  // the round-3 kernel, kept for the A/B (P2MT_LDE12=1)
+      hipLaunchKernelGGL(k_coset_lde12, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
+                         rate_bits, cp, twf, tw, d_out, barg());
+    } else {
+      const u64 *ta, *tb;
+      P2MT_TRY(get_lde12_tables(twf, &ta, &tb));
+      hipLaunchKernelGGL(k_coset_lde12_v2, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
+                         rate_bits, (unsigned)n_polys, cp, ta, tb, tw, d_out, barg());
+    }
   } else {
     hipLaunchKernelGGL(k_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,
                        d_coeffs, log_n, rate_bits, cp, tw, d_out, barg());
@@ -710,6 +854,16 @@ extern "C" int p2mt_coset_lde_batch_dev(const uint64_t* d_coeffs, unsigned log_n
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   return P2MT_OK;
+  });
+}
+
+extern "C" int p2mt_coset_lde_leaf_order_dev(const uint64_t* d_coeffs, unsigned log_n, unsigned rate_bits, uint64_t shift,
+                                             size_t n_polys, uint64_t* d_out) {
+  return p2mt::abi_guard([&]() -> int {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n_polys == 0) return P2MT_OK;
+  if (!d_coeffs || !d_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  return p2mt::coset_lde_leaf_order_dev(d_coeffs, log_n, rate_bits, shift, n_polys, d_out);
   });
 }
 

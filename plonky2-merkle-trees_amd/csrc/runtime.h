@@ -44,7 +44,7 @@ struct Runtime {
   unsigned subtree_levels = 4;  // stage 1 as per-lane subtrees of 2^L leaves (env P2MT_SUBTREE=2|3|4|5 pins L); 0 = fused tiles
   bool subtree_auto = true;     // no P2MT_SUBTREE in the environment: L adapts to the size of the build (subtree_levels_for)
   int throughput = 0;        // p2mt_set_throughput_mode: prefer lane-efficient layouts over the latency-optimised ones
-  int use_lde12 = 1;         // register-blocked 2^12 LDE kernel (env P2MT_LDE12=0 selects the generic radix-2 one)
+  int use_lde12 = 2;         // register-blocked 2^12 LDE kernel: 2 = round-4 form (shift twiddles), 1 = round-3 form, 0 = generic radix-2 (env P2MT_LDE12)
   unsigned tile_log = 10;    // fused MMR stage: 2^tile_log inputs per workgroup (env P2MT_TILE_LOG = 9|10|11)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // per-kernel HIP-event profiling of the dominant launches (p2mt_profile_*): pairs recorded around each launch

@@ -353,7 +353,7 @@ extern "C" int p2mt_init(int device) {
   }
   if (const char* e = getenv("P2MT_QUAD")) rt().use_quad = atoi(e) != 0;
   if (const char* e = getenv("P2MT_THROUGHPUT")) rt().throughput = atoi(e) != 0;
-  if (const char* e = getenv("P2MT_LDE12")) rt().use_lde12 = atoi(e) != 0;
+  if (const char* e = getenv("P2MT_LDE12")) rt().use_lde12 = atoi(e);
   if (const char* e = getenv("P2MT_SUBTREE_BLOCK")) {
     const int v = atoi(e);
     if (v == 64 || v == 128 || v == 256) rt().subtree_block = (unsigned)v;
