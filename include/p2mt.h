@@ -95,7 +95,9 @@ int p2mt_debug_witness_trace(struct p2mt_circuit_data *c, int enable, uint64_t *
  * op 4 / 5: loose add / sub of the LDE kernel (flag_out as in op 2);  op 6: a[i] * b[i] with gl::mul (the generic multiply of the
  * prover kernels);  op 7: gl::mul_add(a, b, c) with c = rotl(a, 17) ^ b;  op 8: the flag-form multiply of the one-hash-per-lane
  * permutation (flag_out as in op 2);  op 9: a[i] - b[i] mod p for any operands, exact;  op 10: the same with its second wrap left
- * to the flag (flag_out as in op 2).  Results are canonicalised. */
+ * to the flag (flag_out as in op 2);  op 11 / 12 / 13: add / sub / multiply of the transform kernels (ntt_arith.hip.h; flag_out as in
+ * op 2);  op 14 / 15: the sum / the difference out of their fused butterfly;  op 16 + E, E in [0, 192): a[i] * 2^E by shifts
+ * (2^96 = -1; flag_out as in op 2).  Results are canonicalised. */
 int p2mt_debug_field_op(int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out, uint8_t *flag_out);
 /* Per-launch HIP-event timing of the dominant kernels (the fused MMR tile stage; the LDE / leaf-sponge kernels of
  * the commit step): enable, run, then read the summed duration and the number of launches recorded. */

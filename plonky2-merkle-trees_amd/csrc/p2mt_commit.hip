@@ -26,6 +26,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <utility>
 
 using gl::u32;
 using gl::u64;
@@ -438,6 +439,197 @@ __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restr
   }
 }
 
+// ---------------------------------------------------------------- 2^20-point transforms: two passes over HBM (four-step)
+// n = 2^20 = 1024 x 1024, i = i1 1024 + i2, k = k1 + 1024 k2:
+//   pass 1  for every column i2:  A[k1][i2] = w_n^(i2 k1) sum_i1 x[i1][i2] w_1024^(i1 k1)      (1024-point transforms down the columns)
+//   pass 2  for every row k1:     X[k1 + 1024 k2] = sum_i2 A[k1][i2] w_1024^(i2 k2)            (1024-point transforms along the rows)
+// LDS holds 2^14 points at most, so two passes is the minimum for this size: 32 B of HBM traffic per point against the 16 B of a
+// transform that fits; each pass kernel below moves its 16 B per point exactly once.
+// One kernel does both passes.  A workgroup of 1024 threads owns a tile of 1024 points x 16 transforms (128 KB: one per CU), every
+// thread 16 points, and the 1024-point DIF is radix 16 x 16 x 4 in registers with two exchanges through LDS:
+//   step A  thread (p_lo, q): points p = 64 k + p_lo, DIF-16 over k; slot a *= w_1024^(p_lo brev4(a))           -> LDS
+//   step B  thread (d, a, q): points p = 64 a + 4 b + d, DIF-16 over b; slot b' *= w_64^(d brev4(b')), d = t >> 8 wave-uniform
+//                                                                                                                -> LDS, in place
+//   step C  thread (beta, a, q): four DIF-4 over d for b' = 4 beta .. 4 beta + 3; slot (a, b', d') is frequency
+//           k = brev2(d') 256 + brev4(b') 16 + brev4(a); pass 1 multiplies by the four-step twiddle; out[k][q].
+// What differs between the passes is only which index is contiguous in memory on the way IN: pass 1 reads 16 neighbouring columns
+// (128-byte granules, one row apart), pass 2 reads 16 whole rows (8 KB runs).  Both write out[k][q0 + q]: 128-byte granules, so
+// pass 2 lands the result in natural order (X[k1 + 1024 k2] with k1 = q0 + q) with no transpose pass.  The two arrays must differ
+// for pass 2 (it reads rows and writes columns); pass 1 may run in place.
+// LDS layout for both exchanges: word(a, p_lo, q) = a * 1104 + p_lo * 17 + q (p_lo = 4 b + d): conflict-free for the writers of
+// step A in either load mapping (lanes along q or along p_lo: stride 17) and for the (a, q)-lane readers / writers of steps B
+// and C (1104 = 16 mod 32: the two values of a in a half-wave take the two halves of the banks).
+// Algorithmic traffic per launch: 16 B per point (+ 8 B per point of twiddles in pass 1, from a table all transforms share).
+namespace ntt20 {
+
+constexpr unsigned kRowA = 1104;             // words per a-plane: 64 * 17 + 16
+constexpr unsigned kTile = 16;               // transforms per workgroup
+constexpr unsigned kLdsWords = 16 * kRowA;   // 141 312 B
+
+constexpr unsigned brev4(unsigned r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// x *= 2^E for an exponent modulo 192 (2^96 = -1: the upper half costs a negation p - y, y > p flags)
+template <int E>
+GL_DEV u64 mul_pow2_mod192(u64 x, u64& sticky) {
+  constexpr int e = ((E % 192) + 192) % 192;
+  if constexpr (e < 96) {
+    return ntt::mul_pow2<e>(x, sticky);
+  } else {
+    const u64 y = ntt::mul_pow2<e - 96>(x, sticky);
+    u32 lo, hi;
+    u64 w;
+    asm("v_sub_co_u32_e64 %[lo], %[w], 1, %[y0]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[hi], %[w], -1, %[y1], %[w]\n\t"
+        "s_or_b64 %[st], %[st], %[w]"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [w] "=&s"(w), [st] "+s"(sticky)
+        : [y0] "v"((u32)y), [y1] "v"((u32)(y >> 32)));
+    return ((u64)hi << 32) | lo;
+  }
+}
+
+}  // namespace ntt20
+
+// ta1[(a - 1) * 64 + p_lo] = w_1024^(p_lo brev4(a)) (a = 1..15), then ta1[960 + d * 16 + b] = w_64^(d brev4(b));
+// t4[k * 1024 + i2] = scale * w_n^(i2 k), n = 2^20
+__global__ __launch_bounds__(kBlock) void k_ntt20_tables(u64 w1024, u64 wn, u64 scale, u64* __restrict__ ta1, u64* __restrict__ t4) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < 15 * 64) {
+    const unsigned a = (unsigned)(i >> 6) + 1, p_lo = (unsigned)i & 63;
+    ta1[i] = gl::canon(gl::pow(w1024, (u64)p_lo * ntt20::brev4(a)));
+  } else if (i < 16 * 64) {
+    const unsigned d = ((unsigned)i >> 4) & 3, b = (unsigned)i & 15;
+    ta1[i] = gl::canon(gl::pow(w1024, (u64)16 * d * ntt20::brev4(b)));
+  }
+  if (i < ((size_t)1 << 20)) {
+    const u64 k = i >> 10, i2 = i & 1023;
+    t4[i] = gl::canon(gl::mul(scale, gl::pow(wn, i2 * k)));
+  }
+}
+
+// DIR 0 forward (w), 1 inverse (w^-1; the 1/n rides in t4).  ROW_IN: the 16 transforms are 16 contiguous rows of `in` (pass 2);
+// otherwise 16 neighbouring columns (pass 1).  TW: multiply the outputs by t4[k][q0 + q] (pass 1).
+// grid: x = polynomial, y = tile (q0 = 16 y).  in / out: [n_polys][1024][1024].
+template <int DIR, bool ROW_IN, bool TW>
+__global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_, u64* __restrict__ out_, const u64* __restrict__ ta1_,
+                                                     const u64* __restrict__ t4_, const u64* __restrict__ tw_half, unsigned force) {
+  using namespace ntt20;
+  constexpr int Z16 = DIR ? 36 : 156, Z4 = DIR ? 144 : 48;
+  __shared__ __attribute__((aligned(16))) u64 buf[kLdsWords];
+  const unsigned t = threadIdx.x;
+  const unsigned q0 = blockIdx.y * kTile;
+  const gcptr in = as_global(in_) + ((size_t)blockIdx.x << 20);
+  const gptr out = as_global(out_) + ((size_t)blockIdx.x << 20);
+  const gcptr ta1 = as_global(ta1_), t4 = as_global(t4_);
+  u64 sticky = 0;
+  u64 x[16];
+  // ---- load + step A
+  const unsigned qa = ROW_IN ? (t >> 6) : (t & 15), p_lo = ROW_IN ? (t & 63) : (t >> 4);
+  {
+    u64 tw[16];
+    const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << 10) + q0 + qa;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << 10];
+#pragma unroll
+    for (int a = 1; a < 16; ++a) tw[a] = ta1[(a - 1) * 64 + p_lo];
+    __builtin_amdgcn_sched_barrier(0);
+    ntt::dif16<Z16>(x, sticky);
+    poseidon::static_for<1, 16>([&](auto rc) {
+      constexpr int a = decltype(rc)::value;
+      x[a] = ntt::mul(x[a], tw[a], sticky);
+    });
+  }
+#pragma unroll
+  for (int a = 0; a < 16; ++a) buf[a * kRowA + p_lo * 17 + qa] = x[a];
+  __syncthreads();
+  // ---- step B: thread (d, a, q), d wave-uniform
+  const unsigned d = __builtin_amdgcn_readfirstlane(t >> 8), ab = (t >> 4) & 15, q = t & 15;
+  u64* const plane = buf + ab * kRowA + q;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) x[b] = plane[(4 * b + d) * 17];
+  {
+    // slot b' *= w_64^(d brev4(b')), wave-uniform.  (These are powers of two -- w_64 = 2^39 -- but selecting the shift amounts per
+    // wave takes a uniform branch around the asm blocks, and hipcc 7.2 drops the taken side's results there: the table costs
+    // 4 issue slots per point more and no control flow.)
+    u64 twb[16];
+#pragma unroll
+    for (int b = 1; b < 16; ++b) twb[b] = ta1[15 * 64 + d * 16 + b];
+    __builtin_amdgcn_sched_barrier(0);
+    ntt::dif16<Z16>(x, sticky);
+    poseidon::static_for<1, 16>([&](auto rc) {
+      constexpr int b = decltype(rc)::value;
+      x[b] = ntt::mul(x[b], twb[b], sticky);
+    });
+  }
+#pragma unroll
+  for (int b = 0; b < 16; ++b) plane[(4 * b + d) * 17] = x[b];  // in place: the words this thread read
+  __syncthreads();
+  // ---- step C: thread (beta, a, q): b' = 4 beta + bb
+  const unsigned beta = d;
+  u64 tw[16];
+  if constexpr (TW) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
+        tw[4 * bb + dd] = t4[((size_t)k << 10) + q0 + q];
+      }
+  }
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) x[4 * bb + dd] = plane[(4 * (4 * beta + bb) + dd) * 17];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    u64 y[4] = {x[4 * bb], x[4 * bb + 1], x[4 * bb + 2], x[4 * bb + 3]};
+    ntt::dif4<Z4>(y, sticky);
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) x[4 * bb + dd] = TW ? ntt::mul(y[dd], tw[4 * bb + dd], sticky) : y[dd];
+  }
+  if (__builtin_expect(__syncthreads_or(sticky != 0) || force, 0)) {
+    // rare (or forced by the tests): the workgroup redoes its tile with the exact radix-2 code.  flat[q * 1024 + p]; the in-place
+    // DIF leaves frequency k at position brev10(k).
+    u64* const flat = buf;
+    __syncthreads();
+    {
+      const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << 10) + q0 + qa;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) flat[qa * 1024 + 64 * k + p_lo] = gl::canon(ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << 10]);
+    }
+    __syncthreads();
+    for (unsigned s = 0; s < 10; ++s) {
+      const unsigned half = 512u >> s;
+      for (unsigned i = t; i < 16 * 512; i += 1024) {
+        const unsigned col = i >> 9, bf = i & 511, blk = bf / half, j = bf & (half - 1);
+        const unsigned i0 = col * 1024 + blk * 2 * half + j, i1 = i0 + half;
+        const u64 u = flat[i0], v = flat[i1];
+        flat[i0] = cadd(u, v);
+        flat[i1] = cmul(csub(u, v), tw_half[(size_t)j << s]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
+        u64 v = flat[q * 1024 + brev32(k, 10)];
+        if constexpr (TW) v = cmul(v, t4[((size_t)k << 10) + q0 + q]);
+        out[((size_t)k << 10) + q0 + q] = v;
+      }
+    return;
+  }
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+      const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
+      out[((size_t)k << 10) + q0 + q] = gl::canon(x[4 * bb + dd]);
+    }
+}
+
 // ---------------------------------------------------------------- leaves
 // Poly-major [w][n_pts] -> leaf-major [n_pts][w] through a 32x32 LDS tile (+1 pad: conflict-free column reads).
 __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in, u64* __restrict__ out, size_t w,
@@ -699,6 +891,51 @@ int get_coset_pows(unsigned log_n, unsigned rate_bits, u64 shift, const u64** ou
   return P2MT_OK;
 }
 
+// tables of the 2^20-point four-step transform, per direction (built once)
+int get_ntt20_tables(int inverse, const u64** ta1, const u64** t4) {
+  std::lock_guard<std::mutex> lock(tables_mutex());
+  static u64* d[2] = {nullptr, nullptr};
+  if (!d[inverse]) {
+    u64* p = nullptr;
+    const size_t words = 16 * 64 + ((size_t)1 << 20);
+    if (hipMalloc((void**)&p, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
+    u64 w1024 = h_root_of_unity(10), wn = h_root_of_unity(20), scale = 1;
+    if (inverse) {
+      w1024 = h_pow(w1024, gl::P - 2);
+      wn = h_pow(wn, gl::P - 2);
+      scale = h_pow(((u64)1 << 20) % gl::P, gl::P - 2);
+    }
+    hipLaunchKernelGGL(k_ntt20_tables, dim3(grid_for((size_t)1 << 20)), dim3(kBlock), 0, p2mt::rt().stream, w1024, wn, scale, p,
+                       p + 16 * 64);
+    P2MT_LAUNCH_CHECK();
+    P2MT_HIP(hipStreamSynchronize(p2mt::rt().stream));
+    d[inverse] = p;
+  }
+  *ta1 = d[inverse];
+  *t4 = d[inverse] + 16 * 64;
+  return P2MT_OK;
+}
+
+// fft_with_options / ifft_with_options for 2^20 points, natural order in and out: d_data -> d_tmp (pass 1, columns) -> d_data
+// (pass 2, rows; the result lands transposed, i.e. in natural order).  Two launches, 16 B of HBM traffic per point each.
+int ntt20_natural_dev(u64* d_data, u64* d_tmp, size_t n_polys, int inverse) {
+  const u64 *ta1, *t4, *twh;
+  P2MT_TRY(get_ntt20_tables(inverse, &ta1, &t4));
+  P2MT_TRY(get_twiddles(10, inverse, &twh));
+  hipStream_t st = p2mt::rt().stream;
+  const unsigned force = p2mt::rt().force_fallback ? 1u : 0u;
+  const dim3 grid((unsigned)n_polys, 64);
+  const int slot = p2mt::prof_begin();
+  if (inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true>), grid, dim3(1024), 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, force);
+  else hipLaunchKernelGGL((k_ntt20_pass<0, false, true>), grid, dim3(1024), 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, force);
+  p2mt::prof_end(slot);
+  P2MT_LAUNCH_CHECK();
+  if (inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false>), grid, dim3(1024), 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, force);
+  else hipLaunchKernelGGL((k_ntt20_pass<0, true, false>), grid, dim3(1024), 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, force);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+
 // DIF transform of n_polys contiguous 2^log_n-point rows, in place, natural -> bit-reversed order.
 int ntt_dif_dev(u64* d_data, unsigned log_n, size_t n_polys, int inverse) {
   if (log_n == 0) return P2MT_OK;
@@ -742,10 +979,41 @@ __global__ __launch_bounds__(kBlock) void k_debug_field_op(int op, const u64* __
     case 7: r = gl::mul_add(a[i], b[i], ((a[i] << 17) | (a[i] >> 47)) ^ b[i]); break;      // a b + c, c = rotl(a, 17) ^ b
     case 8: r = poseidon_fast::mul(a[i], b[i], sticky); break;                             // flag form: right unless flagged
     case 9: r = poseidon_fast::sub_any(a[i], b[i]); break;                                 // a - b mod p, any operands, exact
-    default: r = poseidon_fast::sub_flag(a[i], b[i], sticky); break;                       // ... the second wrap left to the flag
+    case 10: r = poseidon_fast::sub_flag(a[i], b[i], sticky); break;                       // ... the second wrap left to the flag
+    default: break;
   }
   out[i] = gl::canon(r);
   flag[i] = (uint8_t)((sticky >> lane) & 1);
+}
+// ops 11..207: the transform kernels' arithmetic (ntt_arith.hip.h), one instantiation per op: no control flow at all around the
+// field operations (their sticky mask lives in an SGPR pair the asm blocks update in place).
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_debug_ntt_op(const u64* __restrict__ a, const u64* __restrict__ b, size_t n,
+                                                         u64* __restrict__ out, uint8_t* __restrict__ flag) {
+  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t i = i0 < n ? i0 : n - 1;
+  const unsigned lane = threadIdx.x & 63;
+  const u64 x = a[i], y = b[i];
+  u64 sticky = 0, r = 0, other;
+  if constexpr (OP == 11) r = ntt::add(x, y, sticky);
+  else if constexpr (OP == 12) r = ntt::sub(x, y, sticky);
+  else if constexpr (OP == 13) r = ntt::mul(x, y, sticky);
+  else if constexpr (OP == 14) ntt::bfly(x, y, r, other, sticky);
+  else if constexpr (OP == 15) ntt::bfly(x, y, other, r, sticky);
+  else r = ntt20::mul_pow2_mod192<OP - 16>(x, sticky);  // x * 2^E for E in [0, 192)  (2^96 = -1)
+  if (i0 < n) {
+    out[i] = gl::canon(r);
+    flag[i] = (uint8_t)((sticky >> lane) & 1);
+  }
+}
+template <int OP>
+void launch_debug_ntt_one(unsigned grid, hipStream_t st, const u64* a, const u64* b, size_t n, u64* out, uint8_t* flag) {
+  hipLaunchKernelGGL((k_debug_ntt_op<OP>), dim3(grid), dim3(kBlock), 0, st, a, b, n, out, flag);
+}
+template <int... I>
+void launch_debug_ntt_op(int op, std::integer_sequence<int, I...>, unsigned grid, hipStream_t st, const u64* a, const u64* b, size_t n,
+                         u64* out, uint8_t* flag) {
+  ((op == 11 + I ? launch_debug_ntt_one<11 + I>(grid, st, a, b, n, out, flag) : (void)0), ...);
 }
 }  // namespace
 
@@ -753,7 +1021,7 @@ extern "C" int p2mt_debug_field_op(int op, const uint64_t* a, const uint64_t* b,
   return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
   if (n == 0) return P2MT_OK;
-  if (!a || !b || !out || !flag_out || op < 0 || op > 10) return p2mt::fail(P2MT_EINVAL, "bad argument");
+  if (!a || !b || !out || !flag_out || op < 0 || op > 207) return p2mt::fail(P2MT_EINVAL, "bad argument");
   DevBuf ba, bb, bo, bf;
   P2MT_TRY(ba.alloc(n * 8));
   P2MT_TRY(bb.alloc(n * 8));
@@ -762,8 +1030,12 @@ extern "C" int p2mt_debug_field_op(int op, const uint64_t* a, const uint64_t* b,
   hipStream_t st = rt().stream;
   P2MT_HIP(hipMemcpyAsync(ba.p, a, n * 8, hipMemcpyHostToDevice, st));
   P2MT_HIP(hipMemcpyAsync(bb.p, b, n * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_debug_field_op, dim3(grid_for(n)), dim3(kBlock), 0, st, op, (const u64*)ba.as<u64>(),
-                     (const u64*)bb.as<u64>(), n, bo.as<u64>(), bf.as<uint8_t>());
+  if (op >= 11)
+    launch_debug_ntt_op(op, std::make_integer_sequence<int, 197>{}, grid_for(n), st, (const u64*)ba.as<u64>(),
+                        (const u64*)bb.as<u64>(), n, bo.as<u64>(), bf.as<uint8_t>());
+  else
+    hipLaunchKernelGGL(k_debug_field_op, dim3(grid_for(n)), dim3(kBlock), 0, st, op, (const u64*)ba.as<u64>(),
+                       (const u64*)bb.as<u64>(), n, bo.as<u64>(), bf.as<uint8_t>());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 8, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipMemcpyAsync(flag_out, bf.p, n, hipMemcpyDeviceToHost, st));
@@ -779,6 +1051,11 @@ extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_pol
   if (n_polys == 0) return P2MT_OK;
   if (!d_data || log_n > 32) return p2mt::fail(P2MT_EINVAL, "ntt: bad argument (2-adicity of the field is 32)");
   const size_t total = n_polys << log_n;
+  if (log_n == 20 && n_polys < ((size_t)1 << 31) && rt().use_lde12) {  // the four-step path (two launches, natural order out)
+    u64* tmp20;
+    P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, total * 8, (void**)&tmp20));
+    return ntt20_natural_dev(d_data, tmp20, n_polys, inverse != 0);
+  }
   DevBuf tmp;
   P2MT_TRY(tmp.alloc(total * 8));
   P2MT_HIP(hipMemcpyAsync(tmp.p, d_data, total * 8, hipMemcpyDeviceToDevice, rt().stream));

@@ -56,7 +56,7 @@ def test_coset_lde_vs_oracle(pkg, oracle, log_n, rate_bits):
 
 
 def test_large_fft_properties(pkg):
-    """2^20-point transforms (global stages + LDS tail): round trip, linearity and a direct evaluation."""
+    """2^20-point transforms (the four-step path): round trip, linearity and a direct evaluation."""
     log_n = 20
     a, b = rand((1, 1 << log_n), 31), rand((1, 1 << log_n), 32)
     fa, fb = pkg.fft(a), pkg.fft(b)
@@ -65,6 +65,29 @@ def test_large_fft_properties(pkg):
     fs = pkg.fft(s)
     assert np.array_equal(fs, ((fa.astype(object) + fb.astype(object)) % P).astype(np.uint64))
     assert int(fa[0, 0]) == int(sum(int(x) for x in a[0]) % P)  # f(1) = sum of coefficients
+
+
+def test_four_step_fft_2pow20_vs_oracle(pkg, oracle):
+    """The two-pass (1024 x 1024) path of p2mt_ntt_batch_dev against the oracle's fft / ifft, every word: random rows, a row of
+    non-canonical and extreme values (the loose-u64 arithmetic must reduce them as the reference's field type does), and the same
+    again with the flagged-tile exact radix-2 redo forced for every tile."""
+    log_n = 20
+    a = rand((3, 1 << log_n), 41)
+    a[1, :] = np.arange(1, (1 << log_n) + 1, dtype=np.uint64)
+    ext = np.array([P, P + 1, 0xFFFFFFFFFFFFFFFF, 0, 1, P - 1, 0xFFFFFFFF00000000, 0xFFFFFFFF, 1 << 63, 0xFFFFFFFEFFFFFFFF],
+                   dtype=np.uint64)
+    a[2, :] = np.resize(ext, 1 << log_n)
+    want_f = [oracle.fft(a[j]) for j in range(3)]
+    want_i = [oracle.ifft(a[j]) for j in range(3)]
+    for force in (0, 1):
+        pkg.lib().p2mt_debug_force_fallback(force)
+        try:
+            f, g = pkg.fft(a), pkg.ifft(a)
+        finally:
+            pkg.lib().p2mt_debug_force_fallback(0)
+        for j in range(3):
+            assert np.array_equal(f[j], want_f[j]), (force, j)
+            assert np.array_equal(g[j], want_i[j]), (force, j)
 
 
 @pytest.mark.parametrize("width", [1, 3, 4, 5, 8, 9, 16, 20, 135])

@@ -578,6 +578,41 @@ def test_field_primitives_rare_paths(pkg):
         assert flag.sum() > 0
 
 
+def test_transform_arithmetic_primitives(pkg):
+    """The NTT / LDE kernels' field arithmetic (csrc/ntt_arith.hip.h): add, sub, multiply, the fused butterfly and the
+    multiplication by every power of two 2^E, E in [0, 192), on crafted edge operands + random ones, against Python integers.
+    A flagged lane (the astronomically rare second wrap the kernels answer with an exact redo) may hold anything; every other lane is
+    exact, the crafted operands do raise the flag where the design says they can, and random operands never do."""
+    lib, N = pkg.lib(), pkg._native
+    M64 = (1 << 64) - 1
+    edge = [0, 1, 2, P - 1, P, P + 1, M64, M64 - 1, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF,
+            0x00000000FFFFFFFE, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF00000002, 0x8000000080000000, 0x3FF, 0xFFFFFC0000000000]
+    rng = np.random.default_rng(123)
+    n_edge = len(edge) ** 2
+    a = np.array([x for x in edge for _ in edge] + [int(v) for v in rng.integers(0, 1 << 64, 3000, dtype=np.uint64)], dtype=np.uint64)
+    b = np.array([y for _ in edge for y in edge] + [int(v) for v in rng.integers(0, 1 << 64, 3000, dtype=np.uint64)], dtype=np.uint64)
+    A, B = [int(x) for x in a], [int(x) for x in b]
+
+    def run(op):
+        out, flag = np.zeros(a.size, np.uint64), np.zeros(a.size, np.uint8)
+        N.check(lib.p2mt_debug_field_op(op, N.ptr(a), N.ptr(b), a.size, N.ptr(out), N.ptr(flag)))
+        return [int(x) for x in out], flag
+
+    flagged_somewhere = 0
+    for op, fn in ((11, lambda x, y: x + y), (12, lambda x, y: x - y), (13, lambda x, y: x * y), (14, lambda x, y: x + y),
+                   (15, lambda x, y: x - y)):
+        out, flag = run(op)
+        assert all(o == fn(x, y) % P for o, x, y, f in zip(out, A, B, flag) if not f), op
+        assert flag[n_edge:].sum() == 0, op  # random operands never take the rare path
+        flagged_somewhere += int(flag.sum())
+    assert flagged_somewhere > 0
+    for e in range(192):
+        out, flag = run(16 + e)
+        k = pow(2, e, P)
+        assert all(o == x * k % P for o, x, f in zip(out, A, flag) if not f), e
+        assert flag[n_edge:].sum() == 0, e
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_mmr_random_extend_sequences(pkg, oracle, seed):
     """Random sequences of extends (sizes 0, 1, small, around the 2^10-leaf tile and 2^12/2^16 policy boundaries)
