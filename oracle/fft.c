@@ -119,3 +119,60 @@ int oracle_polynomial_batch_commit(const uint64_t *polys, int is_values, size_t 
   free(lde);
   return oracle_merkle_cap_commit(leaves_out, big, n_polys, cap_height, digests_out, cap_out);
 }
+
+/* B4: the same commit on all host cores -- what bench.py times beside the GPU's commit phase.  Same arithmetic as
+ * above (textbook transforms, the tuned scalar Poseidon port of poseidon_fast.c for the sponge and the tree), parallel over the
+ * polynomials, then over the leaves, then over each tree level.  Generous: the reference's prover is the reference calls plonky2 with its default features; no claim is made beyond "this C restatement, this many threads".  threads = 0: all cores. */
+#include <omp.h>
+static void fast_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]) {
+  if (n <= 4) {
+    for (size_t i = 0; i < 4; ++i) out[i] = i < n ? gl_canon(in[i]) : 0;
+    return;
+  }
+  uint64_t s[12] = {0};
+  for (size_t off = 0; off < n; off += 8) {
+    size_t len = n - off < 8 ? n - off : 8;
+    for (size_t i = 0; i < len; ++i) s[i] = gl_canon(in[off + i]);
+    oracle_fast_poseidon_permute(s);
+  }
+  memcpy(out, s, 32);
+}
+int oracle_polynomial_batch_commit_parallel(const uint64_t *polys, int is_values, size_t n_polys, unsigned log_n,
+                                            unsigned rate_bits, unsigned cap_height, uint64_t *leaves_out,
+                                            uint64_t *cap_out, int threads) {
+  size_t n = (size_t)1 << log_n, big = n << rate_bits;
+  unsigned log_big = log_n + rate_bits;
+  if (cap_height > log_big) return -1;
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+  {
+    uint64_t *coeffs = (uint64_t *)malloc(n * 8), *lde = (uint64_t *)malloc(big * 8);
+#pragma omp for schedule(dynamic, 1)
+    for (size_t j = 0; j < n_polys; ++j) {
+      memcpy(coeffs, &polys[j * n], n * 8);
+      if (is_values) oracle_ifft(coeffs, log_n);
+      oracle_coset_lde(coeffs, log_n, rate_bits, 7, lde);
+      for (size_t i = 0; i < big; ++i) leaves_out[brev(i, log_big) * n_polys + j] = lde[i];
+    }
+    free(coeffs);
+    free(lde);
+  }
+  uint64_t *lvl = (uint64_t *)malloc(big * 32), *nxt = (uint64_t *)malloc(big * 32);
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < big; ++i) fast_hash_or_noop(&leaves_out[i * n_polys], n_polys, &lvl[4 * i]);
+  size_t cur_n = big;
+  for (unsigned level = 0; level < log_big - cap_height; ++level) {
+#pragma omp parallel for num_threads(threads) schedule(static) if (cur_n >= 256)
+    for (size_t j = 0; j < cur_n / 2; ++j) {
+      uint64_t in[8];
+      memcpy(in, &lvl[8 * j], 64);
+      oracle_fast_two_to_one_batch(in, &nxt[4 * j], 1);
+    }
+    uint64_t *t = lvl; lvl = nxt; nxt = t;
+    cur_n /= 2;
+  }
+  memcpy(cap_out, lvl, cur_n * 32);
+  free(lvl);
+  free(nxt);
+  return threads;
+}

@@ -116,6 +116,10 @@ int oracle_merkle_cap_commit(const uint64_t *leaves, size_t n, size_t width, uns
 int oracle_polynomial_batch_commit(const uint64_t *polys, int is_values, size_t n_polys, unsigned log_n,
                                    unsigned rate_bits, unsigned cap_height, uint64_t *leaves_out,
                                    uint64_t *digests_out, uint64_t *cap_out);
+/* the same on `threads` host cores (0 = all), tuned scalar Poseidon port: bench.py's B4.  Returns the thread count (< 0: error). */
+int oracle_polynomial_batch_commit_parallel(const uint64_t *polys, int is_values, size_t n_polys, unsigned log_n,
+                                            unsigned rate_bits, unsigned cap_height, uint64_t *leaves_out,
+                                            uint64_t *cap_out, int threads);
 
 /* ---- plonky2 iop/challenger.rs, fri/{oracle,prover,verifier}.rs  [parity unpinned] (oracle/fri.c) ---- */
 typedef struct oracle_challenger {

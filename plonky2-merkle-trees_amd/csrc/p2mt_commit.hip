@@ -447,6 +447,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restr
 // transform that fits; each pass kernel below moves its 16 B per point exactly once.
 // One kernel does both passes.  A workgroup of 1024 threads owns a tile of 1024 points x 16 transforms (128 KB: one per CU), every
 // thread 16 points, and the 1024-point DIF is radix 16 x 16 x 4 in registers with two exchanges through LDS:
+//   (numbers for Q = 16 transforms per workgroup; Tile<Q> below)
 //   step A  thread (p_lo, q): points p = 64 k + p_lo, DIF-16 over k; slot a *= w_1024^(p_lo brev4(a))           -> LDS
 //   step B  thread (d, a, q): points p = 64 a + 4 b + d, DIF-16 over b; slot b' *= w_64^(d brev4(b')), d = t >> 8 wave-uniform
 //                                                                                                                -> LDS, in place
@@ -462,9 +463,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restr
 // Algorithmic traffic per launch: 16 B per point (+ 8 B per point of twiddles in pass 1, from a table all transforms share).
 namespace ntt20 {
 
-constexpr unsigned kRowA = 1104;             // words per a-plane: 64 * 17 + 16
-constexpr unsigned kTile = 16;               // transforms per workgroup
-constexpr unsigned kLdsWords = 16 * kRowA;   // 141 312 B
+// Q transforms per workgroup (64 Q threads): LDS word(a, p_lo, q) = a * rowA + p_lo * (Q + 1) + q, rowA = 64 (Q + 1) + Q
+//   Q = 16: 128-byte granules, 141 KB of LDS, one workgroup of 1024 threads per CU (its memory phases are covered by nothing);
+//   Q = 8:   64-byte granules,  75 KB of LDS, two workgroups of 512 threads per CU (one computes while the other loads / stores).
+template <unsigned Q>
+struct Tile {
+  static constexpr unsigned kThreads = 64 * Q, kStride = Q + 1, kRowA = 64 * (Q + 1) + Q, kLdsWords = 16 * kRowA;
+};
 
 constexpr unsigned brev4(unsigned r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
@@ -510,12 +515,14 @@ __global__ __launch_bounds__(kBlock) void k_ntt20_tables(u64 w1024, u64 wn, u64 
 // DIR 0 forward (w), 1 inverse (w^-1; the 1/n rides in t4).  ROW_IN: the 16 transforms are 16 contiguous rows of `in` (pass 2);
 // otherwise 16 neighbouring columns (pass 1).  TW: multiply the outputs by t4[k][q0 + q] (pass 1).
 // grid: x = polynomial, y = tile (q0 = 16 y).  in / out: [n_polys][1024][1024].
-template <int DIR, bool ROW_IN, bool TW>
-__global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_, u64* __restrict__ out_, const u64* __restrict__ ta1_,
+template <int DIR, bool ROW_IN, bool TW, unsigned Q>
+__global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ in_, u64* __restrict__ out_, const u64* __restrict__ ta1_,
                                                      const u64* __restrict__ t4_, const u64* __restrict__ tw_half, unsigned force) {
   using namespace ntt20;
+  using T = Tile<Q>;
+  constexpr unsigned kRowA = T::kRowA, kStride = T::kStride, kTile = Q, kLogQ = Q == 16 ? 4 : 3;
   constexpr int Z16 = DIR ? 36 : 156, Z4 = DIR ? 144 : 48;
-  __shared__ __attribute__((aligned(16))) u64 buf[kLdsWords];
+  __shared__ __attribute__((aligned(16))) u64 buf[T::kLdsWords];
   const unsigned t = threadIdx.x;
   const unsigned q0 = blockIdx.y * kTile;
   const gcptr in = as_global(in_) + ((size_t)blockIdx.x << 20);
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_
   u64 sticky = 0;
   u64 x[16];
   // ---- load + step A
-  const unsigned qa = ROW_IN ? (t >> 6) : (t & 15), p_lo = ROW_IN ? (t & 63) : (t >> 4);
+  const unsigned qa = ROW_IN ? (t >> 6) : (t & (Q - 1)), p_lo = ROW_IN ? (t & 63) : (t >> kLogQ);
   {
     u64 tw[16];
     const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << 10) + q0 + qa;
@@ -540,13 +547,13 @@ __global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_
     });
   }
 #pragma unroll
-  for (int a = 0; a < 16; ++a) buf[a * kRowA + p_lo * 17 + qa] = x[a];
+  for (int a = 0; a < 16; ++a) buf[a * kRowA + p_lo * kStride + qa] = x[a];
   __syncthreads();
   // ---- step B: thread (d, a, q), d wave-uniform
-  const unsigned d = __builtin_amdgcn_readfirstlane(t >> 8), ab = (t >> 4) & 15, q = t & 15;
+  const unsigned d = __builtin_amdgcn_readfirstlane(t >> (kLogQ + 4)), ab = (t >> kLogQ) & 15, q = t & (Q - 1);
   u64* const plane = buf + ab * kRowA + q;
 #pragma unroll
-  for (int b = 0; b < 16; ++b) x[b] = plane[(4 * b + d) * 17];
+  for (int b = 0; b < 16; ++b) x[b] = plane[(4 * b + d) * kStride];
   {
     // slot b' *= w_64^(d brev4(b')), wave-uniform.  (These are powers of two -- w_64 = 2^39 -- but selecting the shift amounts per
     // wave takes a uniform branch around the asm blocks, and hipcc 7.2 drops the taken side's results there: the table costs
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_
     });
   }
 #pragma unroll
-  for (int b = 0; b < 16; ++b) plane[(4 * b + d) * 17] = x[b];  // in place: the words this thread read
+  for (int b = 0; b < 16; ++b) plane[(4 * b + d) * kStride] = x[b];  // in place: the words this thread read
   __syncthreads();
   // ---- step C: thread (beta, a, q): b' = 4 beta + bb
   const unsigned beta = d;
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) x[4 * bb + dd] = plane[(4 * (4 * beta + bb) + dd) * 17];
+    for (int dd = 0; dd < 4; ++dd) x[4 * bb + dd] = plane[(4 * (4 * beta + bb) + dd) * kStride];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) {
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(1024) void k_ntt20_pass(const u64* __restrict__ in_
     __syncthreads();
     for (unsigned s = 0; s < 10; ++s) {
       const unsigned half = 512u >> s;
-      for (unsigned i = t; i < 16 * 512; i += 1024) {
+      for (unsigned i = t; i < Q * 512; i += T::kThreads) {
         const unsigned col = i >> 9, bf = i & 511, blk = bf / half, j = bf & (half - 1);
         const unsigned i0 = col * 1024 + blk * 2 * half + j, i1 = i0 + half;
         const u64 u = flat[i0], v = flat[i1];
@@ -924,15 +931,32 @@ int ntt20_natural_dev(u64* d_data, u64* d_tmp, size_t n_polys, int inverse) {
   P2MT_TRY(get_twiddles(10, inverse, &twh));
   hipStream_t st = p2mt::rt().stream;
   const unsigned force = p2mt::rt().force_fallback ? 1u : 0u;
-  const dim3 grid((unsigned)n_polys, 64);
-  const int slot = p2mt::prof_begin();
-  if (inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true>), grid, dim3(1024), 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, force);
-  else hipLaunchKernelGGL((k_ntt20_pass<0, false, true>), grid, dim3(1024), 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, force);
-  p2mt::prof_end(slot);
-  P2MT_LAUNCH_CHECK();
-  if (inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false>), grid, dim3(1024), 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, force);
-  else hipLaunchKernelGGL((k_ntt20_pass<0, true, false>), grid, dim3(1024), 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, force);
-  P2MT_LAUNCH_CHECK();
+  // (both passes are profiled launches: bench.py's roofline for this transform is per pass, 16 B per point each)
+  // Tile width per pass, measured (profiles/r04_commit_phase.txt): the column pass is faster with 16 transforms per workgroup
+  // (0.87 ms against 1.16 ms: its loads, twiddle loads and stores are all granules, and 64-byte ones double the cache lines a
+  // wave-load touches), the row pass with 8 (0.58 ms against 0.74 ms: two workgroups per CU cover each other's memory phases).
+  // P2MT_LDE12=3 / 4 force 16 / 8 for both (A/B).
+  const int mode = p2mt::rt().use_lde12;
+  for (int pass = 0; pass < 2; ++pass) {
+    const u64* src = pass == 0 ? d_data : d_tmp;
+    u64* dst = pass == 0 ? d_tmp : d_data;
+    const bool wide = mode == 3 || (mode != 4 && pass == 0);
+    const dim3 grid((unsigned)n_polys, wide ? 64 : 128), block(wide ? 1024 : 512);
+    const int slot = p2mt::prof_begin();
+    if (wide) {
+      if (pass == 0 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+      if (pass == 0 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+      if (pass == 1 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, true, false, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+      if (pass == 1 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+    } else {
+      if (pass == 0 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+      if (pass == 0 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+      if (pass == 1 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, true, false, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+      if (pass == 1 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
+    }
+    p2mt::prof_end(slot);
+    P2MT_LAUNCH_CHECK();
+  }
   return P2MT_OK;
 }
 

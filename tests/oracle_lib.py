@@ -359,6 +359,21 @@ class Oracle:
         self.lib.oracle_ifft(_ptr(a), a.size.bit_length() - 1)
         return a
 
+    def polynomial_batch_commit_parallel(self, polys, is_values, rate_bits=3, cap_height=4, threads=0):
+        """B4: the commit on `threads` host cores (0 = all) -> (cap, threads used).  Test infrastructure / cpu_baseline only."""
+        polys = _arr(polys)
+        n_polys, n = polys.shape
+        big = n << rate_bits
+        leaves = np.zeros((big, n_polys), np.uint64)
+        cap = np.zeros((1 << cap_height, 4), np.uint64)
+        fn = self.lib.oracle_polynomial_batch_commit_parallel
+        fn.restype = C.c_int
+        fn.argtypes = [_u64p, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, _u64p, _u64p, C.c_int]
+        used = fn(_ptr(polys), int(is_values), n_polys, n.bit_length() - 1, rate_bits, cap_height, _ptr(leaves), _ptr(cap), threads)
+        if used < 0:
+            raise ValueError("oracle_polynomial_batch_commit_parallel: status %d" % used)
+        return cap, used
+
     def coset_lde(self, coeffs, rate_bits, shift=7):
         c = _arr(coeffs)
         out = np.zeros(c.size << rate_bits, np.uint64)
