@@ -31,7 +31,7 @@ enum { kDomainSepHashPad = 0,   // D = hash_pad([]) = hash_no_pad([1,0,0,0,0,0,0
        kDomainSepNone = 2 };    // no D term                                            (a revision without domain separators)
 constexpr int kDigestDomainSeparator = kDomainSepHashPad;
 //   proof of work: the response of a candidate w is `observe(w); get_challenge()` on a copy of the transcript (fri/prover.rs
-//   fri_proof_of_work, one duplexing).  Implemented by k_fri_pow*, the transcript tail of p2mt_fri.hip, verify_fri_queries_host and
+//   fri_proof_of_work, one duplexing).  Implemented by k_fri_pow*, the transcript tail of p2mt_fri.hip, verify_pass (p2mt_circuit.hip) and
 //   the in-circuit check of p2mt_recursion.hip; if plonky2's verify reports "Invalid proof-of-work witness" on the cross-check,
 //   those four sites are what to change.
 constexpr int kPowRule = 0;

@@ -12,7 +12,7 @@
 //          products, the quotient polynomials (k_quotient: four role-wavefronts per 64 points of the 8n-point LDE coset
 //          evaluate every gate's constraints, the permutation checks and L_0 (Z - 1), combined with powers of alpha and
 //          divided by Z_H), coset IFFT, quotient commitment, openings and the FRI proof (p2mt_fri.hip);
-//          verify: transcript and Merkle paths (k_verify_merkle) here, the field arithmetic in p2mt_verify_host.hip.
+//          verify: the transcript here; Merkle paths and the field arithmetic in p2mt_verify_dev.hip, staged beside it.
 // Nothing here is GEMM-shaped: 64-bit modular arithmetic on the integer VALU, latency-bound at these sizes (64..4096 rows).
 #include "tree_common.hip.h"
 #include "circuit_types.h"
@@ -93,6 +93,7 @@ struct p2mt_circuit_data {
   p2mt_challenger* ch = nullptr;
   // verifier scratch (allocated on the first p2mt_circuit_verify)
   u64* d_verify = nullptr;
+  void* vstreams = nullptr;  // side streams + events of the staged verifier (p2mt_verify_dev.hip)
   // batched verifier (p2mt_circuit_verify_batch): one block of the same layout per proof, a challenger state behind each
   u64* d_trace = nullptr;  // debug (p2mt_debug_witness_trace): completion tick of every generator of the dataflow interpreter
   char* d_vbatch = nullptr;
@@ -1362,47 +1363,11 @@ __global__ __launch_bounds__(kBlock) void k_opening_unset(const u64* __restrict_
   out[dst] = set_order[t];
 }
 
-// verify_merkle_proof_to_cap for every (query, tree) pair of a proof: one wavefront per pair hashes the opened row
-// (hash_or_noop) and folds the path on the 12-lanes-per-permutation layout; *bad = 1 + the first failing pair.
+// one (query, tree) pair of a proof under verification: where its opened row, its path and its cap sit in the proof block (built and
+// consumed on the device: p2mt_verify_dev.hip k_verify_items / k_verify_paths; the layout below reserves their space)
 struct VItem {
   u32 leaf_off, width, index, sib_off, n_sib, cap_off;
 };
-__global__ __launch_bounds__(kBlock) void k_verify_merkle(const u64* __restrict__ words, const VItem* __restrict__ items, u32 n_items,
-                                                          int* bad, BatchArg ba, PermCtx ctx) {
-  words = bp(words, ba);
-  items = bp(items, ba);
-  bad = bp(bad, ba);
-  __shared__ u64 rc_lds[kWaveRcWords];
-  ctx = stage_round_constants(rc_lds, ctx);
-  const u32 item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (item >= n_items) return;  // wave-uniform
-  const u32 lane = threadIdx.x & 63;
-  const VItem it = items[item];
-  u64 x = 0;
-  if (it.width <= 4) {
-    if (lane < it.width) x = gl::canon(words[it.leaf_off + lane]);
-  } else {
-#pragma unroll 1
-    for (u32 off = 0; off < it.width; off += 8) {
-      if (lane < 8 && off + lane < it.width) x = words[it.leaf_off + off + lane];
-      x = permute_wave(x, ctx);
-    }
-    x = gl::canon(x);
-  }
-  u32 index = it.index;
-#pragma unroll 1
-  for (u32 s = 0; s < it.n_sib; ++s, index >>= 1) {
-    const u64 up = __shfl_up((unsigned long long)x, 4);  // lanes 4..7 see the current digest
-    const u64 sib = lane < 8 ? words[it.sib_off + 4 * s + (lane & 3)] : 0;
-    const bool sib_left = index & 1;
-    u64 y = 0;
-    if (lane < 4) y = sib_left ? sib : x;
-    else if (lane < 8) y = sib_left ? up : sib;
-    x = gl::canon(permute_wave(y, ctx));
-  }
-  const bool mismatch = lane < 4 && x != words[it.cap_off + 4 * index + lane];
-  if (__any(mismatch) && lane == 0) atomicMin(bad, (int)item + 1);
-}
 
 size_t digests_count(size_t n, unsigned cap_height) {
   size_t c = 0;
@@ -1966,6 +1931,7 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (c->ch) p2mt_challenger_destroy(c->ch);
   if (c->vch) p2mt_challenger_destroy(c->vch);
   if (c->d_verify) (void)hipFree(c->d_verify);
+  if (c->vstreams) p2mt::verify_streams_destroy(c->vstreams);
   if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->vbch) p2mt::challenger_unwrap(c->vbch);
   if (c->d_vbatch) (void)hipFree(c->d_vbatch);
@@ -2532,7 +2498,7 @@ extern "C" int p2mt_circuit_prove_trace(const p2mt_circuit_data* c, int what, ui
 
 // ==================================================================================================== verify
 // circuit_data.verify(proof) (mmr_plonky2_verifier.rs:150): transcript and Merkle paths on the device (two launches chains and
-// two small copies), the field arithmetic on the host (p2mt_verify_host.hip).  *accepted = 1/0; *reason: 0 ok, 10 malformed
+// two small copies) and so does the field arithmetic (p2mt_verify_dev.hip): launches only, one copy back.  *accepted = 1/0; *reason: 0 ok, 10 malformed
 // (length, non-canonical word), 11 vanishing polynomial != Z_H * quotient at zeta (or zeta in the subgroup), 1 proof of work,
 // 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 layer value inconsistent, 5 final polynomial.
 namespace {
@@ -2540,7 +2506,7 @@ namespace {
 // flag | Merkle items
 struct VLayout {
   size_t n_open, off_open, off_fri, off_pi, off_final, final_len, nq, max_items;
-  size_t o_proof, o_cscap, o_fo, o_out, n_out, o_flag, o_items, words;
+  size_t o_proof, o_cscap, o_fo, o_out, n_out, o_flag, o_res, o_items, o_dig, words;
   u32 nred;
 };
 VLayout verify_layout(const p2mt_circuit_data* c) {
@@ -2554,21 +2520,47 @@ VLayout verify_layout(const p2mt_circuit_data* c) {
   L.off_final = L.off_fri + c->fri_len - 1 - 2 * L.final_len;
   L.max_items = L.nq * (4 + L.nred);
   L.o_proof = 8, L.o_cscap = L.o_proof + c->proof_len, L.o_fo = L.o_cscap + 64, L.o_out = L.o_fo + 2 * L.n_open;
-  L.n_out = 8 + 2 + 2 * 8 + 1 + L.nq, L.o_flag = L.o_out + L.n_out + 1, L.o_items = L.o_flag + 1;
-  L.words = L.o_items + (L.max_items * sizeof(VItem) + 7) / 8 + 1;
+  L.n_out = 8 + 2 + 2 * 8 + 1 + L.nq, L.o_flag = L.o_out + L.n_out + 1, L.o_res = L.o_flag + 1, L.o_items = L.o_res + 1;
+  L.o_dig = L.o_items + (L.max_items * sizeof(VItem) + 7) / 8 + 1;
+  L.words = L.o_dig + 4 * L.max_items;
   return L;
 }
 constexpr int kFlagClear = 0x7F7F7F7F;  // "no failing Merkle path" (the kernel keeps the smallest failing item + 1)
 
 // One pass over B proofs (B = 1: dv is the circuit's own block and no batch context is active; B > 1: dv is block 0 of B blocks
 // `stride` bytes apart and the calling thread's batch context is set).  Everything that depends only on the proof -- the whole
-// transcript and every Merkle path -- runs on the device with the proofs in grid z; the field arithmetic runs on host threads.
+// transcript, every Merkle path and all field arithmetic -- runs on the device with the proofs in grid z; the host decides from one small copy.
 int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t stride, const uint64_t* proofs, size_t proof_stride,
                 unsigned B, int* accepted, int* reason) {
   const VLayout L = verify_layout(c);
   const u32 n_cs = c->n_cs, log_n = c->degree_bits, log_big = log_n + kRateBits, nred = L.nred;
   const size_t nq = L.nq;
   hipStream_t st = rt().stream;
+  // everything depends on the transcript only through device memory: the row sponges, the vanishing-polynomial check, the FRI
+  // arithmetic and the path folds are staged beside / behind it (p2mt_verify_dev.hip), and ONE small copy brings back the verdict
+  p2mt::VerifyDevArgs va{};
+  va.d.degree_bits = log_n, va.d.num_wires = kNumWires, va.d.num_routed = kNumRouted, va.d.num_constants = kNumConsts;
+  va.d.num_selectors = c->num_selectors, va.d.num_challenges = kNumCh, va.d.quotient_degree_factor = kQF, va.d.n_kinds = c->n_kinds;
+  for (u32 g = 0; g < kMaxGateTypes; ++g) va.d.kind[g] = c->kind[g], va.d.sel[g] = c->sel[g], va.d.gs[g] = c->gs[g], va.d.ge[g] = c->ge[g];
+  va.fri = c->fri;
+  va.n_polys[0] = n_cs, va.n_polys[1] = kNumWires, va.n_polys[2] = kNumZs, va.n_polys[3] = kNumQuot;
+  va.w_big = h_root_of_unity(log_big), va.w_n = h_root_of_unity(log_n), va.w16 = h_root_of_unity(4);
+  va.o_proof = (u32)L.o_proof, va.o_fo = (u32)L.o_fo, va.o_out = (u32)L.o_out, va.o_cscap = (u32)L.o_cscap;
+  va.off_open = (u32)L.off_open, va.off_fri = (u32)L.off_fri, va.off_final = (u32)L.off_final, va.final_len = (u32)L.final_len;
+  {
+    size_t qw = 0;
+    for (u32 tr = 0; tr < 4; ++tr) qw += va.n_polys[tr] + 4 * (size_t)(log_big - kCapHeight);
+    unsigned log_sz = log_big;
+    for (u32 l = 0; l < nred; ++l) {
+      const unsigned ab = c->fri.reduction_arity_bits[l];
+      qw += ((size_t)2 << ab) + 4 * (size_t)(log_sz - ab - kCapHeight);
+      log_sz -= ab;
+    }
+    va.query_words = (u32)qw;
+  }
+  if (!c->vstreams) P2MT_TRY(p2mt::verify_streams_create(&c->vstreams));
+  int* d_flag = reinterpret_cast<int*>(dv + L.o_flag);      // [0] Merkle: smallest failing item + 1
+  int* d_res = reinterpret_cast<int*>(dv + L.o_res);        // [0] openings ok, [1] FRI: 8 * query + reason
   std::vector<char> live(B, 1);
   for (unsigned b = 0; b < B; ++b) {
     accepted[b] = 0;
@@ -2589,6 +2581,8 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   } else {
     P2MT_HIP(hipMemcpyAsync(dv + L.o_proof, proofs, c->proof_len * 8, hipMemcpyHostToDevice, st));
   }
+  P2MT_TRY(p2mt::batch_fill(d_flag, 0x7F, 16));  // flag word and result word: "nothing failed / nothing reported yet"
+  P2MT_TRY(p2mt::verify_dev_begin(c->vstreams, dv, dv + L.o_dig, va));
   if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(dv + L.o_proof + L.off_pi, 1, c->n_pi, 0, dv + 4));
   else P2MT_TRY(p2mt::batch_fill(dv + 4, 0, 32));
   // the whole transcript depends only on the proof: enqueue it in one go
@@ -2596,6 +2590,7 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   P2MT_TRY(p2mt_challenger_restart_duplex_dev(ch, dv, 8 + 64, d_out, 2 * kNumCh));                          // betas, gammas
   P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + 64, 64, d_out + 2 * kNumCh, kNumCh));           // alphas
   P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + 128, 64, d_out + 3 * kNumCh, 2));                // zeta
+  P2MT_TRY(p2mt::verify_dev_after_zeta(c->vstreams, dv, d_res, c->d_kis, va));
   hipLaunchKernelGGL(k_opening_unset, bgrid(grid_for(2 * L.n_open)), dim3(kBlock), 0, st, (const u64*)(dv + L.o_proof + L.off_open),
                      dv + L.o_fo, n_cs, barg());
   P2MT_LAUNCH_CHECK();
@@ -2604,133 +2599,37 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
     P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + L.off_fri + 64 * l, 64, d_out + 10 + 2 * l, 2));  // FRI betas
   P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + L.off_final, 2 * L.final_len + 1, d_out + 26, 1));    // PoW response
   P2MT_TRY(p2mt_challenger_get_challenges_dev(ch, nq, d_out + 27));                                           // query indices
-  std::vector<u64> out((size_t)B * L.n_out), pi_hash((size_t)B * 4);
-  if (B > 1) {
-    P2MT_HIP(hipMemcpy2DAsync(out.data(), L.n_out * 8, d_out, stride, L.n_out * 8, B, hipMemcpyDeviceToHost, st));
-    P2MT_HIP(hipMemcpy2DAsync(pi_hash.data(), 32, dv + 4, stride, 32, B, hipMemcpyDeviceToHost, st));
-  } else {
-    P2MT_HIP(hipMemcpyAsync(out.data(), d_out, L.n_out * 8, hipMemcpyDeviceToHost, st));
-    P2MT_HIP(hipMemcpyAsync(pi_hash.data(), dv + 4, 32, hipMemcpyDeviceToHost, st));
-  }
-  P2MT_HIP(hipStreamSynchronize(st));
-
-  p2mt::VerifyDesc vd{};
-  vd.degree_bits = log_n, vd.num_wires = kNumWires, vd.num_routed = kNumRouted, vd.num_constants = kNumConsts;
-  vd.num_selectors = c->num_selectors, vd.num_challenges = kNumCh, vd.quotient_degree_factor = kQF, vd.n_kinds = c->n_kinds;
-  for (u32 g = 0; g < kMaxGateTypes; ++g) vd.kind[g] = c->kind[g], vd.sel[g] = c->sel[g], vd.gs[g] = c->gs[g], vd.ge[g] = c->ge[g];
-  const size_t big = (size_t)1 << log_big;
-  const uint64_t n_polys[4] = {n_cs, kNumWires, kNumZs, kNumQuot};
-  const u32 cap_off[4] = {(u32)L.o_cscap, (u32)L.o_proof, (u32)L.o_proof + 64, (u32)L.o_proof + 128};
-  const size_t n_items = L.max_items;
-  std::vector<VItem> items((size_t)B * n_items);
-  std::vector<u64> x_indices((size_t)B * nq);
-  std::vector<char> is_layer(n_items);
-  // host arithmetic, one proof per task; the tasks are independent and pure, so a batch spreads them over a few threads
-  auto for_each_proof = [&](auto&& fn) {
-    const unsigned T = B > 1 ? std::min<unsigned>(B, std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()))) : 1;
-    if (T <= 1) {
-      for (unsigned b = 0; b < B; ++b) fn(b);
-      return;
-    }
-    // A worker that throws (std::bad_alloc in a per-proof buffer) must not reach std::terminate, and a pool that cannot be
-    // created (std::system_error) must not leave joinable threads behind: the first exception is carried to the calling thread
-    // and rethrown there, where the entry point's abi_guard turns it into a status code.
-    std::exception_ptr first_exc;
-    std::mutex exc_mutex;
-    std::vector<std::thread> pool;
-    auto body = [&](unsigned t) {
-      try {
-        for (unsigned b = t; b < B; b += T) fn(b);
-      } catch (...) {
-        std::lock_guard<std::mutex> g(exc_mutex);
-        if (!first_exc) first_exc = std::current_exception();
-      }
-    };
-    try {
-      pool.reserve(T);
-      for (unsigned t = 1; t < T; ++t) pool.emplace_back(body, t);
-    } catch (...) {  // fewer workers than planned: their strides are done below by this thread
-      std::lock_guard<std::mutex> g(exc_mutex);
-      if (!first_exc) first_exc = std::current_exception();
-    }
-    const unsigned started = (unsigned)pool.size() + 1;
-    body(0);
-    for (unsigned t = started; t < T; ++t) body(t);
-    for (auto& th : pool) th.join();
-    if (first_exc) std::rethrow_exception(first_exc);
+  P2MT_TRY(p2mt::verify_dev_finish(c->vstreams, dv, dv + L.o_items, dv + L.o_dig, d_flag, d_res, va));
+  // results, gathered per proof: the proof-of-work response (d_out[26]) and the two words {Merkle flag, -} {openings ok, FRI}
+  struct Verdict {
+    int flag, pad, ok, fri;
   };
-  for_each_proof([&](unsigned b) {
-    const uint64_t* proof = proofs + (size_t)b * proof_stride;
-    const u64* o = &out[(size_t)b * L.n_out];
-    if (live[b]) {
-      reason[b] = 11;
-      if (!p2mt::verify_openings_host(vd, c->k_is, o + 3 * kNumCh, proof + L.off_open, &pi_hash[(size_t)b * 4], o, o + kNumCh, o + 2 * kNumCh)) live[b] = 0;
-    }
-    if (live[b]) {
-      reason[b] = 1;
-      if (c->fri.proof_of_work_bits && (o[26] >> (64 - c->fri.proof_of_work_bits)) != 0) live[b] = 0;
-    }
-    // Merkle paths of every query: oracle rows against the four caps, layer cosets against the layer caps
-    VItem* it = &items[(size_t)b * n_items];
-    size_t k = 0, w = L.o_proof + L.off_fri + (size_t)nred * 64;
-    for (size_t q = 0; q < nq; ++q) {
-      size_t x_index = (size_t)(o[27 + q] % big);
-      x_indices[(size_t)b * nq + q] = x_index;
-      for (u32 tr = 0; tr < 4; ++tr) {
-        it[k] = VItem{(u32)w, (u32)n_polys[tr], (u32)x_index, (u32)(w + n_polys[tr]), log_big - kCapHeight, cap_off[tr]};
-        if (b == 0) is_layer[k] = 0;
-        ++k;
-        w += n_polys[tr] + 4 * (size_t)(log_big - kCapHeight);
-      }
-      unsigned log_sz = log_big;
-      for (u32 l = 0; l < nred; ++l) {
-        const unsigned ab = c->fri.reduction_arity_bits[l];
-        const size_t arity = (size_t)1 << ab;
-        x_index >>= ab;
-        const u32 n_sib = log_sz - ab - kCapHeight;
-        it[k] = VItem{(u32)w, (u32)(2 * arity), (u32)x_index, (u32)(w + 2 * arity), n_sib, (u32)(L.o_proof + L.off_fri + 64 * l)};
-        if (b == 0) is_layer[k] = 1;
-        ++k;
-        w += 2 * arity + 4 * (size_t)n_sib;
-        log_sz -= ab;
-      }
-    }
-  });
-  int* d_flag = reinterpret_cast<int*>(dv + L.o_flag);
-  VItem* d_items = reinterpret_cast<VItem*>(dv + L.o_items);
-  P2MT_TRY(p2mt::batch_fill(d_flag, 0x7F, 8));
+  std::vector<u64> pow_resp(B);
+  std::vector<Verdict> vr(B);
+  static_assert(sizeof(Verdict) == 16, "two consecutive device words");
   if (B > 1) {
-    P2MT_HIP(hipMemcpy2DAsync(d_items, stride, items.data(), n_items * sizeof(VItem), n_items * sizeof(VItem), B, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpy2DAsync(pow_resp.data(), 8, d_out + 26, stride, 8, B, hipMemcpyDeviceToHost, st));
+    P2MT_HIP(hipMemcpy2DAsync(vr.data(), 16, dv + L.o_flag, stride, 16, B, hipMemcpyDeviceToHost, st));
   } else {
-    P2MT_HIP(hipMemcpyAsync(d_items, items.data(), n_items * sizeof(VItem), hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(pow_resp.data(), d_out + 26, 8, hipMemcpyDeviceToHost, st));
+    P2MT_HIP(hipMemcpyAsync(vr.data(), dv + L.o_flag, 16, hipMemcpyDeviceToHost, st));
   }
-  hipLaunchKernelGGL(k_verify_merkle, bgrid((unsigned)((n_items + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st,
-                     (const u64*)dv, (const VItem*)d_items, (u32)n_items, d_flag, barg(), p2mt::perm_ctx());
-  P2MT_LAUNCH_CHECK();
-  std::vector<int> flags(B, 0);
-  if (B > 1) P2MT_HIP(hipMemcpy2DAsync(flags.data(), sizeof(int), d_flag, stride, sizeof(int), B, hipMemcpyDeviceToHost, st));
-  else P2MT_HIP(hipMemcpyAsync(flags.data(), d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
-  for_each_proof([&](unsigned b) {
-    if (!live[b]) return;
-    if (flags[b] != kFlagClear) {
-      reason[b] = is_layer[(size_t)flags[b] - 1] ? 4 : 2;
-      return;
+  for (unsigned b = 0; b < B; ++b) {
+    if (!live[b]) continue;  // reason 10
+    if (vr[b].ok != 1) {
+      reason[b] = 11;
+    } else if (c->fri.proof_of_work_bits && (pow_resp[b] >> (64 - c->fri.proof_of_work_bits)) != 0) {
+      reason[b] = 1;
+    } else if (vr[b].flag != kFlagClear) {
+      reason[b] = ((size_t)(vr[b].flag - 1) % (4 + nred)) >= 4 ? 4 : 2;
+    } else if (vr[b].fri != kFlagClear) {
+      reason[b] = vr[b].fri & 7;
+    } else {
+      reason[b] = 0;
+      accepted[b] = 1;
     }
-    const uint64_t* proof = proofs + (size_t)b * proof_stride;
-    const u64* o = &out[(size_t)b * L.n_out];
-    // openings in transcript order for the FRI arithmetic (host reorder of the OpeningSet)
-    std::vector<u64> fo(2 * L.n_open);
-    const u64* so = proof + L.off_open;
-    const size_t a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot);
-    std::copy(so, so + a, fo.begin());
-    std::copy(so + a + 2 * kNumCh, so + a + 2 * kNumCh + tail, fo.begin() + a);
-    std::copy(so + a, so + a + 2 * kNumCh, fo.begin() + a + tail);
-    const int r = p2mt::verify_fri_queries_host(c->fri, n_polys, 4, kNumCh, o + 3 * kNumCh, fo.data(), o + 8, o + 10, proof + L.off_fri,
-                                                c->fri_len, &x_indices[(size_t)b * nq]);
-    reason[b] = r;
-    accepted[b] = r == 0;
-  });
+  }
   return P2MT_OK;
 }
 }  // namespace

@@ -190,17 +190,26 @@ int fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_ora
 int challenger_wrap(void* d_state, p2mt_challenger** out);
 void challenger_unwrap(p2mt_challenger* c);
 constexpr size_t kChallengerStateBytes = 8 * (12 + 8 + 8) + 8;
-// exported by p2mt_verify_host.hip: the field arithmetic of CircuitData::verify (the hashing runs on the device)
+// p2mt_verify_dev.hip: the field arithmetic of CircuitData::verify, on the device like the hashing (p2mt_circuit.hip)
 struct VerifyDesc {
   uint32_t degree_bits, num_wires, num_routed, num_constants, num_selectors, num_challenges, quotient_degree_factor, n_kinds;
   uint32_t kind[16], sel[16], gs[16], ge[16];
 };
-int verify_openings_host(const VerifyDesc& d, const uint64_t* k_is, const uint64_t zeta[2], const uint64_t* openings,
-                         const uint64_t pi_hash[4], const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas);
-int verify_fri_queries_host(const p2mt_fri_params& p, const uint64_t* n_polys, size_t n_oracles, size_t n_next,
-                            const uint64_t zeta[2], const uint64_t* openings, const uint64_t alpha[2], const uint64_t* betas,
-                            const uint64_t* fri_proof, size_t fri_len, const uint64_t* x_indices);
-
+// the same arithmetic on the device (p2mt_verify_dev.hip): word offsets are relative to the per-proof block `dv` of verify_pass
+struct VerifyDevArgs {
+  VerifyDesc d;
+  p2mt_fri_params fri;
+  uint64_t n_polys[4];
+  uint64_t w_big, w_n, w16;  // primitive roots of unity of order 2^(degree_bits + rate_bits), 2^degree_bits, 16
+  uint32_t o_proof, o_fo, o_out, o_cscap, off_open, off_fri, off_final, final_len, query_words;
+};
+// staged behind the transcript (see p2mt_verify_dev.hip): begin after the proof upload, after_zeta once zeta is squeezed, finish at the end
+int verify_streams_create(void** out);
+void verify_streams_destroy(void* vs);
+int verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const VerifyDevArgs& a);
+int verify_dev_after_zeta(void* vs, const uint64_t* dv, int* d_res, const uint64_t* d_k_is, const VerifyDevArgs& a);
+int verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const uint64_t* d_digests, int* d_flag, int* d_res,
+                      const VerifyDevArgs& a);
 }  // namespace p2mt
 
 #define P2MT_HIP(x)                                                           \
