@@ -49,6 +49,7 @@ typedef enum p2mt_status {
 int p2mt_init(int device);              /* select device, upload Poseidon tables; idempotent */
 int p2mt_device_count(void);            /* number of visible HIP devices (0 => nothing can run) */
 int p2mt_set_stream(void *hip_stream);  /* stream for all subsequent launches of the CALLING THREAD (NULL = default stream) */
+int p2mt_get_stream(void **hip_stream_out); /* the calling thread's current library stream (to restore after a scoped p2mt_set_stream) */
 /* Give the calling host thread its own non-blocking stream (and, implicitly, its own scratch buffers): from then on its
  * calls enqueue there.  This is how several provers run concurrently on one GPU -- one handle (MMR, circuit data,
  * challenger) per thread; a 64-row prove occupies a few CUs for ~2.6 ms, so independent proofs overlap almost freely. */
@@ -78,7 +79,8 @@ int p2mt_get_build_config(int *subtree_levels, int *tile_log, int *subtree_block
 /* Levels the stage-1 launch of a build of n_leaves (from an empty MMR) fuses: with per-lane subtrees (the default) the subtree size
  * adapts to the build -- 2^4 leaves per lane from 2^22 leaves up, 2^3 / 2^2 for smaller builds, so that the launch still puts ~4
  * wavefronts on every SIMD (a 2^21-leaf shard of an 8-GPU strong-scaling run is otherwise two wavefronts per SIMD running 15
- * dependent hashes each) -- unless the environment pins it (P2MT_SUBTREE=2|3|4|5).  0 = fused tiles. */
+ * dependent hashes each) -- unless the environment pins it (P2MT_SUBTREE=2|3|4|5).  > 0: levels; a negative value is a status
+ * code (the library could not initialise), never a configuration. */
 int p2mt_mmr_stage1_levels(size_t n_leaves);
 /* Debug/test knob: make every wave of the mds=2 path take its exact fallback (results must not change). */
 int p2mt_debug_force_fallback(int on);
@@ -406,6 +408,9 @@ size_t p2mt_cb_num_gates(const p2mt_circuit_builder *b);
 /* builder.build::<PoseidonGoldilocksConfig>() (:89): public-input hash + PublicInputGate, ConstantGates, padding to a power
  * of two with NoopGates, selector / constant / sigma polynomials and their commitment on the device, circuit digest.
  * The builder must not be used afterwards (plonky2's build consumes it); destroy it.  P2MT_EINVAL for more than 2^12 rows. */
+/* Limits (both are what the reference's circuits need, not a property of the method): at most 2^12 rows after padding
+ * (P2MT_EINVAL beyond; the outer circuit of mmr_plonky2_verifier_1_recursion is 2^12), and ONE level of recursion -- see
+ * p2mt_cb_verify_proof. */
 int p2mt_cb_build(p2mt_circuit_builder *b, p2mt_circuit_data **out);
 int p2mt_circuit_destroy(p2mt_circuit_data *c);
 typedef struct p2mt_circuit_info {
@@ -475,8 +480,9 @@ size_t p2mt_batch_prover_batch(const p2mt_batch_prover *b);
  * work, 2 Merkle proof of an oracle row, 4 Merkle proof of a FRI layer, 3 inconsistent layer value, 5 final polynomial. */
 int p2mt_circuit_verify(p2mt_circuit_data *c, const uint64_t *proof, size_t proof_len, int *accepted, int *reason);
 /* circuit_data.verify for n proofs of this circuit (proofs[i] at proofs + i * proof_stride words): passes of up to 256 proofs with
- * the proof index in a grid dimension of every launch -- one transcript replay and one Merkle-path launch per pass -- and the
- * field arithmetic of each proof on a few host threads.  accepted[i] / reason[i] as p2mt_circuit_verify. */
+ * the proof index in a grid dimension of every launch: one transcript replay, the row sponges and the vanishing-polynomial check
+ * beside it, the FRI arithmetic and the path folds behind it, one small copy back per pass (csrc/p2mt_verify_dev.hip; nothing of a
+ * verification runs on the host).  accepted[i] / reason[i] as p2mt_circuit_verify. */
 int p2mt_circuit_verify_batch(p2mt_circuit_data *c, const uint64_t *proofs, size_t n, size_t proof_stride, int *accepted, int *reason);
 /* ---- the outer circuit of the recursion (mmr_plonky2_verifier_1_recursion.rs:84-140): plonky2's in-circuit verifier.
  * `inner` stands for `inner_circuit_data.common` (and `.verifier_only` for the witness): the built inner circuit.

@@ -43,6 +43,8 @@ def stage1_info(n_leaves=1 << 24):
     _native.check(lib().p2mt_get_build_config(C.byref(sub), C.byref(tile), C.byref(blk)))
     if sub.value:
         lv = int(lib().p2mt_mmr_stage1_levels(n_leaves))
+        if lv < 0:
+            _native.check(lv)  # a status code, not a level count
         return {"key": "subtree%d" % lv, "levels": lv,
                 "kernel": "k_mmr_subtree (stage 1: each lane builds levels 1..%d of its own 2^%d leaves)" % (lv, lv)}
     lv = tile.value - 6

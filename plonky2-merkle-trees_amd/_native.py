@@ -29,6 +29,7 @@ SIGNATURES = {
     "p2mt_init": (C.c_int, [C.c_int]),
     "p2mt_device_count": (C.c_int, []),
     "p2mt_set_stream": (C.c_int, [voidp]),
+    "p2mt_get_stream": (C.c_int, [C.POINTER(voidp)]),
     "p2mt_thread_stream_create": (C.c_int, []),
     "p2mt_thread_stream_destroy": (C.c_int, []),
     "p2mt_set_throughput_mode": (C.c_int, [C.c_int]),

@@ -930,6 +930,7 @@ extern "C" int p2mt_fri_params_standard(unsigned degree_bits, p2mt_fri_params* o
 }
 
 extern "C" size_t p2mt_fri_proof_len(const p2mt_fri_params* p, size_t n_oracles, const uint64_t* n_polys) {
+  // (pure integer arithmetic on caller data: nothing here can throw, so no abi_guard; 0 = bad parameters)
   if (!params_ok(p) || (n_oracles && !n_polys)) return 0;
   const unsigned log_big = p->degree_bits + p->rate_bits;
   size_t len = (size_t)p->num_reductions * ((size_t)4 << p->cap_height);

@@ -770,8 +770,14 @@ extern "C" int p2mt_mmr_extend(p2mt_mmr* m, const uint64_t* leaves, size_t k) {
 extern "C" size_t p2mt_mmr_num_leaves(const p2mt_mmr* m) { return m ? m->n_leaves + m->pending.size() : 0; }
 extern "C" size_t p2mt_mmr_len(const p2mt_mmr* m) { return m ? mmr_len_for(m->n_leaves + m->pending.size()) : 0; }
 extern "C" const uint64_t* p2mt_mmr_elements_dev(const p2mt_mmr* m) {
-  if (!m || mmr_flush(m) != P2MT_OK) return nullptr;
-  return m->elements;
+  const uint64_t* out = nullptr;  // NULL on any failure, an exception inside the flush included (p2mt_last_error has the reason)
+  (void)p2mt::abi_guard([&]() -> int {
+    if (!m) return p2mt::fail(P2MT_EINVAL, "null handle");
+    P2MT_TRY(mmr_flush(m));
+    out = m->elements;
+    return P2MT_OK;
+  });
+  return out;
 }
 
 extern "C" int p2mt_mmr_copy_elements(const p2mt_mmr* m, size_t first, size_t count, uint64_t* out) {

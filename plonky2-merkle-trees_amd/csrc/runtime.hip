@@ -409,6 +409,14 @@ extern "C" int p2mt_set_stream(void* hip_stream) {
   });
 }
 
+extern "C" int p2mt_get_stream(void** hip_stream_out) {
+  return p2mt::abi_guard([&]() -> int {
+  if (!hip_stream_out) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  *hip_stream_out = static_cast<void*>(rt().stream);
+  return P2MT_OK;
+  });
+}
+
 extern "C" int p2mt_sync(void) {
   return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());
@@ -446,10 +454,12 @@ extern "C" int p2mt_get_variant(int* mds, int* partial) {
 }
 
 extern "C" int p2mt_mmr_stage1_levels(size_t n_leaves) {
-  if (p2mt::ensure_init() != P2MT_OK) return 0;
+  return p2mt::abi_guard([&]() -> int {
+  P2MT_TRY(p2mt::ensure_init());  // a negative status, never a level count, when the library cannot initialise
   if (rt().mds != 2) return (int)rt().tile_log - 6;
   const unsigned lv = p2mt::subtree_levels_for(n_leaves);
   return lv ? (int)lv : (int)rt().tile_log - 6;
+  });
 }
 
 extern "C" int p2mt_get_build_config(int* subtree_levels, int* tile_log, int* subtree_block) {

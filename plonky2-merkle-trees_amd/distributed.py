@@ -101,11 +101,24 @@ class ShardedMMR:
             self._d_mine = torch.zeros(4, dtype=torch.int64, device="cuda")
             self._h_all = torch.zeros(2 * w * 4, dtype=torch.int64).pin_memory()
         lib = N.lib()
-        N.check(lib.p2mt_mmr_root_dev(self.local._h, N.ptr(self._d_mine)))
-        self.dist.all_gather_into_tensor(self._d_all[:4 * w], self._d_mine)
-        base = self._d_all.data_ptr()
-        N.check(lib.p2mt_mmr_combine_shard_roots_dev(base, w, base + 32 * w if w > 1 else None, base + 32 * (2 * w - 1)))
-        self._h_all.copy_(self._d_all)  # synchronises (device -> pinned host)
+        # The library enqueues on ITS stream and torch.distributed on torch's current stream: nothing else orders the root kernel
+        # before the collective or the collective before the combine launch.  For the duration of the exchange the library is
+        # pointed at torch's current stream (whatever it is: the null stream, a torch.cuda.stream(...) context, a stream the
+        # caller installed with p2mt_set_stream earlier), after draining what it had queued on its own; restored afterwards.
+        import ctypes as C
+        cur = torch.cuda.current_stream().cuda_stream
+        saved = C.c_void_p()
+        N.check(lib.p2mt_get_stream(C.byref(saved)))
+        N.check(lib.p2mt_sync())
+        N.check(lib.p2mt_set_stream(cur))
+        try:
+            N.check(lib.p2mt_mmr_root_dev(self.local._h, N.ptr(self._d_mine)))
+            self.dist.all_gather_into_tensor(self._d_all[:4 * w], self._d_mine)
+            base = self._d_all.data_ptr()
+            N.check(lib.p2mt_mmr_combine_shard_roots_dev(base, w, base + 32 * w if w > 1 else None, base + 32 * (2 * w - 1)))
+            self._h_all.copy_(self._d_all)  # synchronises torch's current stream (device -> pinned host)
+        finally:
+            N.check(lib.p2mt_set_stream(saved))
         host = self._h_all.numpy().view(np.uint64).reshape(2 * w, 4)
         self.shard_roots = host[:w].copy()
         self.top_nodes = host[w:2 * w - 1].copy()

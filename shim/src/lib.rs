@@ -1,14 +1,21 @@
 //! The reference crate's module layout (/root/reference/src/lib.rs:1-2) over the MI355X library:
 //! `simple_merkle_tree::simple_merkle_tree::{MerkleTree, verify_merkle_proof}` and
 //! `mmr::merkle_mountain_ranges::{MMR, MMR_proof, get_mmr_index, get_heights_bitmap_for_mmr_size}` keep their names and
-//! signatures; every hash runs in libp2mt_hip.so.  A caller switches by changing the crate name in its `use` lines.
+//! signatures; every hash runs in libp2mt_hip.so.  `mmr::{common, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion}` keep the
+//! reference's circuit constructors (names, arguments, tuple returns) over `plonk::CircuitBuilder` / `CircuitData::prove` /
+//! `verify`, which forward to the library's prover.  A caller switches by changing the crate name in its `use` lines; the two
+//! call-site edits that remain are listed in INTEGRATION.md (the `elements` field, by-reference getters).
 pub mod ffi;
 
 pub mod simple_merkle_tree {
     pub mod simple_merkle_tree;
 }
+pub mod plonk;
 pub mod mmr {
+    pub mod common;
     pub mod merkle_mountain_ranges;
+    pub mod mmr_plonky2_verifier;
+    pub mod mmr_plonky2_verifier_1_recursion;
 }
 
 use plonky2::field::goldilocks_field::GoldilocksField;

@@ -19,6 +19,14 @@ pub struct MMR_proof {
     pub peaks: Vec<HashOut<GoldilocksField>>,
 }
 
+/// :25-28 (declared by the reference, private fields, constructed nowhere: kept so that the type name resolves)
+pub struct MMR_extended_proof {
+    #[allow(dead_code)]
+    mmr_proof: MMR_proof,
+    #[allow(dead_code)]
+    root_subtree: HashOut<GoldilocksField>,
+}
+
 /// :39-81
 pub fn get_heights_bitmap_for_mmr_size(mmr_size: usize) -> (u64, usize) {
     let mut rem = 0usize;
@@ -58,7 +66,9 @@ impl MMR {
         ok(unsafe { ffi::p2mt_mmr_extend(self.h, words.as_ptr(), words.len()) })
     }
 
-    /// the reference's public field `elements` (:11), copied out of HBM
+    /// The reference's PUBLIC FIELD `elements` (:11) is a method here: the array lives in HBM (1 GB at 2^24 leaves) and a field
+    /// would need a host mirror kept coherent on every add_leaf.  This is the one source edit a caller makes:
+    /// `mmr.elements.len()` -> `mmr.elements().len()` (the reference's own test does this at :339).
     pub fn elements(&self) -> Vec<HashOut<GoldilocksField>> {
         let len = unsafe { ffi::p2mt_mmr_len(self.h) };
         let mut words = vec![0u64; 4 * len];

@@ -149,7 +149,8 @@ def test_rust_ffi_matches_header():
     have = re.findall(r"pub fn (p2mt_\w+)\(", ffi)
     assert sorted(have) == sorted(declared)
     # the shim's modules call only functions the extern block declares
-    for rel in ("lib.rs", "simple_merkle_tree/simple_merkle_tree.rs", "mmr/merkle_mountain_ranges.rs"):
+    for rel in ("lib.rs", "plonk.rs", "simple_merkle_tree/simple_merkle_tree.rs", "mmr/merkle_mountain_ranges.rs", "mmr/common.rs",
+                "mmr/mmr_plonky2_verifier.rs", "mmr/mmr_plonky2_verifier_1_recursion.rs"):
         src = open(os.path.join(ROOT, "shim", "src", rel)).read()
         for name in set(re.findall(r"ffi::(p2mt_\w+)\(", src)):
             assert name in declared, (rel, name)
@@ -166,3 +167,44 @@ def test_rust_ffi_matches_header():
                 "pub fn get_merkle_proof(self, leaf_index: usize) -> Vec<HashOut<GoldilocksField>>",
                 "pub fn get_in_between_hashes(self, leaf_index: usize) -> Vec<HashOut<GoldilocksField>>"):
         assert sig in mt, sig
+
+
+def test_rust_shim_circuit_surface():
+    """The circuit side of the shim (source only): the reference's module list (/root/reference/src/mmr/mod.rs), its constructor names
+    with their tuple returns, and the Plonky2 surface they are written against -- with arities checked against the extern block, so a
+    header change that the shim does not follow fails here rather than at a maintainer's first `cargo build`."""
+    src = lambda rel: open(os.path.join(ROOT, "shim", "src", rel)).read()
+    lib = src("lib.rs")
+    for mod in ("common", "merkle_mountain_ranges", "mmr_plonky2_verifier", "mmr_plonky2_verifier_1_recursion"):
+        assert "pub mod %s;" % mod in lib, mod
+    common = src("mmr/common.rs")
+    for sig in ("pub fn equal(builder: &mut CircuitBuilder, first: HashOutTarget, second: HashOutTarget) -> BoolTarget",
+                "pub fn or_list(builder: &mut CircuitBuilder, ins: Vec<BoolTarget>) -> BoolTarget",
+                "pub fn pick_hash(builder: &mut CircuitBuilder, option1: HashOutTarget, option2: HashOutTarget, pick_left: BoolTarget) -> HashOutTarget"):
+        assert sig in common, sig
+    # pick_hash: the reference's call order (not, four mul on option2, four mul_add on option1) is what fixes the gate layout
+    body = common[common.index("pub fn pick_hash"):]
+    assert body.index("builder.not(") < body.index("builder.mul(") < body.index("builder.mul_add(")
+    assert "pub fn verify_mmr_proof_circuit(nr_merkle_proof_elms: usize, nr_peaks: usize) -> (CircuitData, Target, Vec<(HashOutTarget, BoolTarget)>, Vec<HashOutTarget>)" \
+        in src("mmr/mmr_plonky2_verifier.rs")
+    rec = src("mmr/mmr_plonky2_verifier_1_recursion.rs")
+    assert "pub fn verify_inner_merkle_proof_circuit(nr_merkle_proof_elms: usize, nr_peaks: usize) -> (CircuitData, Target, Vec<(HashOutTarget, BoolTarget)>)" in rec
+    assert "-> (CircuitData, ProofWithPublicInputsTarget, VerifierCircuitTarget, Vec<HashOutTarget>)" in rec
+    plonk = src("plonk.rs")
+    for name in ("pub fn prove(&self, pw: PartialWitness)", "pub fn verify(&self, proof: ProofWithPublicInputs)", "pub fn set_target(",
+                 "pub fn set_hash_target(", "pub fn set_bool_target(", "pub fn set_proof_with_pis_target(", "pub fn set_verifier_data_target(",
+                 "pub fn add_virtual_proof_with_pis(", "pub fn add_virtual_verifier_data(", "pub fn verify_proof(", "pub fn build(self) -> CircuitData"):
+        assert name in plonk, name
+    # every ffi call in plonk.rs passes as many arguments as the extern block declares
+    ffi = src("ffi.rs")
+    arity = {m.group(1): (0 if not m.group(2).strip() else m.group(2).count(",") + 1) for m in re.finditer(r"pub fn (p2mt_\w+)\(([^)]*)\)", ffi)}
+    for m in re.finditer(r"ffi::(p2mt_\w+)\(", plonk):
+        name, i, depth, commas, any_arg = m.group(1), m.end(), 1, 0, False
+        while depth:
+            ch = plonk[i]
+            if ch in "([": depth += 1
+            elif ch in ")]": depth -= 1
+            elif ch == "," and depth == 1: commas += 1
+            elif depth == 1 and not ch.isspace(): any_arg = True
+            i += 1
+        assert (commas + 1 if any_arg else 0) == arity[name], (name, commas + 1, arity[name])
