@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void k_lde12_tables(const u64* __restrict__
 __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restrict__ coeffs_, unsigned rate_bits, unsigned n_polys,
                                                               const u64* __restrict__ coset_pow, const u64* __restrict__ ta_,
                                                               const u64* __restrict__ tb_, const u64* __restrict__ tw_half,
-                                                              u64* __restrict__ out_, BatchArg ba) {
+                                                              u64* __restrict__ out_, unsigned force, BatchArg ba) {
   using namespace lde12;
   __shared__ __attribute__((aligned(16))) u64 buf[16 * kRowA];
   const unsigned t = threadIdx.x;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restr
 #pragma unroll
   for (int r = 0; r < 16; ++r) buf[t * kRowC + r] = gl::canon(x[r]);
   __syncthreads();
-  if (__builtin_expect(__syncthreads_or(sticky != 0), 0)) {  // rare: the whole workgroup redoes it exactly
+  if (__builtin_expect(__syncthreads_or(sticky != 0) || force, 0)) {  // rare (or forced by the tests): the workgroup redoes it exactly
     for (unsigned m = t; m < 4096; m += kBlock) buf[m] = cmul(c[m], cp[m]);
     __syncthreads();
     lds_dif(buf, 12, 0, tw_half);
@@ -1128,7 +1128,7 @@ int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned
       const u64 *ta, *tb;
       P2MT_TRY(get_lde12_tables(twf, &ta, &tb));
       hipLaunchKernelGGL(k_coset_lde12_v2, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), 0, rt().stream, d_coeffs,
-                         rate_bits, (unsigned)n_polys, cp, ta, tb, tw, d_out, barg());
+                         rate_bits, (unsigned)n_polys, cp, ta, tb, tw, d_out, rt().force_fallback ? 1u : 0u, barg());
     }
   } else {
     hipLaunchKernelGGL(k_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)8 << log_n, rt().stream,

@@ -55,6 +55,25 @@ def test_coset_lde_vs_oracle(pkg, oracle, log_n, rate_bits):
         assert np.array_equal(out[j], oracle.coset_lde(c[j], rate_bits))
 
 
+def test_coset_lde_2pow12_fast_path_and_forced_redo(pkg, oracle):
+    """k_coset_lde12_v2 (shift-only radix-16 passes, flag-form arithmetic): 19 polynomials (two full groups of 8 in the XCD-aware
+    block order + a partial group in plain order), non-canonical and extreme coefficients among them, against the oracle, every word;
+    then the same with the flagged-workgroup exact radix-2 redo forced for every workgroup."""
+    c = rand((19, 4096), 77)
+    c[1, :] = np.arange(1, 4097, dtype=np.uint64)
+    ext = np.array([P, P + 1, 0xFFFFFFFFFFFFFFFF, 0, 1, P - 1, 0xFFFFFFFF00000000, 0xFFFFFFFF, 1 << 63, 0xFFFFFFFEFFFFFFFF], dtype=np.uint64)
+    c[2, :] = np.resize(ext, 4096)
+    want = [oracle.coset_lde(c[j], 3) for j in range(19)]
+    for force in (0, 1):
+        pkg.lib().p2mt_debug_force_fallback(force)
+        try:
+            out = pkg.coset_lde(c, 3)
+        finally:
+            pkg.lib().p2mt_debug_force_fallback(0)
+        for j in range(19):
+            assert np.array_equal(out[j], want[j]), (force, j)
+
+
 def test_large_fft_properties(pkg):
     """2^20-point transforms (the four-step path): round trip, linearity and a direct evaluation."""
     log_n = 20
