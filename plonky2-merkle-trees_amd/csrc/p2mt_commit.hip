@@ -193,6 +193,20 @@ __global__ __launch_bounds__(kBlock) void k_ifft_coset_lde(const u64* __restrict
   for (unsigned q = threadIdx.x; q < n; q += kBlock) o[q] = buf[q];
 }
 
+// The scaling half of the x2^r coset LDE for transforms above 2^12 points: row = p * 2^r + brev_r(j) of `out` gets
+// c_p[m] * (shift * w_N^j)^m, m = 0 .. n-1 (natural order), ready for the in-place DIF.  The power is built per thread from two
+// exponentiations (base^(256 * (m / 256)) once per block, times base^(m % 256)): ~40 multiplications per element against the
+// transform's ~100.
+__global__ __launch_bounds__(kBlock) void k_coset_scale_rows(const u64* __restrict__ coeffs, unsigned log_n, unsigned rate_bits, u64 shift,
+                                                             u64 w_big, u64* __restrict__ out) {
+  const size_t m = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned row = blockIdx.y, poly = row >> rate_bits, c = row & ((1u << rate_bits) - 1), j = brev32(c, rate_bits);
+  if (m >= ((size_t)1 << log_n)) return;
+  const u64 base = gl::mul(shift, gl::pow(w_big, j));
+  const u64 pw = gl::mul(gl::pow(base, (u64)blockIdx.x * kBlock), gl::pow(base, threadIdx.x));
+  out[((size_t)row << log_n) + m] = cmul(coeffs[((size_t)poly << log_n) + m], pw);
+}
+
 // ---------------------------------------------------------------- register-blocked 2^12 coset LDE
 // The streaming version of k_coset_lde for n = 4096 (the d = 12 circuits of config 4).  Each of the 256 threads
 // keeps 16 points in registers and the transform is three radix-16 passes (4096 = 16 x 16 x 16), so the data
@@ -1112,8 +1126,23 @@ extern "C" int p2mt_ntt_batch(uint64_t* data, unsigned log_n, size_t n_polys, in
 // LDE into leaf order (poly-major): d_out[p][brev(i)] = f_p(shift * w_N^i)
 int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned rate_bits, u64 shift, size_t n_polys,
                                    u64* d_out) {
-  if (log_n > kLdsLog) return p2mt::fail(P2MT_EINVAL, "coset_lde: log_n > 12 not supported yet");
   if (rate_bits > 8 || log_n + rate_bits > 32) return p2mt::fail(P2MT_EINVAL, "coset_lde: bad rate_bits");
+  if (log_n > kLdsLog) {
+    // A transform that does not fit one workgroup's LDS: coset j of polynomial p is row p * 2^r + brev_r(j) of the output, so the
+    // scaling writes c_m (s w_N^j)^m straight into its row and ONE in-place DIF over all n_polys * 2^r rows (natural -> bit-reversed,
+    // which is leaf order) finishes it.  General, not fast: the stages above 2^12 are radix-2 passes over HBM (only the 2^20-point
+    // natural-order transform has the two-pass kernel so far); the reference's circuits end at 2^12.
+    if (p2mt::batch_B() != 1) return p2mt::fail(P2MT_EINVAL, "coset_lde: log_n > 12 inside a batched pass");
+    const u64 w_big = h_root_of_unity(log_n + rate_bits);
+    const size_t rows = n_polys << rate_bits;
+    if (rows >= ((size_t)1 << 31)) return p2mt::fail(P2MT_EINVAL, "coset_lde: too many rows");
+    const int slot = p2mt::prof_begin();
+    hipLaunchKernelGGL(k_coset_scale_rows, dim3(grid_for((size_t)1 << log_n), (unsigned)rows), dim3(kBlock), 0, rt().stream, d_coeffs, log_n,
+                       rate_bits, shift % gl::P, w_big, d_out);
+    p2mt::prof_end(slot);
+    P2MT_LAUNCH_CHECK();
+    return ntt_dif_dev(d_out, log_n, rows, 0);
+  }
   const u64 *tw, *cp;
   P2MT_TRY(get_twiddles(log_n, 0, &tw));
   P2MT_TRY(get_coset_pows(log_n, rate_bits, shift, &cp));

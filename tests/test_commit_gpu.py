@@ -55,6 +55,19 @@ def test_coset_lde_vs_oracle(pkg, oracle, log_n, rate_bits):
         assert np.array_equal(out[j], oracle.coset_lde(c[j], rate_bits))
 
 
+@pytest.mark.parametrize("log_n,rate_bits", [(13, 3), (14, 1), (15, 2)])
+def test_coset_lde_above_one_workgroup(pkg, oracle, log_n, rate_bits):
+    """transforms that do not fit a workgroup's LDS (the general path: per-coset scaling into leaf-order rows + one in-place DIF)"""
+    c = rand((3, 1 << log_n), 500 + log_n)
+    c[0, :] = np.arange(1, (1 << log_n) + 1, dtype=np.uint64)
+    out = pkg.coset_lde(c, rate_bits)
+    for j in range(3):
+        assert np.array_equal(out[j], oracle.coset_lde(c[j], rate_bits))
+    pb = pkg.PolynomialBatch.from_coeffs(c[:2, :1 << 13] if log_n > 13 else c[:2], rate_bits, 4, want_leaves=False)
+    _, _, cap = oracle.polynomial_batch_commit(c[:2, :1 << 13] if log_n > 13 else c[:2], False, rate_bits, 4)
+    assert np.array_equal(pb.merkle_tree.cap, cap)
+
+
 def test_coset_lde_2pow12_fast_path_and_forced_redo(pkg, oracle):
     """k_coset_lde12_v2 (shift-only radix-16 passes, flag-form arithmetic): 19 polynomials (two full groups of 8 in the XCD-aware
     block order + a partial group in plain order), non-canonical and extreme coefficients among them, against the oracle, every word;
