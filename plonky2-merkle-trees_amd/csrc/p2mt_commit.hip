@@ -453,8 +453,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restr
   }
 }
 
-// ---------------------------------------------------------------- 2^20-point transforms: two passes over HBM (four-step)
-// n = 2^20 = 1024 x 1024, i = i1 1024 + i2, k = k1 + 1024 k2:
+// ---------------------------------------------------------------- 2^13 .. 2^20-point transforms: two passes over HBM (four-step)
+// (described for n = 2^20 = 1024 x 1024; smaller n = 1024 x 2^m keep the column pass -- with rows of 2^m points -- and take the
+//  general row pass k_ntt_rows_small)   i = i1 1024 + i2, k = k1 + 1024 k2:
 //   pass 1  for every column i2:  A[k1][i2] = w_n^(i2 k1) sum_i1 x[i1][i2] w_1024^(i1 k1)      (1024-point transforms down the columns)
 //   pass 2  for every row k1:     X[k1 + 1024 k2] = sum_i2 A[k1][i2] w_1024^(i2 k2)            (1024-point transforms along the rows)
 // LDS holds 2^14 points at most, so two passes is the minimum for this size: 32 B of HBM traffic per point against the 16 B of a
@@ -509,21 +510,23 @@ GL_DEV u64 mul_pow2_mod192(u64 x, u64& sticky) {
 
 }  // namespace ntt20
 
-// ta1[(a - 1) * 64 + p_lo] = w_1024^(p_lo brev4(a)) (a = 1..15), then ta1[960 + d * 16 + b] = w_64^(d brev4(b));
-// t4[k * 1024 + i2] = scale * w_n^(i2 k), n = 2^20
-__global__ __launch_bounds__(kBlock) void k_ntt20_tables(u64 w1024, u64 wn, u64 scale, u64* __restrict__ ta1, u64* __restrict__ t4) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+// ta1[(a - 1) * 64 + p_lo] = w_1024^(p_lo brev4(a)) (a = 1..15), then ta1[960 + d * 16 + b] = w_64^(d brev4(b))
+__global__ __launch_bounds__(kBlock) void k_ntt1024_tables(u64 w1024, u64* __restrict__ ta1) {
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
   if (i < 15 * 64) {
-    const unsigned a = (unsigned)(i >> 6) + 1, p_lo = (unsigned)i & 63;
+    const unsigned a = (i >> 6) + 1, p_lo = i & 63;
     ta1[i] = gl::canon(gl::pow(w1024, (u64)p_lo * ntt20::brev4(a)));
   } else if (i < 16 * 64) {
-    const unsigned d = ((unsigned)i >> 4) & 3, b = (unsigned)i & 15;
+    const unsigned d = (i >> 4) & 3, b = i & 15;
     ta1[i] = gl::canon(gl::pow(w1024, (u64)16 * d * ntt20::brev4(b)));
   }
-  if (i < ((size_t)1 << 20)) {
-    const u64 k = i >> 10, i2 = i & 1023;
-    t4[i] = gl::canon(gl::mul(scale, gl::pow(wn, i2 * k)));
-  }
+}
+// the four-step twiddles of a 2^(10 + log_c)-point transform: t4[k1 * 2^log_c + i2] = scale * w_n^(i2 k1)
+__global__ __launch_bounds__(kBlock) void k_fourstep_twiddles(u64 wn, u64 scale, unsigned log_c, u64* __restrict__ t4) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ((size_t)1 << (10 + log_c))) return;
+  const u64 k = i >> log_c, i2 = i & (((size_t)1 << log_c) - 1);
+  t4[i] = gl::canon(gl::mul(scale, gl::pow(wn, i2 * k)));
 }
 
 // DIR 0 forward (w), 1 inverse (w^-1; the 1/n rides in t4).  ROW_IN: the 16 transforms are 16 contiguous rows of `in` (pass 2);
@@ -531,16 +534,18 @@ __global__ __launch_bounds__(kBlock) void k_ntt20_tables(u64 w1024, u64 wn, u64 
 // grid: x = polynomial, y = tile (q0 = 16 y).  in / out: [n_polys][1024][1024].
 template <int DIR, bool ROW_IN, bool TW, unsigned Q>
 __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ in_, u64* __restrict__ out_, const u64* __restrict__ ta1_,
-                                                     const u64* __restrict__ t4_, const u64* __restrict__ tw_half, unsigned force) {
+                                                     const u64* __restrict__ t4_, const u64* __restrict__ tw_half, unsigned log_c, unsigned force) {
   using namespace ntt20;
-  using T = Tile<Q>;
+  using T = Tile<Q>;  // (ROW_IN: rows of 1024 points, i.e. log_c == 10)
   constexpr unsigned kRowA = T::kRowA, kStride = T::kStride, kTile = Q, kLogQ = Q == 16 ? 4 : 3;
   constexpr int Z16 = DIR ? 36 : 156, Z4 = DIR ? 144 : 48;
   __shared__ __attribute__((aligned(16))) u64 buf[T::kLdsWords];
   const unsigned t = threadIdx.x;
   const unsigned q0 = blockIdx.y * kTile;
-  const gcptr in = as_global(in_) + ((size_t)blockIdx.x << 20);
-  const gptr out = as_global(out_) + ((size_t)blockIdx.x << 20);
+  // log_c: log2 of the row pitch of in / out (the number of columns): 10 for a 2^20-point transform; the column pass of a
+  // 2^(10 + log_c)-point transform runs with 3 <= log_c <= 10 (its rows are 2^log_c long, its columns 1024)
+  const gcptr in = as_global(in_) + ((size_t)blockIdx.x << (10 + log_c));
+  const gptr out = as_global(out_) + ((size_t)blockIdx.x << (10 + log_c));
   const gcptr ta1 = as_global(ta1_), t4 = as_global(t4_);
   u64 sticky = 0;
   u64 x[16];
@@ -548,9 +553,9 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
   const unsigned qa = ROW_IN ? (t >> 6) : (t & (Q - 1)), p_lo = ROW_IN ? (t & 63) : (t >> kLogQ);
   {
     u64 tw[16];
-    const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << 10) + q0 + qa;
+    const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << log_c) + q0 + qa;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << 10];
+    for (int k = 0; k < 16; ++k) x[k] = ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << log_c];
 #pragma unroll
     for (int a = 1; a < 16; ++a) tw[a] = ta1[(a - 1) * 64 + p_lo];
     __builtin_amdgcn_sched_barrier(0);
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
 #pragma unroll
       for (int dd = 0; dd < 4; ++dd) {
         const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
-        tw[4 * bb + dd] = t4[((size_t)k << 10) + q0 + q];
+        tw[4 * bb + dd] = t4[((size_t)k << log_c) + q0 + q];
       }
   }
 #pragma unroll
@@ -615,9 +620,9 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
     u64* const flat = buf;
     __syncthreads();
     {
-      const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << 10) + q0 + qa;
+      const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << log_c) + q0 + qa;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) flat[qa * 1024 + 64 * k + p_lo] = gl::canon(ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << 10]);
+      for (int k = 0; k < 16; ++k) flat[qa * 1024 + 64 * k + p_lo] = gl::canon(ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << log_c]);
     }
     __syncthreads();
     for (unsigned s = 0; s < 10; ++s) {
@@ -637,8 +642,8 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
       for (int dd = 0; dd < 4; ++dd) {
         const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
         u64 v = flat[q * 1024 + brev32(k, 10)];
-        if constexpr (TW) v = cmul(v, t4[((size_t)k << 10) + q0 + q]);
-        out[((size_t)k << 10) + q0 + q] = v;
+        if constexpr (TW) v = cmul(v, t4[((size_t)k << log_c) + q0 + q]);
+        out[((size_t)k << log_c) + q0 + q] = v;
       }
     return;
   }
@@ -647,8 +652,38 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd) {
       const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
-      out[((size_t)k << 10) + q0 + q] = gl::canon(x[4 * bb + dd]);
+      out[((size_t)k << log_c) + q0 + q] = gl::canon(x[4 * bb + dd]);
     }
+}
+
+// The row pass for rows shorter than 1024 points (transforms of 2^13 .. 2^19 points): a workgroup takes 16 whole rows of 2^m points
+// (m = log_c, 3..9), transforms them in LDS with the exact radix-2 butterflies and writes out[k2 * 1024 + r0 + r] -- the same
+// 128-byte granules as the 1024-point row pass, natural order.  General rather than fast: the column pass above carries ten of the
+// transform's stages, this one the remaining m.
+template <int DIR>
+__global__ __launch_bounds__(kBlock) void k_ntt_rows_small(const u64* __restrict__ in_, u64* __restrict__ out_, const u64* __restrict__ tw_half,
+                                                           unsigned m) {
+  extern __shared__ __attribute__((aligned(16))) u64 rows[];  // [16][2^m]
+  const unsigned t = threadIdx.x, r0 = blockIdx.y * 16, len = 1u << m;
+  const gcptr in = as_global(in_) + ((size_t)blockIdx.x << (10 + m)) + ((size_t)r0 << m);
+  const gptr out = as_global(out_) + ((size_t)blockIdx.x << (10 + m));
+  for (unsigned i = t; i < 16 * len; i += kBlock) rows[i] = gl::canon(in[i]);
+  __syncthreads();
+  for (unsigned s = 0; s < m; ++s) {
+    const unsigned half = (len >> 1) >> s;
+    for (unsigned i = t; i < 8 * len; i += kBlock) {
+      const unsigned row = i >> (m - 1), bf = i & ((len >> 1) - 1), blk = bf / half, j = bf & (half - 1);
+      const unsigned i0 = row * len + blk * 2 * half + j, i1 = i0 + half;
+      const u64 u = rows[i0], v = rows[i1];
+      rows[i0] = cadd(u, v);
+      rows[i1] = cmul(csub(u, v), tw_half[(size_t)j << s]);
+    }
+    __syncthreads();
+  }
+  for (unsigned i = t; i < 16 * len; i += kBlock) {
+    const unsigned r = i & 15, k2 = i >> 4;
+    out[((size_t)k2 << 10) + r0 + r] = rows[r * len + brev32(k2, m)];  // the in-place DIF leaves frequency k2 at position brev(k2)
+  }
 }
 
 // ---------------------------------------------------------------- leaves
@@ -912,63 +947,84 @@ int get_coset_pows(unsigned log_n, unsigned rate_bits, u64 shift, const u64** ou
   return P2MT_OK;
 }
 
-// tables of the 2^20-point four-step transform, per direction (built once)
-int get_ntt20_tables(int inverse, const u64** ta1, const u64** t4) {
+// tables of the four-step transforms (built once per direction / size)
+int get_fourstep_tables(unsigned log_n, int inverse, const u64** ta1, const u64** t4) {
   std::lock_guard<std::mutex> lock(tables_mutex());
-  static u64* d[2] = {nullptr, nullptr};
-  if (!d[inverse]) {
+  static u64* d_ta1[2] = {nullptr, nullptr};
+  static std::map<std::pair<unsigned, int>, u64*> d_t4;
+  hipStream_t st = p2mt::rt().stream;
+  if (!d_ta1[inverse]) {
     u64* p = nullptr;
-    const size_t words = 16 * 64 + ((size_t)1 << 20);
-    if (hipMalloc((void**)&p, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
-    u64 w1024 = h_root_of_unity(10), wn = h_root_of_unity(20), scale = 1;
-    if (inverse) {
-      w1024 = h_pow(w1024, gl::P - 2);
-      wn = h_pow(wn, gl::P - 2);
-      scale = h_pow(((u64)1 << 20) % gl::P, gl::P - 2);
-    }
-    hipLaunchKernelGGL(k_ntt20_tables, dim3(grid_for((size_t)1 << 20)), dim3(kBlock), 0, p2mt::rt().stream, w1024, wn, scale, p,
-                       p + 16 * 64);
+    if (hipMalloc((void**)&p, 16 * 64 * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
+    u64 w1024 = h_root_of_unity(10);
+    if (inverse) w1024 = h_pow(w1024, gl::P - 2);
+    hipLaunchKernelGGL(k_ntt1024_tables, dim3(4), dim3(kBlock), 0, st, w1024, p);
     P2MT_LAUNCH_CHECK();
-    P2MT_HIP(hipStreamSynchronize(p2mt::rt().stream));
-    d[inverse] = p;
+    P2MT_HIP(hipStreamSynchronize(st));
+    d_ta1[inverse] = p;
   }
-  *ta1 = d[inverse];
-  *t4 = d[inverse] + 16 * 64;
+  auto key = std::make_pair(log_n, inverse);
+  auto it = d_t4.find(key);
+  if (it == d_t4.end()) {
+    u64* p = nullptr;
+    if (hipMalloc((void**)&p, ((size_t)8) << log_n) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(twiddles) failed");
+    u64 wn = h_root_of_unity(log_n), scale = 1;
+    if (inverse) {
+      wn = h_pow(wn, gl::P - 2);
+      scale = h_pow(((u64)1 << log_n) % gl::P, gl::P - 2);
+    }
+    hipLaunchKernelGGL(k_fourstep_twiddles, dim3(grid_for((size_t)1 << log_n)), dim3(kBlock), 0, st, wn, scale, log_n - 10, p);
+    P2MT_LAUNCH_CHECK();
+    P2MT_HIP(hipStreamSynchronize(st));
+    it = d_t4.emplace(key, p).first;
+  }
+  *ta1 = d_ta1[inverse];
+  *t4 = it->second;
   return P2MT_OK;
 }
 
-// fft_with_options / ifft_with_options for 2^20 points, natural order in and out: d_data -> d_tmp (pass 1, columns) -> d_data
-// (pass 2, rows; the result lands transposed, i.e. in natural order).  Two launches, 16 B of HBM traffic per point each.
-int ntt20_natural_dev(u64* d_data, u64* d_tmp, size_t n_polys, int inverse) {
-  const u64 *ta1, *t4, *twh;
-  P2MT_TRY(get_ntt20_tables(inverse, &ta1, &t4));
+// fft_with_options / ifft_with_options for 2^13 .. 2^20 points, natural order in and out: n = 1024 x 2^m (four-step).
+// d_data -> d_tmp (pass 1: 1024-point transforms down the columns, times w_n^(i2 k1)) -> d_data (pass 2: 2^m-point transforms along the
+// rows, the result written transposed = natural order).  Two launches, 16 B of HBM traffic per point each.
+int ntt_fourstep_natural_dev(u64* d_data, u64* d_tmp, unsigned log_n, size_t n_polys, int inverse) {
+  const unsigned m = log_n - 10;
+  const u64 *ta1, *t4, *twh, *twm;
+  P2MT_TRY(get_fourstep_tables(log_n, inverse, &ta1, &t4));
   P2MT_TRY(get_twiddles(10, inverse, &twh));
+  P2MT_TRY(get_twiddles(m, inverse, &twm));
   hipStream_t st = p2mt::rt().stream;
   const unsigned force = p2mt::rt().force_fallback ? 1u : 0u;
-  // (both passes are profiled launches: bench.py's roofline for this transform is per pass, 16 B per point each)
-  // Tile width per pass, measured (profiles/r04_commit_phase.txt): the column pass is faster with 16 transforms per workgroup
+  // Tile width per pass, measured at 2^20 (profiles/r04_commit_phase.txt): the column pass is faster with 16 transforms per workgroup
   // (0.87 ms against 1.16 ms: its loads, twiddle loads and stores are all granules, and 64-byte ones double the cache lines a
   // wave-load touches), the row pass with 8 (0.58 ms against 0.74 ms: two workgroups per CU cover each other's memory phases).
-  // P2MT_LDE12=3 / 4 force 16 / 8 for both (A/B).
+  // P2MT_LDE12=3 / 4 force 16 / 8 for both (A/B).  Rows of 8 points leave room for 8 columns only.
   const int mode = p2mt::rt().use_lde12;
-  for (int pass = 0; pass < 2; ++pass) {
-    const u64* src = pass == 0 ? d_data : d_tmp;
-    u64* dst = pass == 0 ? d_tmp : d_data;
-    const bool wide = mode == 3 || (mode != 4 && pass == 0);
+  {
+    const bool wide = m >= 4 && mode != 4;
+    const dim3 grid((unsigned)n_polys, (1u << m) / (wide ? 16 : 8)), block(wide ? 1024 : 512);
+    const int slot = p2mt::prof_begin();
+    if (wide && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 16>), grid, block, 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, m, force);
+    if (wide && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true, 16>), grid, block, 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, m, force);
+    if (!wide && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 8>), grid, block, 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, m, force);
+    if (!wide && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true, 8>), grid, block, 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, m, force);
+    p2mt::prof_end(slot);
+    P2MT_LAUNCH_CHECK();
+  }
+  if (m == 10) {
+    const bool wide = mode == 3;
     const dim3 grid((unsigned)n_polys, wide ? 64 : 128), block(wide ? 1024 : 512);
     const int slot = p2mt::prof_begin();
-    if (wide) {
-      if (pass == 0 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-      if (pass == 0 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-      if (pass == 1 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, true, false, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-      if (pass == 1 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false, 16>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-    } else {
-      if (pass == 0 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-      if (pass == 0 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, false, true, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-      if (pass == 1 && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, true, false, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-      if (pass == 1 && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false, 8>), grid, block, 0, st, src, dst, ta1, t4, twh, force);
-    }
+    if (wide && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, true, false, 16>), grid, block, 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, 10u, force);
+    if (wide && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false, 16>), grid, block, 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, 10u, force);
+    if (!wide && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, true, false, 8>), grid, block, 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, 10u, force);
+    if (!wide && inverse) hipLaunchKernelGGL((k_ntt20_pass<1, true, false, 8>), grid, block, 0, st, (const u64*)d_tmp, d_data, ta1, t4, twh, 10u, force);
     p2mt::prof_end(slot);
+    P2MT_LAUNCH_CHECK();
+  } else {
+    const dim3 grid((unsigned)n_polys, 64);
+    const size_t lds = (size_t)16 * 8 << m;
+    if (inverse) hipLaunchKernelGGL((k_ntt_rows_small<1>), grid, dim3(kBlock), lds, st, (const u64*)d_tmp, d_data, twm, m);
+    else hipLaunchKernelGGL((k_ntt_rows_small<0>), grid, dim3(kBlock), lds, st, (const u64*)d_tmp, d_data, twm, m);
     P2MT_LAUNCH_CHECK();
   }
   return P2MT_OK;
@@ -1089,10 +1145,10 @@ extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_pol
   if (n_polys == 0) return P2MT_OK;
   if (!d_data || log_n > 32) return p2mt::fail(P2MT_EINVAL, "ntt: bad argument (2-adicity of the field is 32)");
   const size_t total = n_polys << log_n;
-  if (log_n == 20 && n_polys < ((size_t)1 << 31) && rt().use_lde12) {  // the four-step path (two launches, natural order out)
+  if (log_n >= 13 && log_n <= 20 && n_polys < ((size_t)1 << 31) && rt().use_lde12) {  // the four-step path (two launches, natural order out)
     u64* tmp20;
     P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, total * 8, (void**)&tmp20));
-    return ntt20_natural_dev(d_data, tmp20, n_polys, inverse != 0);
+    return ntt_fourstep_natural_dev(d_data, tmp20, log_n, n_polys, inverse != 0);
   }
   DevBuf tmp;
   P2MT_TRY(tmp.alloc(total * 8));

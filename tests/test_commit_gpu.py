@@ -21,8 +21,9 @@ def rand(shape, seed):
     return np.random.default_rng(seed).integers(0, P, size=shape, dtype=np.uint64)
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 9, 11, 12, 13, 15])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_fft_ifft_vs_oracle(pkg, oracle, log_n):
+    """(2^13 points and up: the two-pass four-step path -- 1024-point column pass + the row pass for 2^(log_n - 10)-point rows)"""
     n_polys = 5 if log_n < 13 else 2
     a = rand((n_polys, 1 << log_n), 100 + log_n)
     a[0, :] = np.arange(1, (1 << log_n) + 1, dtype=np.uint64)
@@ -97,6 +98,19 @@ def test_large_fft_properties(pkg):
     fs = pkg.fft(s)
     assert np.array_equal(fs, ((fa.astype(object) + fb.astype(object)) % P).astype(np.uint64))
     assert int(fa[0, 0]) == int(sum(int(x) for x in a[0]) % P)  # f(1) = sum of coefficients
+
+
+def test_four_step_column_pass_forced_redo_small_rows(pkg, oracle):
+    """the column pass's exact redo with 8- and 16-column tiles (rows of 8 and of 64 points)"""
+    for log_n in (13, 16):
+        a = rand((2, 1 << log_n), 900 + log_n)
+        pkg.lib().p2mt_debug_force_fallback(1)
+        try:
+            f, g = pkg.fft(a), pkg.ifft(a)
+        finally:
+            pkg.lib().p2mt_debug_force_fallback(0)
+        for j in range(2):
+            assert np.array_equal(f[j], oracle.fft(a[j])) and np.array_equal(g[j], oracle.ifft(a[j])), (log_n, j)
 
 
 def test_four_step_fft_2pow20_vs_oracle(pkg, oracle):
