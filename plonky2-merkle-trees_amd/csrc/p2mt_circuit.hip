@@ -94,6 +94,8 @@ struct p2mt_circuit_data {
   // verifier scratch (allocated on the first p2mt_circuit_verify)
   u64* d_verify = nullptr;
   void* vstreams = nullptr;  // side streams + events of the staged verifier (p2mt_verify_dev.hip)
+  const void* vconst_in[2] = {nullptr, nullptr};
+  unsigned vconst_B[2] = {0, 0};  // the block (single / batch) that holds this circuit's digest and constants cap already
   // batched verifier (p2mt_circuit_verify_batch): one block of the same layout per proof, a challenger state behind each
   u64* d_trace = nullptr;  // debug (p2mt_debug_witness_trace): completion tick of every generator of the dataflow interpreter
   char* d_vbatch = nullptr;
@@ -2506,7 +2508,7 @@ namespace {
 // flag | Merkle items
 struct VLayout {
   size_t n_open, off_open, off_fri, off_pi, off_final, final_len, nq, max_items;
-  size_t o_proof, o_cscap, o_fo, o_out, n_out, o_flag, o_res, o_items, o_dig, words;
+  size_t o_proof, o_cscap, o_fo, o_out, n_out, o_flag, o_res, o_pow, o_items, o_dig, words;
   u32 nred;
 };
 VLayout verify_layout(const p2mt_circuit_data* c) {
@@ -2520,7 +2522,7 @@ VLayout verify_layout(const p2mt_circuit_data* c) {
   L.off_final = L.off_fri + c->fri_len - 1 - 2 * L.final_len;
   L.max_items = L.nq * (4 + L.nred);
   L.o_proof = 8, L.o_cscap = L.o_proof + c->proof_len, L.o_fo = L.o_cscap + 64, L.o_out = L.o_fo + 2 * L.n_open;
-  L.n_out = 8 + 2 + 2 * 8 + 1 + L.nq, L.o_flag = L.o_out + L.n_out + 1, L.o_res = L.o_flag + 1, L.o_items = L.o_res + 1;
+  L.n_out = 8 + 2 + 2 * 8 + 1 + L.nq, L.o_flag = L.o_out + L.n_out + 1, L.o_res = L.o_flag + 1, L.o_pow = L.o_res + 1, L.o_items = L.o_pow + 1;
   L.o_dig = L.o_items + (L.max_items * sizeof(VItem) + 7) / 8 + 1;
   L.words = L.o_dig + 4 * L.max_items;
   return L;
@@ -2572,11 +2574,20 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
         break;
       }
   }
-  P2MT_HIP(hipMemcpyAsync(dv, c->digest, 32, hipMemcpyHostToDevice, st));
-  P2MT_HIP(hipMemcpyAsync(dv + L.o_cscap, c->cs_cap, sizeof c->cs_cap, hipMemcpyHostToDevice, st));
+  // the circuit's own words (digest, constants_sigmas cap) go up once per block, not once per verification; nothing overwrites them.
+  // (a batch block is filled for the largest batch it was sized for: B only shrinks within one allocation)
+  const int slot = B > 1 ? 1 : 0;
+  if (c->vconst_in[slot] != dv || B > c->vconst_B[slot]) {
+    P2MT_HIP(hipMemcpyAsync(dv, c->digest, 32, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(dv + L.o_cscap, c->cs_cap, sizeof c->cs_cap, hipMemcpyHostToDevice, st));
+    if (B > 1) {
+      P2MT_TRY(p2mt::batch_broadcast(dv, 32));
+      P2MT_TRY(p2mt::batch_broadcast(dv + L.o_cscap, sizeof c->cs_cap));
+    }
+    c->vconst_in[slot] = dv;
+    c->vconst_B[slot] = B;
+  }
   if (B > 1) {
-    P2MT_TRY(p2mt::batch_broadcast(dv, 32));
-    P2MT_TRY(p2mt::batch_broadcast(dv + L.o_cscap, sizeof c->cs_cap));
     P2MT_HIP(hipMemcpy2DAsync(dv + L.o_proof, stride, proofs, proof_stride * 8, c->proof_len * 8, B, hipMemcpyHostToDevice, st));
   } else {
     P2MT_HIP(hipMemcpyAsync(dv + L.o_proof, proofs, c->proof_len * 8, hipMemcpyHostToDevice, st));
@@ -2600,26 +2611,22 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + L.off_final, 2 * L.final_len + 1, d_out + 26, 1));    // PoW response
   P2MT_TRY(p2mt_challenger_get_challenges_dev(ch, nq, d_out + 27));                                           // query indices
   P2MT_TRY(p2mt::verify_dev_finish(c->vstreams, dv, dv + L.o_items, dv + L.o_dig, d_flag, d_res, va));
-  // results, gathered per proof: the proof-of-work response (d_out[26]) and the two words {Merkle flag, -} {openings ok, FRI}
+  // results, gathered per proof in ONE copy: {Merkle flag, -} {openings ok, FRI} {proof-of-work response} -- three consecutive words
+  // (k_verify_fri leaves a copy of the response next to its own result)
   struct Verdict {
     int flag, pad, ok, fri;
+    u64 pow;
   };
-  std::vector<u64> pow_resp(B);
   std::vector<Verdict> vr(B);
-  static_assert(sizeof(Verdict) == 16, "two consecutive device words");
-  if (B > 1) {
-    P2MT_HIP(hipMemcpy2DAsync(pow_resp.data(), 8, d_out + 26, stride, 8, B, hipMemcpyDeviceToHost, st));
-    P2MT_HIP(hipMemcpy2DAsync(vr.data(), 16, dv + L.o_flag, stride, 16, B, hipMemcpyDeviceToHost, st));
-  } else {
-    P2MT_HIP(hipMemcpyAsync(pow_resp.data(), d_out + 26, 8, hipMemcpyDeviceToHost, st));
-    P2MT_HIP(hipMemcpyAsync(vr.data(), dv + L.o_flag, 16, hipMemcpyDeviceToHost, st));
-  }
+  static_assert(sizeof(Verdict) == 24, "three consecutive device words");
+  if (B > 1) P2MT_HIP(hipMemcpy2DAsync(vr.data(), 24, dv + L.o_flag, stride, 24, B, hipMemcpyDeviceToHost, st));
+  else P2MT_HIP(hipMemcpyAsync(vr.data(), dv + L.o_flag, 24, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
   for (unsigned b = 0; b < B; ++b) {
     if (!live[b]) continue;  // reason 10
     if (vr[b].ok != 1) {
       reason[b] = 11;
-    } else if (c->fri.proof_of_work_bits && (pow_resp[b] >> (64 - c->fri.proof_of_work_bits)) != 0) {
+    } else if (c->fri.proof_of_work_bits && (vr[b].pow >> (64 - c->fri.proof_of_work_bits)) != 0) {
       reason[b] = 1;
     } else if (vr[b].flag != kFlagClear) {
       reason[b] = ((size_t)(vr[b].flag - 1) % (4 + nred)) >= 4 ? 4 : 2;
@@ -2680,6 +2687,7 @@ extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* p
       return p2mt::fail(P2MT_ENOMEM, "hipMalloc(verify batch) failed");
     }
     c->vbatch_cap = want, c->vbatch_stride = stride;
+    c->vconst_in[1] = nullptr;
     if (c->vbch) p2mt::challenger_unwrap(c->vbch);
     c->vbch = nullptr;
     P2MT_TRY(p2mt::challenger_wrap(c->d_vbatch + ((L.words * 8 + 7) & ~(size_t)7), &c->vbch));
