@@ -591,13 +591,17 @@ int p2mt::verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const u
   VerifyStreams* v = static_cast<VerifyStreams*>(vs);
   hipStream_t st = p2mt::rt().stream;
   const unsigned nq = a.fri.num_query_rounds, n_items = nq * (4 + a.fri.num_reductions);
+  // the FRI arithmetic beside the path folds: it goes to the side stream the vanishing-polynomial check used (long done by now)
+  P2MT_HIP(hipEventRecord(v->e_zeta, st));  // (re-used: "the transcript is complete")
+  P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_zeta, 0));
+  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, v->s_open, dv, d_res + 1, a, barg());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipEventRecord(v->e_open, v->s_open));  // behind k_verify_openings AND k_verify_fri on that stream
   hipLaunchKernelGGL(k_verify_items, bgrid((nq + 63) / 64), dim3(64), 0, st, dv, (VItem*)d_items, a, barg());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamWaitEvent(st, v->e_leaf, 0));
   hipLaunchKernelGGL(k_verify_paths, bgrid((n_items + kMerkleBlock / 64 - 1) / (kMerkleBlock / 64)), dim3(kMerkleBlock), 0, st, dv,
                      (const VItem*)d_items, d_digests, n_items, d_flag, barg(), p2mt::perm_ctx());
-  P2MT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, st, dv, d_res + 1, a, barg());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamWaitEvent(st, v->e_open, 0));
   return P2MT_OK;
