@@ -1145,7 +1145,7 @@ extern "C" int p2mt_ntt_batch_dev(uint64_t* d_data, unsigned log_n, size_t n_pol
   if (n_polys == 0) return P2MT_OK;
   if (!d_data || log_n > 32) return p2mt::fail(P2MT_EINVAL, "ntt: bad argument (2-adicity of the field is 32)");
   const size_t total = n_polys << log_n;
-  if (log_n >= 13 && log_n <= 20 && n_polys < ((size_t)1 << 31) && rt().use_lde12) {  // the four-step path (two launches, natural order out)
+  if (log_n >= 13 && log_n <= 20 && n_polys < ((size_t)1 << 31) && rt().use_lde12 && p2mt::batch_B() == 1) {  // the four-step path (two launches, natural order out)
     u64* tmp20;
     P2MT_TRY(p2mt::scratch_get(p2mt::kScratchLde, total * 8, (void**)&tmp20));
     return ntt_fourstep_natural_dev(d_data, tmp20, log_n, n_polys, inverse != 0);
