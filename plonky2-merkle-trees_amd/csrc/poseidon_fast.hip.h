@@ -34,6 +34,11 @@ GL_DEV ctab as_const_table(const u64* global_table) { return (ctab)(unsigned lon
 GL_DEV const u32* as_u32(const u64* p) { return reinterpret_cast<const u32*>(p); }
 GL_DEV ctab32 as_u32(ctab p) { return (ctab32)p; }
 
+// sticky |= mask on the scalar pipe, as an opaque statement: a plain C "|=" lets the optimiser re-associate the ORs of a loop body into
+// a tree at its end, which keeps every lane mask alive until then -- in SGPRs spilled to VGPR lanes (44 v_writelane / v_readlane per group
+// of four partial rounds, measured)
+GL_DEV void raise(u64& sticky, u64 mask) { asm("s_or_b64 %0, %0, %1" : "+s"(sticky) : "s"(mask) : "scc"); }
+
 using gl::add32;
 using gl::eps_if;
 using gl::mad_carry;
@@ -68,7 +73,7 @@ GL_DEV u64 reduce128(u64 lo, u64 hi, u64& sticky) {
   const u64 d1 = mad_eps_carry(hl, lo, c1);     // wrapped by 2^64 in lanes of c1
   const u64 d2 = add32(eps_if(c1), d1);         // + EPS there; cannot wrap again (d1 < 2^64 - 2^33 when wrapped)
   const u64 d3 = sub32_borrow(d2, hh, b);       // borrows only if d2 < hh < 2^32
-  sticky |= b;
+  raise(sticky, b);
   return d3;
 }
 
@@ -90,7 +95,7 @@ GL_DEV u64 reduce128_c(u64 lo, u64 hi, u64 c, u64& sticky) {
   const u64 d1 = mad_eps_carry(hl, lo, c1);
   const u64 d2 = add32(eps_if(c1), d1);
   const u64 d3 = sub32_borrow_in(d2, hh, c, b);    // hh + c < 2^32 (the product is < 2^128): borrows only if d2 < 2^32
-  sticky |= b;
+  raise(sticky, b);
   return d3;
 }
 
@@ -191,7 +196,7 @@ GL_DEV void mds_layer(u64 (&s)[12], P add, u64& sticky) {
     } else {
       u64 cm;
       s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);      // top * EPS + val; wraps with probability ~2^-22
-      sticky |= cm;
+      raise(sticky, cm);
     }
   });
 }
@@ -210,7 +215,7 @@ GL_DEV u64 mds_row(const u64 (&s)[12], u64& sticky) {
   ah = add32((u32)(al >> 32), ah);
   u64 cm;
   const u64 r = mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
-  sticky |= cm;
+  raise(sticky, cm);
   return r;
 }
 
@@ -326,7 +331,7 @@ GL_DEV void mds_layer_mfma(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) 
         const u64 val = ((u64)(u32)ah << 32) | (u32)al;
         u64 cm;
         s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);
-        sticky |= cm;
+        raise(sticky, cm);
       }
     });
   });
@@ -411,7 +416,7 @@ GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc
     const u64 val = ((u64)(u32)ah << 32) | (u32)al;
     u64 cm;
     s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);
-    sticky |= cm;
+    raise(sticky, cm);
   });
 }
 
@@ -438,7 +443,14 @@ constexpr int kP3W = kP3K + 14 * kP3Groups;    // right behind the addends: u32[
                                                // lane 1: row 0 of M^2, lane 2 + r: row r of M^3; then the lane's d1 and d2 coefficients
 constexpr int kP3WaveWords = 14 * kP3Groups + 98;  // what stage_round_constants() copies behind the 360 round constants
 constexpr int kLeafPairK0 = kP3W + 98;         // 12 u64: sum_{k not in {0, 4}} MDS[r][k] (rc[k])^7 + rc[12 + r] (two_to_one of two leaf digests)
-constexpr int kTableWords = kLeafPairK0 + 12;
+// behind those: the tables of partial_rounds_g (round 4): the 22 partial rounds as four groups of FOUR and two groups of three.  Per
+// group of G rounds G + 11 rows of 16 u32 -- rows 0 .. G-2: row 0 of M^(i+1) (the S-box input of the group's round i+1; row 0 of M itself
+// is written as immediates and its slot unused), rows G-1 .. G+10: M^G -- with the coefficients of the earlier rounds' d_k in
+// entries 12 .., then 16 u64 of addends (the round constants pushed through the powers of M).  Rows are 64 bytes: one s_load_dwordx16.
+constexpr int kPGTab = (kLeafPairK0 + 12 + 7) & ~7;
+constexpr int pg_words(int G) { return 8 * (G + 11) + 16; }
+constexpr int kPG4Groups = 4, kPG3Groups = 2;  // rounds 4-7, 8-11, 12-15, 16-19 | 20-22, 23-25
+constexpr int kTableWords = kPGTab + kPG4Groups * pg_words(4) + kPG3Groups * pg_words(3);
 
 struct Dot {
   u64 a0l, a0h, a1l, a1h, a2l, a2h;
@@ -509,7 +521,7 @@ GL_DEV u64 sub_flag(u64 a, u64 b, u64& sticky) {
   u64 m, m2;
   const u64 d = sub64_borrow(a, b, m);
   const u64 d2 = sub32_borrow(d, eps_if(m), m2);
-  sticky |= m2;
+  raise(sticky, m2);
   return d2;
 }
 // acc += a * k, k wave-uniform (SGPR)
@@ -586,6 +598,111 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox, u64& sticky)
   });
 }
 
+// ------------------------------------------------------------------ FOUR partial rounds per MDS application (round 4)
+// The same identity one round further: v4 = M^4 y + d1 (M^2 m0) + d2 (M m0) + d3 m0 + (M^3 c1 + M^2 c2 + M c3 + c4), with the three
+// intermediate S-box inputs from row 0 of M y, M^2 y, M^3 y.  The entries of M^4 are 29-bit numbers, still one v_mad_u64_u32 per term
+// and 32-bit half, but the row sums reach 1.04 x 2^32: a chain of twelve terms can pass 2^64 -- only in its LAST link, because every
+// entry of M^4 is above 0.083 x 2^32 (runtime.hip checks both facts when it builds the table) -- and only for states whose twelve
+// halves are all within 4 % of 2^32.  The last link's carry-out therefore goes to the sticky flag (exact redo), and so does the
+// carry of "hi chain += lo chain >> 32".  Per round 180 instructions against 208 for groups of three: 22 = 4 x 4 + 2 x 3 rounds
+// replaces 7 x 3 + one dense round.
+GL_DEV void mac_s_flag(u64& acc, u32 a, u32 k, u64& sticky) {
+  u64 cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "s"(k));
+  raise(sticky, cy);
+}
+GL_DEV u64 add32_flag(u32 a, u64 c, u64& sticky) {
+  u64 d, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(cy) : "v"(a), "v"(c));
+  raise(sticky, cy);
+  return d;
+}
+// `tab`: the group's table (kPGTab + ...), a loop-variant address for the reason partial_rounds3 gives
+template <int G, typename P, typename Sbox>
+GL_DEV void partial_rounds_g(u64 (&s)[12], P tab, Sbox&& sbox, u64& sticky) {
+  static_assert(G == 3 || G == 4, "groups of three or four");
+  const auto T = as_u32(tab);
+  const P K = tab + 8 * (G + 11);
+  // (al + ah 2^32) mod p, loose, for al, ah < 2^58: ah = ahl + ahh 2^32 and 2^64 == EPS, so al + ahh EPS (< 2^59: no carry) and then
+  // ahl onto the high word, whose carry (one row in ~2^6) is another EPS.  No (word, word) pair has to be put together: no v_mov.
+  auto finish = [](u64 al, u64 ah) -> u64 {
+    u64 unused, k;
+    const u64 r = mad_eps_carry((u32)(ah >> 32), al, unused);
+    u32 rh = (u32)(r >> 32);
+    asm("v_add_co_u32_e64 %0, %1, %0, %2" : "+v"(rh), "=s"(k) : "v"((u32)ah));
+    return add32(eps_if(k), ((u64)rh << 32) | (u32)r);  // wrapped high word < 2^27: + EPS cannot wrap again
+  };
+  s[0] = sbox(s[0]);
+  u32 lo[12], hi[12], dl[G - 1], dh[G - 1];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  constexpr u32 m00 = poseidon::mds_entry(0, 0);
+  poseidon::static_for<1, G>([&](auto ic) {  // x_i = word 0 in front of the S-box of the group's round i; d_i = S(x_i) - x_i
+    constexpr int i = decltype(ic)::value;
+    const u64 c = K[i - 1];
+    u64 al, ah;
+    if constexpr (i == 1) {
+      al = mac_const_first<m00>(lo[0], (u64)(u32)c), ah = mac_const_first<m00>(hi[0], (u64)(u32)(c >> 32));
+      poseidon::static_for<1, 12>([&](auto cc) {
+        constexpr int j = decltype(cc)::value;
+        constexpr u32 k = poseidon::mds_entry(0, j);
+        mac_const<k>(al, lo[j]);
+        mac_const<k>(ah, hi[j]);
+      });
+    } else {
+      const auto R = T + 16 * (i - 1);
+      al = mac_const_first<m00>(dl[i - 2], (u64)(u32)c), ah = mac_const_first<m00>(dh[i - 2], (u64)(u32)(c >> 32));  // d_(i-1) m0[0]
+#pragma unroll
+      for (int k = 0; k < i - 2; ++k) {
+        const u32 w = R[12 + k];
+        mac_s(al, dl[k], w);
+        mac_s(ah, dh[k], w);
+      }
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const u32 w = R[j];
+        mac_s(al, lo[j], w);
+        mac_s(ah, hi[j], w);
+      }
+    }
+    const u64 x = finish(al, ah);  // accumulators < 2^57 (row sums of M^3 < 2^25)
+    const u64 d = sub_flag(sbox(x), x, sticky);
+    dl[i - 1] = (u32)d, dh[i - 1] = (u32)(d >> 32);
+  });
+  poseidon::static_for<0, 12>([&](auto rcst) {
+    constexpr int r = decltype(rcst)::value;
+    constexpr u32 m0r = poseidon::mds_entry(r, 0);
+    const auto R = T + 16 * (G - 1 + r);
+    const u64 c = K[G - 1 + r];
+    u64 al = mac_const_first<m0r>(dl[G - 2], (u64)(u32)c), ah = mac_const_first<m0r>(dh[G - 2], (u64)(u32)(c >> 32));
+#pragma unroll
+    for (int k = 0; k < G - 2; ++k) {
+      const u32 w = R[12 + k];
+      mac_s(al, dl[k], w);
+      mac_s(ah, dh[k], w);
+    }
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const u32 w = R[j];
+      mac_s(al, lo[j], w);
+      mac_s(ah, hi[j], w);
+    }
+    if constexpr (G == 4) {  // the one link that can pass 2^64, then a full 32-bit top word
+      mac_s_flag(al, lo[11], R[11], sticky);
+      mac_s_flag(ah, hi[11], R[11], sticky);
+      ah = add32_flag((u32)(al >> 32), ah, sticky);
+      s[r] = exact::fold96((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al);
+    } else {
+      mac_s(al, lo[11], R[11]);
+      mac_s(ah, hi[11], R[11]);
+      s[r] = finish(al, ah);
+    }
+  });
+}
+
 // Input: any u64 words.  Output: loose u64 words, valid iff the returned sticky mask is 0 for the whole wave.
 // `rc`: the 360 round constants in GLOBAL memory (kernel argument: base + immediate offsets let the compiler
 // fetch a whole round with wide s_load_dwordx8/x16; the __constant__ symbol would cost a PC-relative address
@@ -603,11 +720,12 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox, u64& sticky)
 //   mfma_ctx_init(), made while every lane of the wave was still active).  Same function, same flag semantics.
 //   3 = every 12-row dense MDS layer (seven of the 8 full rounds + the last partial round) as one v_mfma_i32_32x32x32_i8 per limb
 //   (mds_layer_mfma32; `mc` from mfma32_ctx_init()), the other partial rounds batched as in P3.
-// P3: the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round.
+// P3: 1 = the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round;
+//   2 = four groups of four and two groups of three (partial_rounds_g).
 // FIRST_DONE: the caller passes the state in front of round 1's S-boxes (it did round 0 itself: the proof-of-work grind shares eleven of
 //   the twelve first-round S-boxes between all candidates of a proof).  LAST_ROW >= 0: only that word of the result is computed.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
+          int P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
 GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   static_assert(!P3 || (!EXACT && !SPARSE && (MFMA == 0 || MFMA == 3)), "partial_rounds3 belongs to the dense flag form");
   u64 sticky = 0;
@@ -643,7 +761,7 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
       ah = add32((u32)(al >> 32), ah);
       u64 cm;
       s[r] = mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
-      sticky |= cm;
+      raise(sticky, cm);
     });
   } else if constexpr (LEAF_PAIR) {  // round 0: words 0 and 4 only
     s[0] = sbox(gl::add_c(s[0], rc[0]));
@@ -719,6 +837,12 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
     // the constants of the first full round of the second half (the dense form folds them into the previous MDS layer)
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[12 * (POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS) + i]);
+  } else if constexpr (P3 == 2) {
+    static_assert(POSEIDON_PARTIAL_ROUNDS == 4 * kPG4Groups + 3 * kPG3Groups, "four groups of four + two of three");
+#pragma unroll 1
+    for (int g = 0; g < kPG4Groups; ++g) partial_rounds_g<4>(s, rc + kPGTab + pg_words(4) * g, sbox, sticky);
+#pragma unroll 1
+    for (int g = 0; g < kPG3Groups; ++g) partial_rounds_g<3>(s, rc + kPGTab + pg_words(4) * kPG4Groups + pg_words(3) * g, sbox, sticky);
   } else if constexpr (P3) {
     static_assert(POSEIDON_PARTIAL_ROUNDS == 3 * kP3Groups + 1, "7 groups of three + one round");
 #pragma unroll 1
@@ -749,7 +873,7 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
 }
 // `rc` = the GLOBAL constant table (p2mt::perm_ctx().rc), never the LDS copy of the 12-lane layout
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          bool P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
+          int P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
   if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*, MULV, FIRST_DONE, LAST_ROW>(s, rc, mc);
   else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab, MULV, FIRST_DONE, LAST_ROW>(s, as_const_table(rc), mc);

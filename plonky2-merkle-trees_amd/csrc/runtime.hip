@@ -251,8 +251,11 @@ extern "C" int p2mt_init(int device) {
     // group of three rounds the constants c1[0], (M c1 + c2)[0] and M^2 c1 + M c2 + c3 (mod p)
     // and, last, for two_to_one of two leaf digests the share of the ten constant first-round S-box outputs in round 0's MDS layer,
     // with round 1's constants in (poseidon_fast.hip.h kLeafPairK0): 12 words
-    static uint64_t table[1372 + 84 * 7 + 14 * 7 + 98 + 12];
-    static_assert(sizeof(table) / 8 == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98 + 98 + 12, "layout of poseidon_fast.hip.h");
+    // and the tables of the four-round groups (poseidon_fast.hip.h kPGTab): per group of G rounds G + 11 rows of 16 u32 and 16 u64 addends
+    constexpr int kPGTab = 1372 + 84 * 7 + 14 * 7 + 98 + 12, kPG4 = 8 * (4 + 11) + 16, kPG3 = 8 * (3 + 11) + 16;
+    static_assert(kPGTab % 8 == 0, "64-byte rows");
+    static uint64_t table[kPGTab + 4 * kPG4 + 2 * kPG3];
+    static_assert(kPGTab == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98 + 98 + 12, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
     memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
     memcpy(table + 382, POSEIDON_FAST_K, sizeof(POSEIDON_FAST_K));
@@ -321,6 +324,62 @@ extern "C" int p2mt_init(int device) {
         k[1] = (uint64_t)(((u128)mc1[0] + c2[0]) % p);
         for (int r = 0; r < 12; ++r) k[2 + r] = (uint64_t)(((u128)m2c1[r] + mc2[r] + c3[r]) % p);
       }
+    }
+    {  // partial_rounds_g: groups of G rounds starting at round r0 (the rounds are numbered 0..29; 4..25 are the partial ones)
+      typedef unsigned __int128 u128;
+      const u128 p = 0xFFFFFFFF00000001ULL;
+      const uint64_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+      uint64_t Mp[5][12][12];  // Mp[k] = M^k (integers: M^4 has 29-bit entries)
+      for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) {
+          Mp[0][r][c] = r == c;
+          Mp[1][r][c] = circ[((c - r) % 12 + 12) % 12] + ((r == 0 && c == 0) ? 8 : 0);
+        }
+      for (int k = 2; k <= 4; ++k)
+        for (int r = 0; r < 12; ++r)
+          for (int c = 0; c < 12; ++c) {
+            uint64_t a = 0;
+            for (int j = 0; j < 12; ++j) a += Mp[k - 1][r][j] * Mp[1][j][c];
+            Mp[k][r][c] = a;
+          }
+      {  // what the overflow handling of the groups of four rests on: entries below 2^32, and any eleven of a row's twelve terms plus
+         // the d terms and the addend stay below 2^64 -- only the last link of a chain can carry out
+        const u128 X = 0xFFFFFFFFu;
+        for (int r = 0; r < 12; ++r) {
+          u128 tot = X;  // the addend's half
+          uint64_t mn = ~0ull;
+          for (int c = 0; c < 12; ++c) {
+            if (Mp[4][r][c] >> 32) return p2mt::fail(P2MT_EINVAL, "p2mt_init: M^4 entry does not fit 32 bits");
+            tot += (u128)Mp[4][r][c] * X;
+            mn = Mp[4][r][c] < mn ? Mp[4][r][c] : mn;
+          }
+          tot += (u128)(Mp[3][r][0] + Mp[2][r][0] + Mp[1][r][0]) * X;
+          if ((tot - (u128)mn * X) >> 64) return p2mt::fail(P2MT_EINVAL, "p2mt_init: a chain of the four-round groups can overflow early");
+        }
+      }
+      auto build_group = [&](uint64_t* g, int G, int r0) {
+        uint32_t* T = reinterpret_cast<uint32_t*>(g);
+        memset(g, 0, 8 * (size_t)(8 * (G + 11) + 16));
+        for (int i = 1; i < G; ++i) {  // row i - 1: S-box input of the group's round i = row 0 of M^i y + sum_k d_k M^(i-k)[0][0] + ...
+          for (int c = 0; c < 12; ++c) T[16 * (i - 1) + c] = (uint32_t)Mp[i][0][c];
+          for (int k = 1; k <= i - 2; ++k) T[16 * (i - 1) + 12 + (k - 1)] = (uint32_t)Mp[i - k][0][0];  // (d_(i-1) m0[0] is an immediate)
+        }
+        for (int r = 0; r < 12; ++r) {
+          for (int c = 0; c < 12; ++c) T[16 * (G - 1 + r) + c] = (uint32_t)Mp[G][r][c];
+          for (int k = 1; k <= G - 2; ++k) T[16 * (G - 1 + r) + 12 + (k - 1)] = (uint32_t)Mp[G - k][r][0];
+        }
+        uint64_t* K = g + 8 * (G + 11);
+        auto addend = [&](int i, int r) -> uint64_t {  // (sum_{t=1..i} M^(i-t) c_t)[r] mod p, c_t = the constants of round r0 + t
+          u128 a = 0;
+          for (int t = 1; t <= i; ++t)
+            for (int c = 0; c < 12; ++c) a = (a + (u128)Mp[i - t][r][c] * POSEIDON_RC[12 * (r0 + t) + c]) % p;
+          return (uint64_t)a;
+        };
+        for (int i = 1; i < G; ++i) K[i - 1] = addend(i, 0);
+        for (int r = 0; r < 12; ++r) K[G - 1 + r] = addend(G, r);
+      };
+      for (int g = 0; g < 4; ++g) build_group(table + kPGTab + kPG4 * g, 4, 4 + 4 * g);
+      for (int g = 0; g < 2; ++g) build_group(table + kPGTab + 4 * kPG4 + kPG3 * g, 3, 20 + 3 * g);
     }
     const int word_of[10] = {8, 9, 10, 11, 1, 2, 3, 5, 6, 7};
     for (int i = 0; i < 10; ++i) {
@@ -431,7 +490,7 @@ extern "C" int p2mt_set_variant(int mds, int partial) {
   return p2mt::abi_guard([&]() -> int {
   // partial: 0 dense, 1 sparse partial rounds; 2 / 3 (with mds == 2 only) = dense with all / only the partial rounds' MDS layers on the matrix pipe, 4 = one MDS
   // layer per partial round (round 2's form; the default batches three partial rounds per MDS application) -- stage-1 A/B
-  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 6 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 7 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
   return P2MT_OK;

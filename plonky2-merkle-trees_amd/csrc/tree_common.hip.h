@@ -74,7 +74,7 @@ GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr, cons
   };
   if constexpr (M == IMPL_FAST) {  // capacity words are zero and only 4 output words are needed
     load(s);
-    const u64 sticky = poseidon_fast::permute<true, 4, false, LEAF_PAIR, PR == 1, (PR == 2 || PR == 3 ? PR - 1 : (PR == 5 ? 3 : 0)), PR == 0 || PR == 5 || PR == 6, (PR == 6 ? 1 : 0)>(s, ctx.rc, mc) | ctx.force_fallback;
+    const u64 sticky = poseidon_fast::permute<true, 4, false, LEAF_PAIR, PR == 1, (PR == 2 || PR == 3 ? PR - 1 : (PR == 5 || PR == 7 ? 3 : 0)), (PR == 7 ? 2 : PR == 0 || PR == 5 || PR == 6), (PR == 6 ? 1 : 0)>(s, ctx.rc, mc) | ctx.force_fallback;
     if (__builtin_expect(sticky != 0, 0)) {  // ~0.5 % of waves.  (Redoing with the exact fast-form instead was
       load(s);                               //  measured 2 % slower overall: bigger kernel, worse allocation.)
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);

@@ -316,7 +316,7 @@ def test_mfma_mds_variant(pkg, oracle):
         pkg.set_variant(*DEFAULT_VARIANT)
 
 
-@pytest.mark.parametrize("variant", [(2, 0), (2, 5), (2, 6)])
+@pytest.mark.parametrize("variant", [(2, 0), (2, 5), (2, 6), (2, 7)])
 def test_mfma32_default_and_valu_forms(pkg, oracle, variant):
     """The default of the fast path puts every 12-row dense MDS layer on ONE v_mfma_i32_32x32x32_i8 per 8-bit limb (block-structured A
     operand, one hash per lane, no cross-lane movement: poseidon_fast::mds_layer_mfma32) and multiplies in four mads with the
