@@ -729,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (off + k < w) s[k] = in[(off + k) * n_pts + i];
-        if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), true>(s, ctx.rc, &mc);
+        if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : 1)>(s, ctx.rc, &mc);
         else if constexpr (M == 2) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
         else poseidon::permute<M, PR>(s);
       }

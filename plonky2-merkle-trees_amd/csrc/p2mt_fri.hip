@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
           s[r] = poseidon_fast::mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
           sticky |= cm;
         }
-        sticky |= poseidon_fast::permute<false, 12, false, false, false, 3, true, 0, true, 7>(s, ctx.rc, &mc);
+        sticky |= poseidon_fast::permute<false, 12, false, false, false, 3, 2, 0, true, 7>(s, ctx.rc, &mc);
         if (__builtin_expect(sticky != 0, 0)) {  // flagged wave: the exact reference permutation from the full input
           load(s);
           poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);

@@ -666,8 +666,9 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       // variants exist for 2^4-leaf subtrees in 256-lane workgroups only, and subtree_levels_for() never asks for anything else
       // while one of them is selected
       const int variant = (sub_lv == 4 && sb == 256) ? rt().partial : 0;
-      // template PR of the fast path: 5 = the default (dense MDS layers on the matrix pipe), 0 = VALU MDS (variant 5), 6 = VALU MDS
-      // with the previous field multiply (variant 6), 1..4 = the older A/B forms (variants 1..4)
+      // template PR of the fast path: 5 = the default (dense MDS layers on the matrix pipe, partial rounds in groups of four), 0 = VALU
+      // MDS (variant 5), 6 = VALU MDS with the previous field multiply (variant 6), 7 = 5 with the partial rounds in groups of three
+      // (variant 7), 1..4 = the older A/B forms (variants 1..4)
 #define P2MT_SUB4(LVV, PRR)                                                                                                          \
   hipLaunchKernelGGL((k_mmr_subtree<LVV, 256, PRR, 4>), dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_leaves, leaf_base, \
                      m->elements, block0, n_blocks, p2mt::perm_ctx())
@@ -677,7 +678,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       else if (sub_lv != 4) return p2mt::fail(P2MT_EINVAL, "stage 1: no kernel for this subtree size");
       else if (variant == 5) P2MT_SUB4(4, 0);      // VALU MDS in the full rounds too (A/B: p2mt_set_variant(2, 5))
       else if (variant == 6) P2MT_SUB4(4, 6);      // ... and the previous field multiply (A/B: p2mt_set_variant(2, 6))
-      else if (variant == 7) P2MT_SUB4(4, 7);      // the default with the partial rounds in groups of four (A/B: p2mt_set_variant(2, 7))
+      else if (variant == 7) P2MT_SUB4(4, 7);      // partial rounds in groups of three, round 3's default (A/B: p2mt_set_variant(2, 7))
 #ifndef P2MT_DEV_FEWER_VARIANTS
       else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers as 4x4x4 MFMAs (A/B: p2mt_set_variant(2, 2))
       else if (variant == 3) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))

@@ -116,9 +116,23 @@ def check(funcs):
                         dist = need
                         break
                     touched = set().union(*[regs(o) for o in ops2]) if ops2 else set()
-                    chain = (op2.startswith("v_mfma") or op2.startswith("v_smfma")) and len(ops2) >= 4 and regs(ops2[3]) == dst and \
-                        not (regs(ops2[1]) | regs(ops2[2])) & dst
-                    if touched & dst and not chain:
+                    if op2.startswith("v_mfma") or op2.startswith("v_smfma"):
+                        # MFMA after MFMA (both compiler-visible, listed for completeness): the whole result as the accumulator input
+                        # of the next one needs nothing; an overlapping SrcC needs `passes` wait states, SrcA / SrcB passes + 2; a later
+                        # MFMA that only overwrites the registers is ordered by the in-order matrix pipe and ends the window
+                        passes = need - 3
+                        ab = (regs(ops2[1]) | regs(ops2[2])) & dst if len(ops2) >= 3 else set()
+                        cc = regs(ops2[3]) & dst if len(ops2) >= 4 else set()
+                        if ab and dist < passes + 2:
+                            need = passes + 2
+                            break
+                        if cc and regs(ops2[3]) != dst and dist < passes:
+                            need = passes
+                            break
+                        if regs(ops2[0]) & dst and not ab:
+                            dist = need
+                            break
+                    elif touched & dst:
                         break
                     dist += states(op2, ops2)
                     j += 1
