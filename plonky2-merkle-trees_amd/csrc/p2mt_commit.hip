@@ -479,7 +479,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_coset_lde12_v2(const u64* __restr
 namespace ntt20 {
 
 // Q transforms per workgroup (64 Q threads): LDS word(a, p_lo, q) = a * rowA + p_lo * (Q + 1) + q, rowA = 64 (Q + 1) + Q
-//   Q = 16: 128-byte granules, 141 KB of LDS, one workgroup of 1024 threads per CU (its memory phases are covered by nothing);
+//   Q = 16: 128-byte granules, 141 KB of LDS, one workgroup of 1024 threads per CU (its memory phases are covered by nothing; sending
+//           the exchanges through LDS one 32-bit half at a time halves the array, but a second workgroup of 1024 threads also needs
+//           the kernel in 64 VGPRs and it has 128 + 34 spilled: built in round 4, 102 spills and 412 B of scratch, dropped);
 //   Q = 8:   64-byte granules,  75 KB of LDS, two workgroups of 512 threads per CU (one computes while the other loads / stores).
 template <unsigned Q>
 struct Tile {

@@ -443,13 +443,13 @@ constexpr int kP3W = kP3K + 14 * kP3Groups;    // right behind the addends: u32[
                                                // lane 1: row 0 of M^2, lane 2 + r: row r of M^3; then the lane's d1 and d2 coefficients
 constexpr int kP3WaveWords = 14 * kP3Groups + 98;  // what stage_round_constants() copies behind the 360 round constants
 constexpr int kLeafPairK0 = kP3W + 98;         // 12 u64: sum_{k not in {0, 4}} MDS[r][k] (rc[k])^7 + rc[12 + r] (two_to_one of two leaf digests)
-// behind those: the tables of partial_rounds_g (round 4): the 22 partial rounds as four groups of FOUR and two groups of three.  Per
+// behind those: the tables of partial_rounds_g (round 4): round 3's MDS layer and the 22 partial rounds as five groups of FOUR and one of three.  Per
 // group of G rounds G + 11 rows of 16 u32 -- rows 0 .. G-2: row 0 of M^(i+1) (the S-box input of the group's round i+1; row 0 of M itself
 // is written as immediates and its slot unused), rows G-1 .. G+10: M^G -- with the coefficients of the earlier rounds' d_k in
 // entries 12 .., then 16 u64 of addends (the round constants pushed through the powers of M).  Rows are 64 bytes: one s_load_dwordx16.
 constexpr int kPGTab = (kLeafPairK0 + 12 + 7) & ~7;
 constexpr int pg_words(int G) { return 8 * (G + 11) + 16; }
-constexpr int kPG4Groups = 4, kPG3Groups = 2;  // rounds 4-7, 8-11, 12-15, 16-19 | 20-22, 23-25
+constexpr int kPG4Groups = 5, kPG3Groups = 1;  // MDS layers of rounds 3-6 (the first one follows a FULL S-box layer), 7-10, 11-14, 15-18, 19-22 | 23-25
 constexpr int kTableWords = kPGTab + kPG4Groups * pg_words(4) + kPG3Groups * pg_words(3);
 
 struct Dot {
@@ -604,8 +604,9 @@ GL_DEV void partial_rounds3(u64 (&s)[12], P rc, int g, Sbox&& sbox, u64& sticky)
 // and 32-bit half, but the row sums reach 1.04 x 2^32: a chain of twelve terms can pass 2^64 -- only in its LAST link, because every
 // entry of M^4 is above 0.083 x 2^32 (runtime.hip checks both facts when it builds the table) -- and only for states whose twelve
 // halves are all within 4 % of 2^32.  The last link's carry-out therefore goes to the sticky flag (exact redo), and so does the
-// carry of "hi chain += lo chain >> 32".  Per round 180 instructions against 208 for groups of three: 22 = 4 x 4 + 2 x 3 rounds
-// replaces 7 x 3 + one dense round.
+// carry of "hi chain += lo chain >> 32".  Per round 180 instructions against 208 for groups of three.  The first group takes the MDS
+// layer of the last full round of the first half as its first application (LEAD = false): 1 + 22 = 5 x 4 + 3 layers replace that
+// matrix-pipe layer, 7 x 3 and one dense round.
 GL_DEV void mac_s_flag(u64& acc, u32 a, u32 k, u64& sticky) {
   u64 cy;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "s"(k));
@@ -618,7 +619,9 @@ GL_DEV u64 add32_flag(u32 a, u64 c, u64& sticky) {
   return d;
 }
 // `tab`: the group's table (kPGTab + ...), a loop-variant address for the reason partial_rounds3 gives
-template <int G, typename P, typename Sbox>
+// LEAD: the group starts with the S-box of its first round on word 0.  Without it the caller has applied a full S-box layer: the MDS
+// layer of the last full round of the first half then is the group's first MDS application (and one matrix-pipe layer fewer).
+template <int G, bool LEAD = true, typename P, typename Sbox>
 GL_DEV void partial_rounds_g(u64 (&s)[12], P tab, Sbox&& sbox, u64& sticky) {
   static_assert(G == 3 || G == 4, "groups of three or four");
   const auto T = as_u32(tab);
@@ -632,7 +635,7 @@ GL_DEV void partial_rounds_g(u64 (&s)[12], P tab, Sbox&& sbox, u64& sticky) {
     asm("v_add_co_u32_e64 %0, %1, %0, %2" : "+v"(rh), "=s"(k) : "v"((u32)ah));
     return add32(eps_if(k), ((u64)rh << 32) | (u32)r);  // wrapped high word < 2^27: + EPS cannot wrap again
   };
-  s[0] = sbox(s[0]);
+  if constexpr (LEAD) s[0] = sbox(s[0]);
   u32 lo[12], hi[12], dl[G - 1], dh[G - 1];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
@@ -721,7 +724,7 @@ GL_DEV void partial_rounds_g(u64 (&s)[12], P tab, Sbox&& sbox, u64& sticky) {
 //   3 = every 12-row dense MDS layer (seven of the 8 full rounds + the last partial round) as one v_mfma_i32_32x32x32_i8 per limb
 //   (mds_layer_mfma32; `mc` from mfma32_ctx_init()), the other partial rounds batched as in P3.
 // P3: 1 = the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round;
-//   2 = four groups of four and two groups of three (partial_rounds_g).
+//   2 = the MDS layer of round 3 and the 22 partial rounds as five groups of four and one of three (partial_rounds_g).
 // FIRST_DONE: the caller passes the state in front of round 1's S-boxes (it did round 0 itself: the proof-of-work grind shares eleven of
 //   the twelve first-round S-boxes between all candidates of a proof).  LAST_ROW >= 0: only that word of the result is computed.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
@@ -787,7 +790,7 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   }
   static_assert(!(SPARSE && EXACT), "the exact redo path keeps the dense partial rounds");
 #pragma unroll 1
-  for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS - (SPARSE ? 1 : 0); ++r) {
+  for (int r = 1; r < POSEIDON_HALF_FULL_ROUNDS - (SPARSE || P3 == 2 ? 1 : 0); ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
     mds(T{}, R12{}, rc + 12 * (r + 1));
@@ -838,9 +841,14 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::add_c(s[i], rc[12 * (POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS) + i]);
   } else if constexpr (P3 == 2) {
-    static_assert(POSEIDON_PARTIAL_ROUNDS == 4 * kPG4Groups + 3 * kPG3Groups, "four groups of four + two of three");
+    static_assert(POSEIDON_PARTIAL_ROUNDS + 1 == 4 * kPG4Groups + 3 * kPG3Groups, "round 3's layer + 22 partial rounds = five groups of four + one of three");
+    {  // the last full round of the first half: its MDS layer opens the first group
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+      partial_rounds_g<4, false>(s, rc + kPGTab, sbox, sticky);
+    }
 #pragma unroll 1
-    for (int g = 0; g < kPG4Groups; ++g) partial_rounds_g<4>(s, rc + kPGTab + pg_words(4) * g, sbox, sticky);
+    for (int g = 1; g < kPG4Groups; ++g) partial_rounds_g<4>(s, rc + kPGTab + pg_words(4) * g, sbox, sticky);
 #pragma unroll 1
     for (int g = 0; g < kPG3Groups; ++g) partial_rounds_g<3>(s, rc + kPGTab + pg_words(4) * kPG4Groups + pg_words(3) * g, sbox, sticky);
   } else if constexpr (P3) {

@@ -254,7 +254,7 @@ extern "C" int p2mt_init(int device) {
     // and the tables of the four-round groups (poseidon_fast.hip.h kPGTab): per group of G rounds G + 11 rows of 16 u32 and 16 u64 addends
     constexpr int kPGTab = 1372 + 84 * 7 + 14 * 7 + 98 + 12, kPG4 = 8 * (4 + 11) + 16, kPG3 = 8 * (3 + 11) + 16;
     static_assert(kPGTab % 8 == 0, "64-byte rows");
-    static uint64_t table[kPGTab + 4 * kPG4 + 2 * kPG3];
+    static uint64_t table[kPGTab + 5 * kPG4 + 1 * kPG3];
     static_assert(kPGTab == 646 + 22 * 11 * 2 + 121 * 2 + 84 * 7 + 98 + 98 + 12, "layout of poseidon_fast.hip.h");
     memcpy(table, POSEIDON_RC, sizeof(POSEIDON_RC));
     memcpy(table + 370, POSEIDON_FAST_FIRST, sizeof(POSEIDON_FAST_FIRST));
@@ -378,8 +378,8 @@ extern "C" int p2mt_init(int device) {
         for (int i = 1; i < G; ++i) K[i - 1] = addend(i, 0);
         for (int r = 0; r < 12; ++r) K[G - 1 + r] = addend(G, r);
       };
-      for (int g = 0; g < 4; ++g) build_group(table + kPGTab + kPG4 * g, 4, 4 + 4 * g);
-      for (int g = 0; g < 2; ++g) build_group(table + kPGTab + 4 * kPG4 + kPG3 * g, 3, 20 + 3 * g);
+      for (int g = 0; g < 5; ++g) build_group(table + kPGTab + kPG4 * g, 4, 3 + 4 * g);  // MDS layers of rounds 3-6, 7-10, .., 19-22
+      build_group(table + kPGTab + 5 * kPG4, 3, 23);                                      // 23-25
     }
     const int word_of[10] = {8, 9, 10, 11, 1, 2, 3, 5, 6, 7};
     for (int i = 0; i < 10; ++i) {
