@@ -102,6 +102,14 @@ int p2mt_debug_witness_trace(struct p2mt_circuit_data *c, int enable, uint64_t *
  * op 2);  op 14 / 15: the sum / the difference out of their fused butterfly;  op 16 + E, E in [0, 192): a[i] * 2^E by shifts
  * (2^96 = -1; flag_out as in op 2).  Results are canonicalised. */
 int p2mt_debug_field_op(int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out, uint8_t *flag_out);
+/* Test hook for the batched partial rounds of the one-hash-per-lane permutation (poseidon_fast::partial_rounds_g): applies group
+ * `group` of the shipped schedule to n arbitrary 12-word states (n x 12 in, n x 12 canonical out).  group 0: the MDS layers of rounds
+ * 3..6 with the word-0 S-boxes of rounds 4..6 between them (its input is the state BEHIND round 3's full S-box layer); 1..4: four
+ * rounds starting with the word-0 S-box of round 7 / 11 / 15 / 19; 5: the three rounds 23..25.  Every group ends with the constants of
+ * the following round added.  flag_out[i] = 1 if the lane raised the sticky flag (a chain of a four-round group carried out of 64
+ * bits, or one of the rare borrows of the flag-form arithmetic): its value is then unspecified -- the kernels redo such a hash with
+ * the exact permutation. */
+int p2mt_debug_partial_group(int group, const uint64_t *states, size_t n, uint64_t *out, uint8_t *flag_out);
 /* Per-launch HIP-event timing of the dominant kernels (the fused MMR tile stage; the LDE / leaf-sponge kernels of
  * the commit step): enable, run, then read the summed duration and the number of launches recorded. */
 int p2mt_profile_enable(int on);

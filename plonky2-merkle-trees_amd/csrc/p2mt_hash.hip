@@ -334,6 +334,55 @@ using p2mt::DevBuf;
 using p2mt::rt;
 
 // =================================================================== stateless batch entry points
+// =================================================================== test hook: one group of partial rounds on arbitrary states
+// (the carry-out of a four-round group's last link needs all twelve halves of a state within 4 % of 2^32: no hash input gets there,
+// so the tests hand the states in directly)
+namespace {
+template <int G, bool LEAD>
+__global__ __launch_bounds__(kBlock) void k_debug_partial_group(const u64* __restrict__ in, size_t n, unsigned table_off,
+                                                                u64* __restrict__ out, uint8_t* __restrict__ flag, PermCtx ctx) {
+  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t i = i0 < n ? i0 : n - 1;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = in[12 * i + k];
+  u64 sticky = 0;
+  const poseidon_fast::ctab rc = poseidon_fast::as_const_table(ctx.rc);
+  auto sbox = [&](u64 x) -> u64 { return poseidon_fast::pow7<0>(x, sticky); };
+  poseidon_fast::partial_rounds_g<G, LEAD>(s, rc + table_off, sbox, sticky);
+  if (i0 < n) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) out[12 * i + k] = gl::canon(s[k]);
+    flag[i] = (uint8_t)((sticky >> (threadIdx.x & 63)) & 1);
+  }
+}
+}  // namespace
+
+extern "C" int p2mt_debug_partial_group(int group, const uint64_t* states, size_t n, uint64_t* out, uint8_t* flag_out) {
+  return p2mt::abi_guard([&]() -> int {
+  P2MT_TRY(p2mt::ensure_init());
+  if (n == 0) return P2MT_OK;
+  using namespace poseidon_fast;
+  if (!states || !out || !flag_out || group < 0 || group >= kPG4Groups + kPG3Groups) return p2mt::fail(P2MT_EINVAL, "bad argument");
+  p2mt::DevBuf bi, bo, bf;
+  P2MT_TRY(bi.alloc(n * 96));
+  P2MT_TRY(bo.alloc(n * 96));
+  P2MT_TRY(bf.alloc(n));
+  hipStream_t st = p2mt::rt().stream;
+  P2MT_HIP(hipMemcpyAsync(bi.p, states, n * 96, hipMemcpyHostToDevice, st));
+  const unsigned off = group < kPG4Groups ? kPGTab + pg_words(4) * group : kPGTab + pg_words(4) * kPG4Groups + pg_words(3) * (group - kPG4Groups);
+  const dim3 grid(grid_for(n)), block(kBlock);
+  if (group == 0) hipLaunchKernelGGL((k_debug_partial_group<4, false>), grid, block, 0, st, (const u64*)bi.as<u64>(), n, off, bo.as<u64>(), bf.as<uint8_t>(), p2mt::perm_ctx());
+  else if (group < kPG4Groups) hipLaunchKernelGGL((k_debug_partial_group<4, true>), grid, block, 0, st, (const u64*)bi.as<u64>(), n, off, bo.as<u64>(), bf.as<uint8_t>(), p2mt::perm_ctx());
+  else hipLaunchKernelGGL((k_debug_partial_group<3, true>), grid, block, 0, st, (const u64*)bi.as<u64>(), n, off, bo.as<u64>(), bf.as<uint8_t>(), p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipMemcpyAsync(out, bo.p, n * 96, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipMemcpyAsync(flag_out, bf.p, n, hipMemcpyDeviceToHost, st));
+  P2MT_HIP(hipStreamSynchronize(st));
+  return P2MT_OK;
+  });
+}
+
 extern "C" int p2mt_poseidon_permute_batch_dev(const uint64_t* d_in, uint64_t* d_out, size_t n) {
   return p2mt::abi_guard([&]() -> int {
   P2MT_TRY(p2mt::ensure_init());

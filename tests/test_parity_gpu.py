@@ -579,6 +579,56 @@ def test_field_primitives_rare_paths(pkg):
         assert flag.sum() > 0
 
 
+def test_partial_round_groups_and_their_overflow_flag(pkg):
+    """The 22 partial rounds run as groups of four (and one of three) with ONE MDS application each (poseidon_fast::partial_rounds_g):
+    M^4 has 29-bit entries and row sums of 1.01 - 1.04 x 2^32, so the last link of a row's mad chain can carry out of 64 bits when
+    all twelve 32-bit halves of a state are within 4 % of 2^32 -- no hash input reaches that, so the states go in directly
+    (p2mt_debug_partial_group).  Against a plain Python restatement of the same rounds: every lane that does not raise the flag is
+    exact; random states never raise it; states of all-ones words always do (in the four-round groups), and so do some of the
+    near-all-ones ones -- the kernels answer the flag with the exact permutation (test_fast_path_fallback_is_exact)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import poseidon_spec as ps
+    lib, N = pkg.lib(), pkg._native
+    rc, mds = ps.round_constants(), ps.mds_matrix()
+    M64 = (1 << 64) - 1
+    rng = np.random.default_rng(2024)
+    n_rand = 600
+    states = [[int(v) for v in row] for row in rng.integers(0, 1 << 64, (n_rand, 12), dtype=np.uint64)]
+    states += [[M64] * 12, [P - 1] * 12, [0] * 12, [0xFFFFFFFF] * 12, [0xFFFFFFFF00000000] * 12]
+    for _ in range(400):  # eleven words of all ones, word 0 anything; and states a few per cent below all ones in every half
+        states.append([int(rng.integers(0, 1 << 64, dtype=np.uint64))] + [M64] * 11)
+        lo = rng.integers(int(0.9 * 2**32), 1 << 32, 12, dtype=np.uint64)
+        hi = rng.integers(int(0.9 * 2**32), 1 << 32, 12, dtype=np.uint64)
+        states.append([int((h << np.uint64(32)) | l) for h, l in zip(hi, lo)])
+    a = np.array(states, dtype=np.uint64)
+
+    def reference(state, g):
+        G, lead, r0 = (3, True, 23) if g == 5 else (4, g != 0, 3 + 4 * g)
+        s = [x % P for x in state]
+        if lead:
+            s[0] = ps.sbox(s[0])
+        for t in range(1, G + 1):
+            s = [(v + rc[12 * (r0 + t) + i]) % P for i, v in enumerate(ps.mat_vec(mds, s))]
+            if t < G:
+                s[0] = ps.sbox(s[0])
+        return s
+
+    for g in range(6):
+        out = np.zeros_like(a)
+        flag = np.zeros(len(states), np.uint8)
+        N.check(lib.p2mt_debug_partial_group(g, N.ptr(a), len(states), N.ptr(out), N.ptr(flag)))
+        assert flag[:n_rand].sum() == 0, "random states must not raise the flag"
+        for i, st in enumerate(states):
+            if not flag[i]:
+                assert [int(x) for x in out[i]] == reference(st, g), (g, i)
+        if g < 5:
+            assert flag[n_rand] == 1, "all-ones words: every chain of a four-round group passes 2^64"
+            assert flag[n_rand + 5:].sum() > 0
+        else:
+            assert flag.sum() == 0 or flag.sum() < 8  # groups of three cannot overflow; only the 2^-32 borrows could flag
+
+
 def test_transform_arithmetic_primitives(pkg):
     """The NTT / LDE kernels' field arithmetic (csrc/ntt_arith.hip.h): add, sub, multiply, the fused butterfly and the
     multiplication by every power of two 2^E, E in [0, 192), on crafted edge operands + random ones, against Python integers.
