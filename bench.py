@@ -784,10 +784,13 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
     acc, reason = C.c_int(0), C.c_int(0)
     Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
     assert acc.value == 1, "the product's verifier rejects the product's proof (reason %d)" % reason.value
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    per_call = []  # a verification is ~1 ms of host wall time: one pre-empted call would move a mean of a few dozen
+    for _ in range(max(args.steps, 20)):
+        t0 = time.perf_counter()
         Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
-    out["verify_ms"] = (time.perf_counter() - t0) * 1e3 / args.steps
+        per_call.append((time.perf_counter() - t0) * 1e3)
+    out["verify_ms"] = float(np.median(per_call))
+    out["verify_ms_mean"] = float(np.mean(per_call))
     # batched verify: 256 proofs per pass (transcripts and Merkle paths with the proof index in grid z, field arithmetic on host threads)
     many = np.ascontiguousarray(np.tile(proof, (256, 1)))
     accs, reasons = (C.c_int * 256)(), (C.c_int * 256)()
@@ -948,10 +951,12 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
     assert outer.verify(final_proof), "the product's verifier rejects the outer proof"
     assert np.array_equal(final_proof[-4:], root), "the outer proof's public input is not the MMR root"
-    t0 = time.perf_counter()
-    for _ in range(max(args.steps // 4, 1)):
+    per_call = []
+    for _ in range(max(args.steps // 2, 10)):
+        t0 = time.perf_counter()
         outer.verify(final_proof)
-    verify_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps // 4, 1)
+        per_call.append((time.perf_counter() - t0) * 1e3)
+    verify_ms = float(np.median(per_call))  # median of per-call wall times (see run_prove)
     counts = list(outer.info.gate_counts)
     out = {"metric": "ms/proof mmr_plonky2_verifier_1_recursion (inner + outer prove, one leaf of a 2^20-leaf MMR)", "value": ms,
            "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_transpose(const u64* __restrict__ in
 
 // hash_or_noop of leaf i = column i of the poly-major matrix: lane i reads in[p * n_pts + i] (coalesced).
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_hash_columns(const u64* __restrict__ in, size_t w, size_t n_pts,
+__global__ __launch_bounds__(kBlock, 4) void k_hash_columns(const u64* __restrict__ in, size_t w, size_t n_pts,
                                                          u64* __restrict__ digests, BatchArg ba, p2mt::PermCtx ctx) {
   in = bp(in, ba);
   digests = bp(digests, ba);

@@ -200,10 +200,45 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow(const ChState* __restrict__ 
 // and moves on; it exits when no proof has work left, so the grid always drains.  Blocks are handed out in increasing order and
 // a taken block is always evaluated unless a smaller witness is already known, so the result is the smallest witness, as in
 // the single-proof search.  counter: one u32 per proof (zeroed by the host), blocks of [base, base + max_blocks * 256).
+// Round 0 of the grind's permutation, the part every candidate of a proof shares: twelve lanes (threadIdx.x < 12; all threads of the
+// workgroup must call it) form base[r] = sum_{k != n_in} M[r][k] (t[k] + rc[k])^7 + rc[12 + r] in `s_base`.
+GL_DEV void pow_shared_first_round(const ChState* st, const PermCtx& ctx, u64* s_y /*[12]*/, u64* s_base /*[12]*/) {
+  const u32 n_in = st->n_in;
+  if (threadIdx.x < 12) {
+    const u32 k = threadIdx.x;
+    u64 v = st->state[k];
+    if (k < 8 && k < n_in) v = st->in[k];
+    s_y[k] = k == n_in ? 0 : gl::canon(gl::pow7(gl::add_c(v, ctx.rc[k])));
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const u32 r = threadIdx.x;
+    u64 acc = ctx.rc[12 + r];
+#pragma unroll
+    for (u32 k = 0; k < 12; ++k) {
+      const u32 idx = k >= r ? k - r : k + 12 - r;  // MDS[r][k] = CIRC[(k - r) mod 12] (+ 8 at [0][0])
+      const u64 word = idx < 8 ? 0x0D0D1C0210290F11ull : 0x14221227ull;
+      const u64 m = ((word >> (8 * (idx & 7))) & 0xFF) + ((r == 0 && k == 0) ? 8u : 0u);
+      acc = gl::canon(gl::mul_add(s_y[k], m, acc));
+    }
+    s_base[r] = acc;
+  }
+  __syncthreads();
+}
+// ... once per proof of a batch, ahead of the queue kernel (whose workgroups would otherwise redo it for every block of 256 candidates:
+// ~450 instructions on one wave and two barriers in front of each ~9 400-instruction candidate hash)
+__global__ __launch_bounds__(64) void k_fri_pow_prep(const ChState* __restrict__ st, u64* __restrict__ base_out, BatchArg ba, PermCtx ctx) {
+  __shared__ u64 s_y[12], s_base[12];
+  pow_shared_first_round(bp(st, ba), ctx, s_y, s_base);
+  if (threadIdx.x < 12) bp(base_out, ba)[threadIdx.x] = s_base[threadIdx.x];
+}
+
+// pow_base0: the per-proof shared first round from k_fri_pow_prep, or nullptr (each block computes it itself)
+// (four waves per SIMD asked for, as for the stage-1 tree kernel: the allocator settles for 137 VGPRs = three on its own)
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restrict__ st0, u32 pow_bits, u64 base, u32 max_blocks,
+__global__ __launch_bounds__(kBlock, 4) void k_fri_pow_queue(const ChState* __restrict__ st0, u32 pow_bits, u64 base, u32 max_blocks,
                                                           unsigned long long* __restrict__ result0, u32* __restrict__ counter0,
-                                                          u32 B, BatchArg ba, PermCtx ctx) {
+                                                          u32 B, BatchArg ba, PermCtx ctx, const u64* __restrict__ pow_base0 = nullptr) {
   __shared__ u32 s_dist, s_blk, s_go;
   unsigned p = blockIdx.x % B;
   poseidon_fast::MfmaCtx mc;  // PR == 5: the permutation below runs with every lane of the workgroup active (its guard is workgroup-uniform)
@@ -264,26 +299,12 @@ __global__ __launch_bounds__(kBlock) void k_fri_pow_queue(const ChState* __restr
         // share of its MDS layer: twelve lanes form base[r] = sum_{k != n_in} M[r][k] (t[k] + rc[k])^7 + rc[12 + r] once per block;
         // a candidate then costs ONE first-round S-box and twelve two-mad rows, and of the last layer only row 7.
         __shared__ u64 s_y[12], s_base[12];
-        if (threadIdx.x < 12) {
-          const u32 k = threadIdx.x;
-          u64 v = st->state[k];
-          if (k < 8 && k < n_in) v = st->in[k];
-          s_y[k] = k == n_in ? 0 : gl::canon(gl::pow7(gl::add_c(v, ctx.rc[k])));
+        if (pow_base0) {  // (workgroup-uniform)
+          if (threadIdx.x < 12) s_base[threadIdx.x] = bp_at(pow_base0, ba, q)[threadIdx.x];
+          __syncthreads();
+        } else {
+          pow_shared_first_round(st, ctx, s_y, s_base);
         }
-        __syncthreads();
-        if (threadIdx.x < 12) {
-          const u32 r = threadIdx.x;
-          u64 acc = ctx.rc[12 + r];
-#pragma unroll
-          for (u32 k = 0; k < 12; ++k) {
-            const u32 idx = k >= r ? k - r : k + 12 - r;  // MDS[r][k] = CIRC[(k - r) mod 12] (+ 8 at [0][0])
-            const u64 word = idx < 8 ? 0x0D0D1C0210290F11ull : 0x14221227ull;
-            const u64 m = ((word >> (8 * (idx & 7))) & 0xFF) + ((r == 0 && k == 0) ? 8u : 0u);
-            acc = gl::canon(gl::mul_add(s_y[k], m, acc));
-          }
-          s_base[r] = acc;
-        }
-        __syncthreads();
         u64 sticky = ctx.force_fallback;
         const u64 y = poseidon_fast::pow7(gl::add_c(cand, ctx.rc[n_in]), sticky);
         const u32 yl = (u32)y, yh = (u32)(y >> 32);
@@ -1002,6 +1023,7 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     return at;
   };
   const size_t o_alpha = carve(2), o_betas = carve(16), o_qch = carve(1 + p->num_query_rounds), o_chsave = carve(32), o_cnt = carve(1);
+  const size_t o_powbase = carve(12);
   const size_t o_apow = carve(2 * (max_cnt + 1)), o_partial = carve(max_groups * 2 * n);
   const size_t o_fin = carve(2 * (size_t)n), o_c0 = carve(2 * (size_t)n), o_c1 = carve(2 * (size_t)n);
   size_t o_vals[8], o_leaves[8], o_dig[8];
@@ -1130,9 +1152,11 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
         const u32 max_blocks = (u32)(batch_chunk / kBlock);
         const u64 wgs = std::min<u64>((u64)B * max_blocks, 2048);
         if (rt().mds == 2 && rt().partial == 0) {  // default: dense MDS layers on the matrix pipe
+          hipLaunchKernelGGL(k_fri_pow_prep, bgrid(1), dim3(64), 0, st, (const ChState*)ch->d, ws + o_powbase, barg(), p2mt::perm_ctx());
+          P2MT_LAUNCH_CHECK();
           hipLaunchKernelGGL((k_fri_pow_queue<2, 5>), dim3((unsigned)wgs), dim3(kBlock), 0, st, (const ChState*)ch->d,
                              (u32)p->proof_of_work_bits, base, max_blocks, d_wit, reinterpret_cast<u32*>(ws + o_cnt), B, barg(),
-                             p2mt::perm_ctx());
+                             p2mt::perm_ctx(), (const u64*)(ws + o_powbase));
           P2MT_LAUNCH_CHECK();
           return P2MT_OK;
         }

@@ -18,7 +18,7 @@ namespace {
 
 // ---------------------------------------------------------------- stateless batch kernels
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
+__global__ __launch_bounds__(kBlock, 4) void k_permute_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
                                                           PermCtx ctx) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kBlock) void k_permute_batch(const u64* __restrict_
 }
 
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
+__global__ __launch_bounds__(kBlock, 4) void k_two_to_one_batch(const u64* __restrict__ in, u64* __restrict__ out, size_t n,
                                                              PermCtx ctx) {
   poseidon_fast::MfmaCtx mc;  // PR == 5: matrix-pipe MDS; every lane stays in the permutation, lanes past the end redo the last pair
   if constexpr (PR == 5) poseidon_fast::mfma32_ctx_init(mc);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_two_to_one_batch(const u64* __restri
 }
 
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_hash_rows(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
+__global__ __launch_bounds__(kBlock, 4) void k_hash_rows(const u64* __restrict__ in, size_t n, size_t len, int noop_short,
                                                       u64* __restrict__ out, BatchArg ba, PermCtx ctx) {
   in = bp(in, ba);
   out = bp(out, ba);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_leaf_digests(const u64* __restrict__
 
 // next_level_hashes (:21-25): out[j] = two_to_one(in[2j], in[2j+1])
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
+__global__ __launch_bounds__(kBlock, 4) void k_merkle_level(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
                                                          BatchArg ba, PermCtx ctx) {
   in = bp(in, ba);
   out = bp(out, ba);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 4) void k_merkle_subtree(const u64* __restrict
 
 // verify_merkle_proof (:91-109), one proof per lane
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_verify_merkle_proof(const u64* __restrict__ leaves, const u64* __restrict__ idx,
+__global__ __launch_bounds__(kBlock, 4) void k_verify_merkle_proof(const u64* __restrict__ leaves, const u64* __restrict__ idx,
                                                                 const u64* __restrict__ roots,
                                                                 const u64* __restrict__ hashes, size_t n_hashes, size_t m,
                                                                 uint8_t* __restrict__ result, PermCtx ctx) {

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_mmr_proof_batch(const u64* __restric
 
 // MMR_proof::verify (:232-252), one proof per lane; `bagged` = hash_or_noop(peaks) computed once by k_bag_peaks
 template <int M, int PR>
-__global__ __launch_bounds__(kBlock) void k_mmr_verify_batch(const u64* __restrict__ sib, const uint8_t* __restrict__ lefts,
+__global__ __launch_bounds__(kBlock, 4) void k_mmr_verify_batch(const u64* __restrict__ sib, const uint8_t* __restrict__ lefts,
                                                              const int32_t* __restrict__ n_sib, size_t max_sib,
                                                              const u64* __restrict__ peaks, int n_peaks,
                                                              const u64* __restrict__ leaves, const u64* __restrict__ root,
