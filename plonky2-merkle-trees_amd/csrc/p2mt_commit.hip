@@ -722,26 +722,28 @@ __global__ __launch_bounds__(kBlock, 4) void k_hash_columns(const u64* __restric
   if (w <= 4) {  // no permutation: zero-padded copy
     for (size_t p = 0; p < w; ++p) s[p] = in[p * n_pts + i];
   } else {
-    auto run = [&](auto fast) -> u64 {
-      u64 sticky = 0;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) s[k] = 0;
+    // A flagged wave (~0.13 % of wave-permutations) redoes THAT permutation with the exact reference form, from the copy of the
+    // state each lane parks in LDS in front of every permutation.  (Until round 4 the flag was collected over the whole sponge and a
+    // flagged wave -- one in ~45 for a 135-column leaf -- redid all 17 permutations at the end, alone on its SIMD for ~1 ms after
+    // every other wave of the launch had finished: that tail was 15 % of the launch.)
+    __shared__ u64 stash[M == 2 ? 12 : 1][kBlock];
 #pragma unroll 1
-      for (size_t off = 0; off < w; off += 8) {
+    for (size_t off = 0; off < w; off += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (off + k < w) s[k] = in[(off + k) * n_pts + i];
-        if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : 1)>(s, ctx.rc, &mc);
-        else if constexpr (M == 2) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
-        else poseidon::permute<M, PR>(s);
+      for (int k = 0; k < 8; ++k)
+        if (off + k < w) s[k] = in[(off + k) * n_pts + i];
+      if constexpr (M == 2) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) stash[k][threadIdx.x] = s[k];
+        const u64 sticky = poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : 1)>(s, ctx.rc, &mc) | ctx.force_fallback;
+        if (__builtin_expect(sticky != 0, 0)) {  // wave-uniform
+#pragma unroll
+          for (int k = 0; k < 12; ++k) s[k] = stash[k][threadIdx.x];
+          poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+        }
+      } else {
+        poseidon::permute<M, PR>(s);
       }
-      return sticky;
-    };
-    if constexpr (M == 2) {
-      const u64 sticky = run(std::true_type{}) | ctx.force_fallback;
-      if (__builtin_expect(sticky != 0, 0)) run(std::false_type{});
-    } else {
-      run(std::false_type{});
     }
   }
   if (!live) return;
