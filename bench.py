@@ -977,12 +977,13 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
                         "note": "dependency chains (witness levels, transcript, Merkle levels), not bandwidth: per-kernel split in "
                                 "profiles/r03_prove_timeline_recursion.txt"}}
     if getattr(args, "workload", "") in ("recursion", "mmr"):
-        # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks per thread at B = 32; two threads so
-        # that one pass's one-workgroup witness interpreter overlaps the other's hashing).  A shorter probe in the default line.
+        # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks per thread at B = 32; four threads so
+        # that a pass's one-workgroup witness interpreter and its latency-bound launches overlap the other passes' hashing: 1.46 k /
+        # 1.66 k / 1.70 k proofs/s with 2 / 3 / 4 threads, round 4).  A shorter probe in the default line.
         secs = "4" if args.workload == "recursion" else "2"
-        out["throughput"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", secs, "2"])
+        out["throughput"] = run_probe([sys.executable, os.path.join(ROOT, "tools", "recursion_batch_probe.py"), "32", secs, "4"])
         if "error" not in out["throughput"]:
-            out["throughput"]["note"] = ("p2mt_batch_prover on the inner and on the outer circuit, two host threads; proofs "
+            out["throughput"]["note"] = ("p2mt_batch_prover on the inner and on the outer circuit, four host threads; proofs "
                                          "bit-identical to the one-at-a-time path's; `value` above stays the single-proof latency")
     if cpu_baseline:
         from oracle import circuit as OC, recursion as R
