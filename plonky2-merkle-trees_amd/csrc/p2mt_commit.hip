@@ -193,6 +193,59 @@ __global__ __launch_bounds__(kBlock) void k_ifft_coset_lde(const u64* __restrict
   for (unsigned q = threadIdx.x; q < n; q += kBlock) o[q] = buf[q];
 }
 
+// The same for n = 64 (the 64-row circuits, i.e. every proof of the batched prover) with ONE WAVEFRONT per polynomial: lane m holds
+// point m, a DIF stage is a lane exchange (ds_bpermute) and a butterfly -- no LDS array, no barrier, and the inverse transform is done
+// once per polynomial instead of once per coset.  (k_ifft_coset_lde starts 8 workgroups of 256 threads per polynomial, 64 of them
+// busy, through 18 barriers each: 340 us for the 34 560 polynomials of a 256-proof pass, 0.4 TB/s.)  Same values, same order.
+__global__ __launch_bounds__(kBlock) void k_ifft_coset_lde_wave64(const u64* __restrict__ vals, unsigned rate_bits, size_t n_polys,
+                                                                  const u64* __restrict__ coset_pow, const u64* __restrict__ tw,
+                                                                  const u64* __restrict__ tw_inv, u64 n_inv, u64* __restrict__ coeffs,
+                                                                  u64* __restrict__ out, BatchArg ba) {
+  vals = bp(vals, ba);
+  coeffs = bp(coeffs, ba);
+  out = bp(out, ba);
+  const unsigned m = threadIdx.x & 63;
+  const size_t poly = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (poly >= n_polys) return;  // wave-uniform
+  auto xchg = [&](u64 v, unsigned half) -> u64 {  // lane m ^ half's value
+    const int addr = (int)((m ^ half) << 2);
+    const u32 lo = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)v), hi = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+  };
+  u64 twf[6], twi[6];  // stage s: tw[(m mod half) << s], half = 32 >> s (used by the lanes of the upper half of each block)
+#pragma unroll
+  for (unsigned s = 0; s < 6; ++s) {
+    const unsigned j = m & ((32u >> s) - 1);
+    twf[s] = tw[j << s];
+    twi[s] = tw_inv[j << s];
+  }
+  auto dif64 = [&](u64 v, const u64 (&t)[6]) -> u64 {  // lds_dif over the wave: natural -> bit-reversed
+#pragma unroll
+    for (unsigned s = 0; s < 6; ++s) {
+      const unsigned half = 32u >> s;
+      const u64 p = xchg(v, half);
+      const bool upper = (m & half) != 0;
+      const u64 sum = cadd(v, p), dif = cmul(csub(p, v), t[s]);  // upper lane: (x - y) tw with x = the partner's, y = its own
+      v = upper ? dif : sum;
+    }
+    return v;
+  };
+  u64 v = dif64(gl::canon(vals[(poly << 6) + m]), twi);
+  v = cmul(v, n_inv);
+  {  // natural order: lane m takes lane brev6(m)'s value
+    const int addr = (int)((__brev(m) >> 26) << 2);
+    const u32 lo = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)v), hi = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)(v >> 32));
+    v = ((u64)hi << 32) | lo;
+  }
+  coeffs[(poly << 6) + m] = v;
+  const unsigned cosets = 1u << rate_bits;
+#pragma unroll 1
+  for (unsigned j = 0; j < cosets; ++j) {
+    const u64 y = dif64(cmul(v, coset_pow[((size_t)j << 6) + m]), twf);
+    out[(poly << (6 + rate_bits)) + ((size_t)brev32(j, rate_bits) << 6) + m] = y;
+  }
+}
+
 // The scaling half of the x2^r coset LDE for transforms above 2^12 points: row = p * 2^r + brev_r(j) of `out` gets
 // c_p[m] * (shift * w_N^j)^m, m = 0 .. n-1 (natural order), ready for the in-place DIF.  The power is built per thread from two
 // exponentiations (base^(256 * (m / 256)) once per block, times base^(m % 256)): ~40 multiplications per element against the
@@ -1439,8 +1492,13 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
     P2MT_TRY(get_twiddles(log_n, 1, &twi));
     P2MT_TRY(get_coset_pows(log_n, rate_bits, 7, &cp));
     const int slot = p2mt::prof_begin();
-    hipLaunchKernelGGL(k_ifft_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)16 << log_n, st, d_polys,
-                       log_n, rate_bits, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde, barg());
+    static const bool wave64_knob = [] { const char* e = getenv("P2MT_LDE_WAVE64"); return e ? atoi(e) != 0 : true; }();
+    if (log_n == 6 && wave64_knob)  // one wavefront per polynomial (env P2MT_LDE_WAVE64=0: the workgroup-per-coset kernel, A/B)
+      hipLaunchKernelGGL(k_ifft_coset_lde_wave64, bgrid((unsigned)((n_polys + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, d_polys,
+                         rate_bits, n_polys, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde, barg());
+    else
+      hipLaunchKernelGGL(k_ifft_coset_lde, bgrid((unsigned)(n_polys << rate_bits)), dim3(kBlock), (size_t)16 << log_n, st, d_polys,
+                         log_n, rate_bits, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde, barg());
     p2mt::prof_end(slot);
     P2MT_LAUNCH_CHECK();
     d_coeffs = coeffs;
