@@ -1493,7 +1493,10 @@ int p2mt::commit_batch_dev(const uint64_t* d_polys, int is_values, size_t n_poly
     P2MT_TRY(get_coset_pows(log_n, rate_bits, 7, &cp));
     const int slot = p2mt::prof_begin();
     static const bool wave64_knob = [] { const char* e = getenv("P2MT_LDE_WAVE64"); return e ? atoi(e) != 0 : true; }();
-    if (log_n == 6 && wave64_knob)  // one wavefront per polynomial (env P2MT_LDE_WAVE64=0: the workgroup-per-coset kernel, A/B)
+    // one wavefront per polynomial for the proofs of a batch (env P2MT_LDE_WAVE64=0: the workgroup-per-coset kernel, A/B); a single
+    // proof keeps the workgroup-per-coset kernel: 171 polynomials do not fill the chip either way and its 18 barrier stages take
+    // 6 us where the wavefront's 54 dependent lane-exchange stages take 11
+    if (log_n == 6 && wave64_knob && p2mt::batch_B() > 1)
       hipLaunchKernelGGL(k_ifft_coset_lde_wave64, bgrid((unsigned)((n_polys + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, d_polys,
                          rate_bits, n_polys, cp, tw, twi, h_pow((u64)n % gl::P, gl::P - 2), coeffs, lde, barg());
     else

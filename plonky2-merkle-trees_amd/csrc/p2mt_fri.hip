@@ -591,6 +591,40 @@ __global__ __launch_bounds__(kBlock) void k_eval_ext_table(const EvalEntry* __re
   }
 }
 
+// The same for 64 coefficients per polynomial (the 64-row circuits: every proof of the batched prover) with EIGHT LANES per
+// polynomial: a lane evaluates its 8 coefficients by Horner, three lane-exchange steps add the eight partial sums with z^8, z^16,
+// z^32.  No LDS, no barrier; a wavefront serves 8 polynomials.  (k_eval_ext_table gives a 64-coefficient polynomial a workgroup of 256
+// threads, 64 of them busy for one coefficient each, and a 6-step tree with a barrier per step: 331 us for the 65 792 openings of a
+// 256-proof pass.)
+__global__ __launch_bounds__(kBlock) void k_eval_ext_table_oct64(const EvalEntry* __restrict__ tab, u32 n_tab, u64* __restrict__ out, BatchArg ba) {
+  out = bp(out, ba);
+  const u32 gid = blockIdx.x * kBlock + threadIdx.x, e = gid >> 3, q = gid & 7, lane = threadIdx.x & 63;
+  if (e >= n_tab) return;  // whole groups of eight lanes
+  const u64* c = bp(tab[e].coeffs, ba) + 8 * q;
+  const u64* pt = bp(tab[e].point, ba);
+  const Ext z{gl::mul(pt[0], tab[e].scale), gl::mul(pt[1], tab[e].scale)};
+  Ext S{0, 0};
+#pragma unroll
+  for (int m = 7; m >= 0; --m) S = ext_mul_add_base(S, z, c[m]);
+  Ext zp = ext_mul(z, z);
+  zp = ext_mul(zp, zp);
+  zp = ext_mul(zp, zp);  // z^8
+#pragma unroll
+  for (u32 d = 1; d < 8; d *= 2) {
+    const int addr = (int)((lane + d) << 2);  // (the lanes that use the value have their partner inside the group)
+    Ext o;
+    o.a = ((u64)(u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)(S.a >> 32)) << 32) | (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)S.a);
+    o.b = ((u64)(u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)(S.b >> 32)) << 32) | (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)S.b);
+    const Ext sum = ext_add(S, ext_mul(zp, o));
+    if ((q & (2 * d - 1)) == 0) S = sum;
+    zp = ext_mul(zp, zp);
+  }
+  if (q == 0) {
+    out[2 * e] = gl::canon(S.a);
+    out[2 * e + 1] = gl::canon(S.b);
+  }
+}
+
 // ---------------------------------------------------------------- host helpers
 inline u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % gl::P); }
 inline u64 h_pow(u64 a, u64 e) {
@@ -885,8 +919,13 @@ int p2mt::fri_openings_points_dev(const p2mt_fri_oracle* oracles, size_t n_oracl
       last_epoch = p2mt::scratch_epoch();
     }
   }
-  hipLaunchKernelGGL(k_eval_ext_table, bgrid((unsigned)tab.size()), dim3(kBlock), 0, st, (const EvalEntry*)d_tab, degree_bits, d_out,
-                     barg());
+  static const bool oct_knob = [] { const char* e = getenv("P2MT_EVAL_OCT"); return e ? atoi(e) != 0 : true; }();
+  if (degree_bits == 6 && oct_knob)  // eight lanes per polynomial (env P2MT_EVAL_OCT=0: the workgroup-per-polynomial kernel, A/B)
+    hipLaunchKernelGGL(k_eval_ext_table_oct64, bgrid((unsigned)((tab.size() * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       (const EvalEntry*)d_tab, (u32)tab.size(), d_out, barg());
+  else
+    hipLaunchKernelGGL(k_eval_ext_table, bgrid((unsigned)tab.size()), dim3(kBlock), 0, st, (const EvalEntry*)d_tab, degree_bits, d_out,
+                       barg());
   P2MT_LAUNCH_CHECK();
   return P2MT_OK;
 }
