@@ -67,10 +67,10 @@ const char *p2mt_last_error(void);
  * MDS mad chains, carry-mask reduction, sticky rare-event flag + exact fallback; with partial 0, the default, the dense
  * MDS layers of the tree-build kernels run on the matrix pipe and four partial rounds share one MDS application);
  * mds 0 / 1 = exact reference variants (v_mad_u64_u32 / v_dot2_u32_u16 MDS) with partial 0 = spec-form, 1 = sparse
- * partial rounds.  With mds 2, partial 1..7 select older forms of the stage-1 MMR kernel for A/B measurements
+ * partial rounds.  With mds 2, partial 1..8 select older forms of the stage-1 MMR kernel for A/B measurements
  * (1 sparse partial rounds, 2 / 3 MDS as 4x4x4 MFMAs in all / the partial rounds, 4 one MDS layer per partial round,
  * 5 VALU MDS everywhere, 6 = 5 with the previous field multiply, 7 = the default with three partial rounds per MDS
- * application instead of four).  All variants are bit-identical. */
+ * application instead of four, 8 = the default with the flag-form folds in its MDS layers).  All variants are bit-identical. */
 int p2mt_set_variant(int mds, int partial);
 int p2mt_get_variant(int *mds, int *partial);
 /* Which stage-1 kernel an MMR build uses with the current variant / environment: subtree_levels = 4|5 -> k_mmr_subtree (each lane

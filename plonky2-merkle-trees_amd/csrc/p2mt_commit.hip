@@ -775,8 +775,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_hash_columns(const u64* __restric
   if (w <= 4) {  // no permutation: zero-padded copy
     for (size_t p = 0; p < w; ++p) s[p] = in[p * n_pts + i];
   } else {
-    // A flagged wave (~0.13 % of wave-permutations) redoes THAT permutation with the exact reference form, from the copy of the
-    // state each lane parks in LDS in front of every permutation.  (Until round 4 the flag was collected over the whole sponge and a
+    // A flagged wave redoes THAT permutation with the exact reference form, from the copy of the state each lane parks in LDS in front
+    // of every permutation.  (With the exact folds of PR == 5 a flag is a 2^-32 event per operation; with flag-form folds it was
+    // ~0.07 % of wave-permutations.)  (Until round 4 the flag was collected over the whole sponge and a
     // flagged wave -- one in ~45 for a 135-column leaf -- redid all 17 permutations at the end, alone on its SIMD for ~1 ms after
     // every other wave of the launch had finished: that tail was 15 % of the launch.)
     __shared__ u64 stash[M == 2 ? 12 : 1][kBlock];
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_hash_columns(const u64* __restric
       if constexpr (M == 2) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) stash[k][threadIdx.x] = s[k];
-        const u64 sticky = poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : 1)>(s, ctx.rc, &mc) | ctx.force_fallback;
+        const u64 sticky = poseidon_fast::permute<false, 12, false, false, false, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : 1), 0, false, -1, PR == 5>(s, ctx.rc, &mc) | ctx.force_fallback;
         if (__builtin_expect(sticky != 0, 0)) {  // wave-uniform
 #pragma unroll
           for (int k = 0; k < 12; ++k) s[k] = stash[k][threadIdx.x];

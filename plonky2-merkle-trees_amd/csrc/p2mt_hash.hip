@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_merkle_level(const u64* __restric
   if constexpr (PR == 5) j = live ? j : n_out - 1;
   else if (!live) return;
   u64 o[4];
-  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+  two_to_one_r<M, PR, false, true>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {  // (exact folds: see k_mmr_level)
     load_hash(in + 8 * j, l);
     load_hash(in + 8 * j + 4, r);
   }, &mc);

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_mmr_level(u64* __restrict__ eleme
   const size_t last_leaf = ((j + 1) << h) - 1;
   const size_t pos = node_pos(last_leaf, h);
   u64 o[4];
-  two_to_one_r<M, PR>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
+  // (exact folds: a wave that redid its hash in the last round of a level launch held the launch for ~60 us)
+  two_to_one_r<M, PR, false, true>(ctx, o, [&](u64 (&l)[4], u64 (&r)[4]) {
     load_hash(elements + 4 * (pos - ((size_t)1 << h)), l);
     load_hash(elements + 4 * (pos - 1), r);
   }, &mc);
@@ -126,12 +127,12 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
   poseidon_fast::MfmaCtx mc;  // PR >= 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
   if constexpr (PR == 2 || PR == 3) mc = poseidon_fast::mfma_ctx_init();
-  if constexpr (PR == 5 || PR == 7) poseidon_fast::mfma32_ctx_init(mc);
+  if constexpr (PR == 5 || PR == 7 || PR == 8) poseidon_fast::mfma32_ctx_init(mc);
   // no lane leaves before the loop (PR == 5 / 7: an MFMA ignores EXEC and every lane's A operand serves the whole wave; a copy or spill
   // of it made under a partial EXEC would lose the idle lanes' rows): lanes past the end rebuild the last subtree and store nothing
   size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
   const bool live = blk < block0 + n_blocks;
-  if constexpr (PR == 5 || PR == 7) blk = live ? blk : block0 + n_blocks - 1;
+  if constexpr (PR == 5 || PR == 7 || PR == 8) blk = live ? blk : block0 + n_blocks - 1;
   else if (!live) return;
   const size_t first_leaf = blk << LV;
   const u64* lp = leaves + (first_leaf - leaf_base);
@@ -679,6 +680,7 @@ static int build_levels(p2mt_mmr* m, const u64* d_leaves, size_t leaf_base, size
       else if (variant == 5) P2MT_SUB4(4, 0);      // VALU MDS in the full rounds too (A/B: p2mt_set_variant(2, 5))
       else if (variant == 6) P2MT_SUB4(4, 6);      // ... and the previous field multiply (A/B: p2mt_set_variant(2, 6))
       else if (variant == 7) P2MT_SUB4(4, 7);      // partial rounds in groups of three, round 3's default (A/B: p2mt_set_variant(2, 7))
+      else if (variant == 8) P2MT_SUB4(4, 8);      // the default with flag-form folds in the MDS layers: 1.6 % fewer instructions, redo tails (p2mt_set_variant(2, 8))
 #ifndef P2MT_DEV_FEWER_VARIANTS
       else if (variant == 2) P2MT_SUB(4, 256, 2);  // MDS layers as 4x4x4 MFMAs (A/B: p2mt_set_variant(2, 2))
       else if (variant == 3) P2MT_SUB(4, 256, 3);  // ... of the 22 partial rounds only (p2mt_set_variant(2, 3))

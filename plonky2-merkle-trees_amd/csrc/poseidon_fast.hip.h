@@ -369,7 +369,8 @@ GL_DEV void mfma32_ctx_init(MfmaCtx& c) {
   });
   c.a32 = a;
 }
-template <bool ADD, int ROWS = 12, typename P = const u64*>
+// XF: the 96 -> 64 bit fold of a row in its exact form (two more instructions per row, no flag: see permute_impl)
+template <bool ADD, int ROWS = 12, typename P = const u64*, bool XF = false>
 GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc) {
   u64 acc[2][12];
   poseidon::static_for<0, 2>([&](auto hc) {
@@ -414,9 +415,13 @@ GL_DEV void mds_layer_mfma32(u64 (&s)[12], P add, u64& sticky, const MfmaCtx& mc
     const u64 al = acc[0][r];
     const u64 ah = add32((u32)(al >> 32), acc[1][r]);
     const u64 val = ((u64)(u32)ah << 32) | (u32)al;
-    u64 cm;
-    s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);
-    raise(sticky, cm);
+    if constexpr (XF) {
+      s[r] = exact::fold96((u32)(ah >> 32), val);
+    } else {
+      u64 cm;
+      s[r] = mad_eps_carry((u32)(ah >> 32), val, cm);
+      raise(sticky, cm);
+    }
   });
 }
 
@@ -725,10 +730,14 @@ GL_DEV void partial_rounds_g(u64 (&s)[12], P tab, Sbox&& sbox, u64& sticky) {
 //   (mds_layer_mfma32; `mc` from mfma32_ctx_init()), the other partial rounds batched as in P3.
 // P3: 1 = the 22 partial rounds as 7 groups of three with one MDS application each (partial_rounds3) + one single round;
 //   2 = the MDS layer of round 3 and the 22 partial rounds as five groups of four and one of three (partial_rounds_g).
+// XF: every 96 -> 64 bit fold of an MDS row in its exact form (+2 instructions per row, +1.6 % per hash).  What is left to raise the
+//   flag then has probability 2^-32 per operation, so a launch practically never redoes a hash -- for kernels of ONE hash per lane,
+//   where a redo (28 k instructions on one wave, ~60 us) in the last wavefronts sets the duration of the whole launch.
 // FIRST_DONE: the caller passes the state in front of round 1's S-boxes (it did round 0 itself: the proof-of-work grind shares eleven of
 //   the twelve first-round S-boxes between all candidates of a proof).  LAST_ROW >= 0: only that word of the result is computed.
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          int P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
+          int P3 = (!EXACT && !SPARSE && MFMA == 0), typename RC = const u64*, int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1,
+          bool XF = false>
 GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
   static_assert(!P3 || (!EXACT && !SPARSE && (MFMA == 0 || MFMA == 3)), "partial_rounds3 belongs to the dense flag form");
   u64 sticky = 0;
@@ -737,8 +746,8 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
     constexpr bool kAdd = decltype(add_tag)::value;
     constexpr int kRows = decltype(rows_tag)::value;
     if constexpr (MFMA == 1 || (MFMA == 2 && decltype(in_partial_round)::value)) mds_layer_mfma<kAdd, kRows>(s, add, sticky, *mc);
-    else if constexpr (MFMA == 3 && kRows == 12) mds_layer_mfma32<kAdd, kRows>(s, add, sticky, *mc);  // (4 rows: 104 mads beat it)
-    else mds_layer<kAdd, kRows, EXACT>(s, add, sticky);
+    else if constexpr (MFMA == 3 && kRows == 12) mds_layer_mfma32<kAdd, kRows, RC, XF>(s, add, sticky, *mc);  // (4 rows: 104 mads beat it)
+    else mds_layer<kAdd, kRows, EXACT || XF>(s, add, sticky);
   };
   auto mds = [&](auto add_tag, auto rows_tag, RC add) { mds4(add_tag, rows_tag, add, std::false_type{}); };
   using T = std::true_type;
@@ -762,9 +771,13 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
       mac_const<m4>(al, y4l);
       mac_const<m4>(ah, y4h);
       ah = add32((u32)(al >> 32), ah);
-      u64 cm;
-      s[r] = mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
-      raise(sticky, cm);
+      if constexpr (XF) {
+        s[r] = exact::fold96((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al);
+      } else {
+        u64 cm;
+        s[r] = mad_eps_carry((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al, cm);
+        raise(sticky, cm);
+      }
     });
   } else if constexpr (LEAF_PAIR) {  // round 0: words 0 and 4 only
     s[0] = sbox(gl::add_c(s[0], rc[0]));
@@ -881,10 +894,10 @@ GL_DEV u64 permute_impl(u64 (&s)[12], RC rc, const MfmaCtx* mc) {
 }
 // `rc` = the GLOBAL constant table (p2mt::perm_ctx().rc), never the LDS copy of the 12-lane layout
 template <bool CAP_ZERO = false, int OUT_ROWS = 12, bool EXACT = false, bool LEAF_PAIR = false, bool SPARSE = false, int MFMA = 0,
-          int P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1>
+          int P3 = (!EXACT && !SPARSE && MFMA == 0), int MULV = 0, bool FIRST_DONE = false, int LAST_ROW = -1, bool XF = false>
 GL_DEV u64 permute(u64 (&s)[12], const u64* __restrict__ rc, const MfmaCtx* mc = nullptr) {
-  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*, MULV, FIRST_DONE, LAST_ROW>(s, rc, mc);
-  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab, MULV, FIRST_DONE, LAST_ROW>(s, as_const_table(rc), mc);
+  if constexpr (SPARSE) return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, const u64*, MULV, FIRST_DONE, LAST_ROW, XF>(s, rc, mc);
+  else return permute_impl<CAP_ZERO, OUT_ROWS, EXACT, LEAF_PAIR, SPARSE, MFMA, P3, ctab, MULV, FIRST_DONE, LAST_ROW, XF>(s, as_const_table(rc), mc);
 }
 
 }  // namespace poseidon_fast

@@ -490,7 +490,7 @@ extern "C" int p2mt_set_variant(int mds, int partial) {
   return p2mt::abi_guard([&]() -> int {
   // partial: 0 dense, 1 sparse partial rounds; 2 / 3 (with mds == 2 only) = dense with all / only the partial rounds' MDS layers on the matrix pipe, 4 = one MDS
   // layer per partial round (round 2's form; the default batches four partial rounds per MDS application, 7 = three) -- stage-1 A/B
-  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 7 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
+  if (mds < 0 || mds > 2 || partial < 0 || partial > (mds == 2 ? 8 : 1)) return p2mt::fail(P2MT_EINVAL, "variant out of range");
   rt().mds = mds;
   rt().partial = partial;
   return P2MT_OK;

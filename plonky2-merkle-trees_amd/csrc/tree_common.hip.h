@@ -44,7 +44,7 @@ template <int M, int PR, typename Load>
 GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load, const poseidon_fast::MfmaCtx* mc = nullptr) {
   load(s);
   if constexpr (M == IMPL_FAST) {  // PR == 1: sparse partial rounds; PR == 5: dense MDS layers on the matrix pipe (`mc`, every lane of the wave active)
-    const u64 sticky = poseidon_fast::permute<false, 12, false, false, PR == 1, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : PR == 0)>(s, ctx.rc, mc) | ctx.force_fallback;
+    const u64 sticky = poseidon_fast::permute<false, 12, false, false, PR == 1, (PR == 5 ? 3 : 0), (PR == 5 ? 2 : PR == 0), 0, false, -1, PR == 5>(s, ctx.rc, mc) | ctx.force_fallback;
     if (__builtin_expect(sticky != 0, 0)) {
       load(s);
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
@@ -59,8 +59,11 @@ GL_DEV void permute_reloadable(u64 (&s)[12], const PermCtx& ctx, Load&& load, co
 // 3 = the same for the MDS layers of the partial rounds only, 4 = dense with one MDS layer per partial round (round 2's form; 0 batches
 // three partial rounds per MDS application, poseidon_fast::partial_rounds3), 5 = the MDS layers of the full rounds as one 32x32x32
 // MFMA per 8-bit limb (poseidon_fast::mds_layer_mfma32) and the partial rounds in groups of four (poseidon_fast::partial_rounds_g),
-// 7 = 5 with the partial rounds in groups of three (round 3's default).
-template <int M, int PR, bool LEAF_PAIR = false, typename LoadLR>
+// 7 = 5 with the partial rounds in groups of three (round 3's default), 8 = 5 with flag-form folds in the MDS layers.
+// XF: exact folds in the MDS layers (poseidon_fast::permute_impl) -- what PR == 5, the default, does anyway since round 4: a wave that
+// redoes a hash finishes ~60-200 us after its neighbours, and the last such wave of a launch sets its duration (stage 1: -1.8 % with
+// 1.6 % MORE instructions; the first level launch above it: 210 -> 167 us).  PR == 8 is PR == 5 with the flag-form folds (A/B).
+template <int M, int PR, bool LEAF_PAIR = false, bool XF = false, typename LoadLR>
 GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr, const poseidon_fast::MfmaCtx* mc = nullptr) {
   u64 s[12];
   auto load = [&](u64 (&st)[12]) {
@@ -75,7 +78,7 @@ GL_DEV void two_to_one_r(const PermCtx& ctx, u64 (&o)[4], LoadLR&& load_lr, cons
   };
   if constexpr (M == IMPL_FAST) {  // capacity words are zero and only 4 output words are needed
     load(s);
-    const u64 sticky = poseidon_fast::permute<true, 4, false, LEAF_PAIR, PR == 1, (PR == 2 || PR == 3 ? PR - 1 : (PR == 5 || PR == 7 ? 3 : 0)), (PR == 5 ? 2 : PR == 0 || PR == 6 || PR == 7), (PR == 6 ? 1 : 0)>(s, ctx.rc, mc) | ctx.force_fallback;
+    const u64 sticky = poseidon_fast::permute<true, 4, false, LEAF_PAIR, PR == 1, (PR == 2 || PR == 3 ? PR - 1 : (PR == 5 || PR == 7 || PR == 8 ? 3 : 0)), (PR == 5 || PR == 8 ? 2 : PR == 0 || PR == 6 || PR == 7), (PR == 6 ? 1 : 0), false, -1, XF || PR == 5>(s, ctx.rc, mc) | ctx.force_fallback;
     if (__builtin_expect(sticky != 0, 0)) {  // ~0.5 % of waves.  (Redoing with the exact fast-form instead was
       load(s);                               //  measured 2 % slower overall: bigger kernel, worse allocation.)
       poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
