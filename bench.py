@@ -363,7 +363,7 @@ def run_mmr(args, torch, pkg, lib, rank, world, local_rank, dist):
                      "kernel": info["kernel"],
                      "launch_ms": launch_ms, "launches_timed": kern_n.value,
                      "algorithmic_bytes_per_launch": algo_bytes, "hashes_per_launch": hashes_in_launch,
-                     "note": "Poseidon is integer-issue bound (see `valu`): ~10k VALU + 44 matrix-pipe instructions per 72 "
+                     "note": "Poseidon is integer-issue bound (see `valu`): ~10.1k VALU + 44 matrix-pipe instructions per 72 "
                              "algorithmic bytes, so the HBM fraction is ~3 % by construction (SURVEY.md 8d)"},
         # counter evidence for "compute-bound, the right way": share of SIMD issue cycles spent on VALU instructions and VALU
         # instructions per hash, from the committed PMC passes (null when this configuration was not profiled)
