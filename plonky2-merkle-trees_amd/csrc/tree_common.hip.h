@@ -106,7 +106,8 @@ GL_DEV void sponge(size_t len, const PermCtx& ctx, u64 (&o)[4], Get&& get) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (off + k < len) s[k] = get(off + k);
-      if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, PR == 1>(s, ctx.rc);
+      // (exact folds unless the sparse A/B form is selected: the flag is collected over the whole row and a flagged wave redoes all of it)
+      if constexpr (decltype(fast)::value) sticky |= poseidon_fast::permute<false, 12, false, false, PR == 1, 0, (PR == 1 ? 0 : 1), 0, false, -1, PR != 1>(s, ctx.rc);
       else if constexpr (M == IMPL_FAST) poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
       else poseidon::permute<M, PR>(s);
     }
