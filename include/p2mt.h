@@ -78,8 +78,8 @@ int p2mt_get_variant(int *mds, int *partial);
  * with it.) */
 int p2mt_get_build_config(int *subtree_levels, int *tile_log, int *subtree_block);
 /* Levels the stage-1 launch of a build of n_leaves (from an empty MMR) fuses: with per-lane subtrees (the default) the subtree size
- * adapts to the build -- 2^4 leaves per lane from 2^22 leaves up, 2^3 / 2^2 for smaller builds, so that the launch still puts ~4
- * wavefronts on every SIMD (a 2^21-leaf shard of an 8-GPU strong-scaling run is otherwise two wavefronts per SIMD running 15
+ * adapts to the build -- 2^4 leaves per lane from 2^24 leaves up, 2^3 from 2^23, 2^2 for smaller builds: the smallest subtree that
+ * still leaves 2^20 lanes (a 2^21-leaf shard of an 8-GPU strong-scaling run at 2^4 per lane is two wavefronts per SIMD running 15
  * dependent hashes each) -- unless the environment pins it (P2MT_SUBTREE=2|3|4|5).  > 0: levels; a negative value is a status
  * code (the library could not initialise), never a configuration. */
 int p2mt_mmr_stage1_levels(size_t n_leaves);

@@ -190,7 +190,10 @@ unsigned subtree_levels_for(size_t n_leaves) {
   // the A/B instantiations (sparse partial rounds, matrix-pipe MDS, 64- / 128-lane workgroups) exist for 2^4-leaf subtrees only
   if (r.partial != 0 || r.subtree_block != 256) return 4;
   unsigned lv = 4;
-  while (lv > 2 && (n_leaves >> lv) < ((size_t)4 * 1024 * 64)) --lv;
+  // 2^4 leaves per lane from 2^24 leaves up, 2^3 from 2^23, 2^2 below: the smallest subtree that still leaves 2^20 lanes (four rounds of
+  // four wavefronts per SIMD) wins at every size since round 4's faster level kernels (2^21 / 2^22 / 2^23 leaves: 0.88 / 1.44 / 2.56 ms
+  // against 0.91 / 1.56 / 2.68 with the round-3 rule of 2^18 lanes; profiles/r04_subtree_size_sweep.txt)
+  while (lv > 2 && (n_leaves >> lv) < ((size_t)1 << 20)) --lv;
   return lv;
 }
 

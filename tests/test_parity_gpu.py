@@ -147,7 +147,7 @@ def test_merkle_tree_vs_oracle(pkg, oracle, log_n):
         assert not pkg.verify_merkle_proof(leaves[i], i, t.tree[0][0], pr)           # wrong root
 
 
-@pytest.mark.parametrize("log_n,levels", [(18, 2), (21, 3), (22, 4)])
+@pytest.mark.parametrize("log_n,levels", [(18, 2), (21, 2), (23, 3)])
 def test_merkle_tree_large_subtree_stage(pkg, oracle, log_n, levels):
     """Large MerkleTree::build: stage 1 as per-lane subtrees of 2^levels leaves (k_merkle_subtree: leaf digests and levels 1..levels in
     one barrier-free launch, level-major slots, matrix-pipe MDS), the level kernels above it.  Every level and the root against the oracle,
@@ -347,15 +347,16 @@ def test_mfma32_default_and_valu_forms(pkg, oracle, variant):
         pkg.set_variant(*DEFAULT_VARIANT)
 
 
-@pytest.mark.parametrize("log_n,levels", [(18, 2), (20, 2), (21, 3), (22, 4)])
+@pytest.mark.parametrize("log_n,levels", [(18, 2), (20, 2), (22, 2), (23, 3)])
 def test_adaptive_subtree_size(pkg, oracle, log_n, levels):
-    """Round 3: the per-lane subtrees of the stage-1 launch shrink with the build (2^4 leaves per lane from 2^22 leaves up, 2^3 /
-    2^2 below, so that a small shard still puts ~4 wavefronts on every SIMD).  Every size class, full node array against the
-    oracle's level-order build, plus a ragged size in the same class."""
+    """The per-lane subtrees of the stage-1 launch shrink with the build (2^4 leaves per lane from 2^24 leaves up, 2^3 from 2^23,
+    2^2 below: the smallest subtree that leaves 2^20 lanes -- round 4's rule; test_full_size_bit_exact_2pow24 is the 2^4 class).
+    Every size class, full node array against the oracle's level-order build, plus a ragged size in the same class."""
     import hashlib
     import torch
     n = 1 << log_n
     assert pkg.lib().p2mt_mmr_stage1_levels(n) == levels
+    assert pkg.lib().p2mt_mmr_stage1_levels(1 << 24) == 4 and pkg.lib().p2mt_mmr_stage1_levels(1 << 21) == 2
     leaves = splitmix_leaves(n + 77, 0x5EED0400 + log_n)
     d = torch.from_numpy(leaves.view(np.int64)).cuda()
     m = pkg.MMR()
