@@ -149,6 +149,13 @@ GL_DEV PermCtx stage_round_constants(u64* lds /*[kWaveRcWords]*/, const PermCtx&
   return PermCtx{lds, ctx.force_fallback, lds + 360};
 }
 
+// lane C of this lane's 16-lane row, as ONE instruction (v_mov_b64_dpp row_newbcast:C).  The twelve state words live in lanes 0..11 of
+// row 0; the other rows compute on their own lanes' values and nobody reads them (round 4: two v_readlane per word before -- 24 of the
+// ~100 instructions of a round).
+template <int C>
+GL_DEV u64 row_bcast64(u64 v) {
+  return (u64)__builtin_amdgcn_update_dpp((long long)0, (long long)v, 0x150 + C, 0xf, 0xf, true);
+}
 template <bool EXACT, typename Hook>
 GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky) {
   const unsigned lane = threadIdx.x & 63;
@@ -186,14 +193,13 @@ GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky
     hook(r, x);
     const u64 y = sbox(x);
     if (full || lane == 0) x = y;
-    const u32 xl = (u32)x, xh = (u32)(x >> 32);
     u64 al = add ? (u64)(u32)c_fold : 0, ah = add ? (u64)(u32)(c_fold >> 32) : 0;
-#pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const u32 sl = (u32)__builtin_amdgcn_readlane((int)xl, c), sh = (u32)__builtin_amdgcn_readlane((int)xh, c);
-      al += (u64)sl * kk[c];
-      ah += (u64)sh * kk[c];
-    }
+    poseidon::static_for<0, 12>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const u64 sc = row_bcast64<c>(x);
+      al += (u64)(u32)sc * kk[c];
+      ah += (u64)(u32)(sc >> 32) * kk[c];
+    });
     ah = poseidon_fast::add32((u32)(al >> 32), ah);
     const u64 val = ((u64)(u32)ah << 32) | (u32)al;
     if constexpr (EXACT) {
@@ -208,29 +214,26 @@ GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky
     ah = poseidon_fast::add32((u32)(al >> 32), ah);
     return poseidon_fast::exact::fold96((u32)(ah >> 32), ((u64)(u32)ah << 32) | (u32)al);
   };
-  auto bcast = [](u64 v, int src) -> u64 {  // lane `src`'s value in every lane
-    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, src);
-  };
+
   auto group = [&](int g) {  // rounds k = 4 + 3g, k + 1, k + 2
     const int k = POSEIDON_HALF_FULL_ROUNDS + 3 * g;
     const u64 init = ctx.w3[14 * g + L];
     hook(k, x);
     const u64 y = sbox(x);
     if (lane == 0) x = y;
-    const u32 xl = (u32)x, xh = (u32)(x >> 32);
     u64 al = (u64)(u32)init, ah = (u64)(u32)(init >> 32);
-#pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      const u32 sl = (u32)__builtin_amdgcn_readlane((int)xl, c), sh = (u32)__builtin_amdgcn_readlane((int)xh, c);
-      al += (u64)sl * k3[c];
-      ah += (u64)sh * k3[c];
-    }
-    const u64 x1 = bcast(fold(al, ah), 0);  // v1[0]
+    poseidon::static_for<0, 12>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      const u64 sc = row_bcast64<c>(x);
+      al += (u64)(u32)sc * k3[c];
+      ah += (u64)(u32)(sc >> 32) * k3[c];
+    });
+    const u64 x1 = row_bcast64<0>(fold(al, ah));  // v1[0]
     hook(k + 1, x1);
     const u64 d1 = poseidon_fast::sub_any(sbox(x1), x1);
     al += (u64)(u32)d1 * cf1;
     ah += (u64)(u32)(d1 >> 32) * cf1;
-    const u64 x2 = bcast(fold(al, ah), 1);  // v2[0]
+    const u64 x2 = row_bcast64<1>(fold(al, ah));  // v2[0]
     hook(k + 2, x2);
     const u64 d2 = poseidon_fast::sub_any(sbox(x2), x2);
     al += (u64)(u32)d2 * cf2;
@@ -263,7 +266,8 @@ template <typename Hook>
 GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
   u64 sticky = ctx.force_fallback;  // lane masks OR-ed on the scalar pipe: wave-uniform
   const u64 y = permute_wave_impl<false>(x, ctx, hook, sticky);
-  if (__builtin_expect(sticky != 0, 0)) return permute_wave_impl<true>(x, ctx, hook, sticky);
+  // (the flag of row 0 only: the other rows of the wave run the same instructions on values nobody reads)
+  if (__builtin_expect((sticky & 0xFFFFull) != 0, 0)) return permute_wave_impl<true>(x, ctx, hook, sticky);
   return y;
 }
 GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
