@@ -851,12 +851,14 @@ __global__ __launch_bounds__(kBlock) void k_hash_columns_wave(const u64* __restr
   if (col >= n_pts) return;  // wave-uniform
   const unsigned lane = threadIdx.x & 63;
   u64 x = 0;
+  u64 nx = (lane < 8 && lane < w) ? in[lane * n_pts + col] : 0;  // the next chunk's word is fetched under the current permutation
 #pragma unroll 1
   for (size_t off = 0; off < w; off += 8) {
     if (lane < 8 && off + lane < w) {
-      x = in[(off + lane) * n_pts + col];
+      x = nx;
       if (leaves) leaves[col * w + off + lane] = x;  // the leaf-major copy the FRI queries read (saves the transpose launch)
     }
+    if (lane < 8 && off + 8 + lane < w) nx = in[(off + 8 + lane) * n_pts + col];
     x = p2mt_dev::permute_wave(x, ctx);
   }
   if (lane < 4) digests[4 * col + lane] = gl::canon(x);
