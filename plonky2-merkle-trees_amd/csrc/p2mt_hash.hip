@@ -84,9 +84,11 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict
     return;
   }
   u64 x = 0;
+  u64 nx = (lane < 8 && lane < len) ? r[lane] : 0;  // the next chunk's word is fetched under the current permutation
 #pragma unroll 1
   for (size_t off = 0; off < len; off += 8) {
-    if (lane < 8 && off + lane < len) x = r[off + lane];  // overwrite mode: the other words keep the previous state
+    if (lane < 8 && off + lane < len) x = nx;  // overwrite mode: the other words keep the previous state
+    if (lane < 8 && off + 8 + lane < len) nx = r[off + 8 + lane];
     x = permute_wave(x, ctx);
   }
   if (lane < 4) out[4 * row + lane] = gl::canon(x);

@@ -171,10 +171,12 @@ __global__ __launch_bounds__(kMerkleBlock) void k_verify_paths(const u64* __rest
   const VItem it = items[item];
   u64 x = lane < 4 ? digests[4 * (size_t)item + lane] : 0;
   u32 index = it.index;
+  u64 sib_next = (lane < 8 && it.n_sib) ? dv[it.sib_off + (lane & 3)] : 0;  // the next sibling is fetched under the current permutation
 #pragma unroll 1
   for (u32 s = 0; s < it.n_sib; ++s, index >>= 1) {
     const u64 up = __shfl_up((unsigned long long)x, 4);  // lanes 4..7 see the current digest
-    const u64 sib = lane < 8 ? dv[it.sib_off + 4 * s + (lane & 3)] : 0;
+    const u64 sib = sib_next;
+    if (lane < 8 && s + 1 < it.n_sib) sib_next = dv[it.sib_off + 4 * (s + 1) + (lane & 3)];
     const bool sib_left = index & 1;
     u64 y = 0;
     if (lane < 4) y = sib_left ? sib : x;
