@@ -8,8 +8,8 @@
 // fri/verifier.rs (PrecomputedReducedOpenings, fri_combine_initial, compute_evaluation, the final polynomial).  The transcript and
 // the Merkle paths were on the device already (p2mt_circuit.hip); with these three kernels a verification is launches only, one
 // small copy back, and the proofs of a batch ride in grid z:
-//   k_verify_items     one lane per query: the query's leaf index from the transcript's challenge and the (row, path, cap) triples
-//                      k_verify_merkle hashes (the host used to build them between two synchronisations);
+//   verify_item()      the query's leaf index from the transcript's challenge and the (row, path, cap) triple of one (query, tree)
+//                      pair, worked out by the wavefront that folds the path (the host used to build them between two synchronisations);
 //   k_verify_fri       16 lanes per query: fri_combine_initial as 16 interleaved Horner sums in alpha^16, the two denominators'
 //                      inverses on two lanes, every reduction layer's 2^arity-point interpolation as ONE barycentric term per lane
 //                      (the points are a coset c<g> of the 2^arity-th roots of unity, so prod_{j != i}(p_i - p_j) = arity p_i^(arity-1)
@@ -77,35 +77,35 @@ GL_DEV E group16_bcast(E v, int src) {
   return E{(u64)__shfl((unsigned long long)v.a, src, 16), (u64)__shfl((unsigned long long)v.b, src, 16)};
 }
 
-// ---------------------------------------------------------------- k_verify_items
+// ---------------------------------------------------------------- the (row, path, cap) triples
 // mirrors the item construction of verify_pass (p2mt_circuit.hip, rounds 1-3): per query 4 oracle rows, then one coset per layer
 struct VItem {
   u32 leaf_off, width, index, sib_off, n_sib, cap_off;
 };
-__global__ __launch_bounds__(64) void k_verify_items(const u64* __restrict__ dv, VItem* __restrict__ items, VerifyDevArgs a, BatchArg ba) {
-  dv = bp(dv, ba);
-  items = bp(items, ba);
-  const u32 q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= a.fri.num_query_rounds) return;
+// the triple of ONE (query, tree) pair, computed by the wavefront that folds its path (until the end of round 4 a k_verify_items launch
+// sat between the end of the transcript and the path folds: 21 us of launch and dependent-load latency for 28 lanes of index arithmetic)
+GL_DEV VItem verify_item(const u64* __restrict__ dv, const VerifyDevArgs& a, u32 q, u32 tr) {
   const u32 log_big = a.fri.degree_bits + a.fri.rate_bits, cap_h = a.fri.cap_height, nred = a.fri.num_reductions;
   u32 x_index = (u32)(dv[a.o_out + 27 + q] & (((u64)1 << log_big) - 1));
   u32 w = a.o_proof + a.off_fri + nred * 64 + q * a.query_words;
-  VItem* it = items + (size_t)q * (4 + nred);
-  const u32 cap_off[4] = {a.o_cscap, a.o_proof, a.o_proof + 64, a.o_proof + 128};
-  for (u32 tr = 0; tr < 4; ++tr) {
-    const u32 np = (u32)a.n_polys[tr];
-    it[tr] = VItem{w, np, x_index, w + np, log_big - cap_h, cap_off[tr]};
-    w += np + 4 * (log_big - cap_h);
-  }
+  VItem r{0, 0, 0, 0, 0, 0};
   u32 log_sz = log_big;
-  for (u32 l = 0; l < nred; ++l) {
-    const u32 ab = a.fri.reduction_arity_bits[l], arity = 1u << ab;
-    x_index >>= ab;
-    const u32 n_sib = log_sz - ab - cap_h;
-    it[4 + l] = VItem{w, 2 * arity, x_index, w + 2 * arity, n_sib, a.o_proof + a.off_fri + 64 * l};
-    w += 2 * arity + 4 * n_sib;
-    log_sz -= ab;
+  for (u32 k = 0; k <= tr; ++k) {
+    if (k < 4) {
+      const u32 np = (u32)a.n_polys[k], n_sib = log_big - cap_h;
+      const u32 cap_off = k == 0 ? a.o_cscap : a.o_proof + 64 * (k - 1);
+      if (k == tr) r = VItem{w, np, x_index, w + np, n_sib, cap_off};
+      w += np + 4 * n_sib;
+    } else {
+      const u32 ab = a.fri.reduction_arity_bits[k - 4], arity = 1u << ab;
+      x_index >>= ab;
+      const u32 n_sib = log_sz - ab - cap_h;
+      if (k == tr) r = VItem{w, 2 * arity, x_index, w + 2 * arity, n_sib, a.o_proof + a.off_fri + 64 * (k - 4)};
+      w += 2 * arity + 4 * n_sib;
+      log_sz -= ab;
+    }
   }
+  return r;
 }
 
 // ---------------------------------------------------------------- Merkle paths in two halves
@@ -157,10 +157,9 @@ __global__ __launch_bounds__(kMerkleBlock) void k_verify_leaf_digests(const u64*
   if (lane < 4) digests[4 * (size_t)item + lane] = x;
 }
 
-__global__ __launch_bounds__(kMerkleBlock) void k_verify_paths(const u64* __restrict__ dv, const VItem* __restrict__ items,
+__global__ __launch_bounds__(kMerkleBlock) void k_verify_paths(const u64* __restrict__ dv, VerifyDevArgs a,
                                                                const u64* __restrict__ digests, u32 n_items, int* bad, BatchArg ba, PermCtx ctx) {
   dv = bp(dv, ba);
-  items = bp(items, ba);
   digests = bp(digests, ba);
   bad = bp(bad, ba);
   __shared__ u64 rc_lds[kWaveRcWords];
@@ -168,7 +167,8 @@ __global__ __launch_bounds__(kMerkleBlock) void k_verify_paths(const u64* __rest
   const u32 item = blockIdx.x * (kMerkleBlock / 64) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const u32 lane = threadIdx.x & 63;
-  const VItem it = items[item];
+  const u32 per_q = 4 + a.fri.num_reductions;
+  const VItem it = verify_item(dv, a, item / per_q, item % per_q);
   u64 x = lane < 4 ? digests[4 * (size_t)item + lane] : 0;
   u32 index = it.index;
   u64 sib_next = (lane < 8 && it.n_sib) ? dv[it.sib_off + (lane & 3)] : 0;  // the next sibling is fetched under the current permutation
@@ -593,17 +593,18 @@ int p2mt::verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const u
   VerifyStreams* v = static_cast<VerifyStreams*>(vs);
   hipStream_t st = p2mt::rt().stream;
   const unsigned nq = a.fri.num_query_rounds, n_items = nq * (4 + a.fri.num_reductions);
-  // the FRI arithmetic beside the path folds: it goes to the side stream the vanishing-polynomial check used (long done by now)
+  // The FRI arithmetic (the longer of the two, ~50 us) stays on the library stream, right behind the transcript; the path folds (~38 us,
+  // each wavefront works out its own (row, path, cap) triple) go beside it on the side stream the vanishing-polynomial check used
+  // (long done by now), which also has to have seen the leaf digests.
+  (void)d_items;
   P2MT_HIP(hipEventRecord(v->e_zeta, st));  // (re-used: "the transcript is complete")
   P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_zeta, 0));
-  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, v->s_open, dv, d_res + 1, a, barg());
+  P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_leaf, 0));
+  hipLaunchKernelGGL(k_verify_paths, bgrid((n_items + kMerkleBlock / 64 - 1) / (kMerkleBlock / 64)), dim3(kMerkleBlock), 0, v->s_open, dv,
+                     a, d_digests, n_items, d_flag, barg(), p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
-  P2MT_HIP(hipEventRecord(v->e_open, v->s_open));  // behind k_verify_openings AND k_verify_fri on that stream
-  hipLaunchKernelGGL(k_verify_items, bgrid((nq + 63) / 64), dim3(64), 0, st, dv, (VItem*)d_items, a, barg());
-  P2MT_LAUNCH_CHECK();
-  P2MT_HIP(hipStreamWaitEvent(st, v->e_leaf, 0));
-  hipLaunchKernelGGL(k_verify_paths, bgrid((n_items + kMerkleBlock / 64 - 1) / (kMerkleBlock / 64)), dim3(kMerkleBlock), 0, st, dv,
-                     (const VItem*)d_items, d_digests, n_items, d_flag, barg(), p2mt::perm_ctx());
+  P2MT_HIP(hipEventRecord(v->e_open, v->s_open));  // behind k_verify_openings AND k_verify_paths on that stream
+  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, st, dv, d_res + 1, a, barg());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipStreamWaitEvent(st, v->e_open, 0));
   return P2MT_OK;
