@@ -110,6 +110,18 @@ int p2mt_debug_field_op(int op, const uint64_t *a, const uint64_t *b, size_t n, 
  * bits, or one of the rare borrows of the flag-form arithmetic): its value is then unspecified -- the kernels redo such a hash with
  * the exact permutation. */
 int p2mt_debug_partial_group(int group, const uint64_t *states, size_t n, uint64_t *out, uint8_t *flag_out);
+/* One-launch tree builds (csrc/p2mt_plan.hip: stage 1 and every level above it as dependency-ordered workgroups of one grid).
+ * Knobs for measurement (a negative argument keeps the current value; the environment sets the defaults: P2MT_PLAN, P2MT_PLAN_MIN_LOG,
+ * P2MT_PLAN_ORDER, P2MT_PLAN_TQ, P2MT_PLAN_TW): enabled 0/1; min_log: smallest subtree (log2 leaves) that takes the one-launch path;
+ * order: 0 = stage 1 first, then level by level, 1 = upper levels interleaved behind the stage-1 items they depend on; tq / tw: a level
+ * with more than 2^tq nodes runs one hash per lane, down to 2^tw four lanes per hash, below one wavefront per hash. */
+int p2mt_debug_plan_knobs(int enabled, int min_log, int order, int tq, int tw);
+/* Record device-clock timestamps per work item in the one-launch builds this thread enqueues from now on (on != 0), and read the rows
+ * of the last such launch: rows_out[item][8] = kind (0 S, 1 U, 2 Q, 3 W), level, first node, start, inputs ready, end (ticks of 10 ns
+ * since the first item started), XCC id, HW_ID.  Returns the number of items of that launch (at most max_items rows are written), or a
+ * negative status. */
+int p2mt_debug_plan_profile(int on);
+int64_t p2mt_debug_plan_profile_read(uint64_t *rows_out, size_t max_items);
 /* Per-launch HIP-event timing of the dominant kernels (the fused MMR tile stage; the LDE / leaf-sponge kernels of
  * the commit step): enable, run, then read the summed duration and the number of launches recorded. */
 int p2mt_profile_enable(int on);

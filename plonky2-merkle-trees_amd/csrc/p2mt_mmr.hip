@@ -205,8 +205,12 @@ struct PosList {
 // get_peaks (:179-200) gather + bagging_the_peaks (:122-127): one lane (<= 32 permutations)
 template <int M, int PR>
 __global__ void k_mmr_peaks_root(const u64* __restrict__ elements, PosList pl, u64* __restrict__ peaks_out,
-                                 u64* __restrict__ root_out, PermCtx ctx) {
+                                 u64* __restrict__ root_out, const u32* __restrict__ plan_state, PermCtx ctx) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (plan_state && plan_state[1] != 0) {  // a hand-off of the one-launch build gave up (p2mt_plan.hip): no root, the host reports it
+    for (int k = 0; k < 4; ++k) root_out[k] = ~0ull;
+    return;
+  }
   for (int i = 0; i < pl.n; ++i) {
     u64 h[4];
     load_hash(elements + 4 * pl.pos[i], h);
@@ -450,6 +454,8 @@ struct p2mt_mmr {
   size_t n_leaves = 0;      // leaves already built into `elements`
   u64* scratch = nullptr;   // device: 64 peaks + root (65 HashOuts)
   std::vector<u64> pending; // add_leaf queue (host), flushed as one bulk extend before the MMR is observed
+  size_t plan_state_cap = 0;
+  uint32_t* plan_state = nullptr;  // state words of the last one-launch subtree build (p2mt_plan.hip); word 1 != 0: a hand-off gave up
 };
 
 static constexpr size_t kMaxPendingLeaves = (size_t)1 << 20;
@@ -495,6 +501,7 @@ extern "C" int p2mt_mmr_destroy(p2mt_mmr* m) {
   if (!m) return P2MT_OK;
   if (m->elements) (void)hipFree(m->elements);
   if (m->scratch) (void)hipFree(m->scratch);
+  if (m->plan_state) (void)hipFree(m->plan_state);
   delete m;
   return P2MT_OK;
   });
@@ -733,7 +740,36 @@ static int mmr_extend_dev_noflush(p2mt_mmr* m, const uint64_t* d_leaves, size_t 
   // (A chunked two-stream variant -- bulk tile kernels on one stream, each chunk's latency-bound upper levels on
   // another -- was measured and removed: 8 chunk launches of 2048 workgroups lose more to partial-wave tails on
   // the 1280 resident slots than the hidden ~0.5 ms of upper-level latency gains; 10.5 ms against 8.5 ms.)
-  P2MT_TRY(build_levels(m, d_leaves, n0, n0, n1, 63));
+  // Round 5: every aligned perfect subtree of the range that is large enough goes to ONE launch (p2mt_plan.hip: stage 1 and all the
+  // levels above it as dependency-ordered workgroups of one grid); what lies between such subtrees, and the carry chain above each
+  // (the nodes of height > H that end with the subtree's last leaf), are built by the launches below as before.
+  size_t plain_lo = n0, pos = n0;
+  while (pos < n1) {
+    unsigned H = pos ? (unsigned)__builtin_ctzll((unsigned long long)pos) : 63;
+    while (H > 0 && (H >= 63 || pos + ((size_t)1 << H) > n1)) --H;
+    const size_t span = (size_t)1 << H;
+    if (pos + span <= n1 && p2mt::tree_plan_wanted(H)) {
+      if (plain_lo < pos) P2MT_TRY(build_levels(m, d_leaves, n0, plain_lo, pos, 63));
+      const p2mt::TreeLayout lay{0, m->elements, nullptr, 0};
+      size_t state_bytes = 0;
+      P2MT_TRY(p2mt::tree_plan_state_bytes(H, &state_bytes));
+      if (state_bytes > m->plan_state_cap) {  // owned by the handle: k_mmr_peaks_root reads its error word later
+        if (m->plan_state) {
+          P2MT_HIP(hipStreamSynchronize(rt().stream));
+          (void)hipFree(m->plan_state);
+          m->plan_state = nullptr;
+          m->plan_state_cap = 0;
+        }
+        P2MT_HIP(hipMalloc((void**)&m->plan_state, state_bytes));
+        m->plan_state_cap = state_bytes;
+      }
+      P2MT_TRY(p2mt::tree_plan_launch(lay, d_leaves + (pos - n0), pos, H, m->plan_state));
+      P2MT_TRY(build_levels(m, d_leaves, n0, pos, pos + span, 63, H));
+      plain_lo = pos + span;
+    }
+    pos += span;
+  }
+  if (plain_lo < n1) P2MT_TRY(build_levels(m, d_leaves, n0, plain_lo, n1, 63));
   m->n_leaves = n1;
   return P2MT_OK;
 }
@@ -918,11 +954,17 @@ static int mmr_peaks_root(const p2mt_mmr* m, uint64_t* peaks_out, int* n_peaks, 
   P2MT_TRY(mmr_peak_positions(m, &pl));
   u64* d_peaks = m->scratch;
   u64* d_root = m->scratch + 4 * 64;
-  P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, d_peaks, d_root);
+  P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, d_peaks, d_root, (const u32*)m->plan_state);
   if (peaks_out) P2MT_HIP(hipMemcpyAsync(peaks_out, d_peaks, (size_t)pl.n * 32, hipMemcpyDeviceToHost, rt().stream));
   if (root_out) P2MT_HIP(hipMemcpyAsync(root_out, d_root, 32, hipMemcpyDeviceToHost, rt().stream));
   P2MT_HIP(hipStreamSynchronize(rt().stream));
   if (n_peaks) *n_peaks = pl.n;
+  if (m->plan_state) {  // (an all-ones word is not a field element: the kernel's mark for "a hand-off of the one-launch build gave up")
+    uint32_t err = 0;
+    if (root_out ? root_out[0] == ~0ull : false) err = 1;
+    if (!root_out) P2MT_HIP(hipMemcpy(&err, m->plan_state + 1, 4, hipMemcpyDeviceToHost));
+    if (err) return p2mt::fail(P2MT_EHIP, "MMR build: an in-launch hand-off timed out (tree plan); the node array is incomplete");
+  }
   return P2MT_OK;
 }
 
@@ -933,7 +975,7 @@ extern "C" int p2mt_mmr_root_dev(const p2mt_mmr* m, uint64_t* d_root_out) {
   P2MT_TRY(mmr_flush(m));
   PosList pl;
   P2MT_TRY(mmr_peak_positions(m, &pl));
-  P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, m->scratch, d_root_out);
+  P2MT_DISPATCH(k_mmr_peaks_root, 1, 64, (const u64*)m->elements, pl, m->scratch, d_root_out, (const u32*)m->plan_state);
   return P2MT_OK;
   });
 }

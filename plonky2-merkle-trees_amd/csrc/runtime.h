@@ -85,7 +85,7 @@ PermCtx perm_ctx();  // (runtime.hip: needs the table layout of poseidon_fast.hi
 
 // Grow-only device scratch slots for the commit pipeline: no hipMalloc/hipFree (and so no implicit device
 // synchronisation) on the steady-state path; all users run on the one library stream, in order.
-enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCircuit, kScratchTables, kScratchPtrs, kScratchPoints, kScratchCount };
+enum ScratchSlot { kScratchCoeffs = 0, kScratchLde, kScratchLevel0, kScratchPing, kScratchTmp, kScratchFri, kScratchPlonk, kScratchCircuit, kScratchTables, kScratchPtrs, kScratchPoints, kScratchPlan, kScratchCount };
 int scratch_get(int slot, size_t bytes, void** out);
 // the same, but never from a batch's per-proof arena: tables the host uploads once for all the proofs of a batch
 int scratch_get_shared(int slot, size_t bytes, void** out);
@@ -147,6 +147,22 @@ struct DevBuf {
     return static_cast<T*>(p);
   }
 };
+
+// p2mt_plan.hip: a whole perfect subtree of 2^H leaves in ONE launch (stage 1 and every level above it as dependency-ordered
+// workgroups of one grid).  Where the nodes go: kind 0 = MMR.elements (post-order; `base` = element 0, node indices are global),
+// kind 1 = MerkleTree.tree of an n-leaf tree (level-major; `base` = leaf digest 0, the root goes to `root`).
+struct TreeLayout {
+  int kind;
+  uint64_t* base;
+  uint64_t* root;
+  uint64_t n;
+};
+bool tree_plan_wanted(unsigned H);  // knobs (env P2MT_PLAN*, p2mt_debug_plan_knobs) and the Poseidon variant allow it for 2^H leaves
+// enqueue on rt().stream; d_leaves[0] is leaf `first_leaf` (a multiple of 2^H).  d_state: tree_plan_state_bytes(H) bytes of device
+// memory owned by the caller, or null for the calling thread's scratch; after the launch word 1 is non-zero if a hand-off poll gave up
+// (cannot happen with a valid plan; a caller that keeps the buffer reports P2MT_EHIP when the tree is next read)
+int tree_plan_state_bytes(unsigned H, size_t* bytes_out);
+int tree_plan_launch(const TreeLayout& lay, const uint64_t* d_leaves, size_t first_leaf, unsigned H, uint32_t* d_state);
 
 // launchers exported by p2mt_hash.hip to the other translation units (enqueue on rt().stream, device pointers)
 int launch_hash_rows_dev(const uint64_t* d_in, size_t n, size_t len, int noop_short, uint64_t* d_out);
