@@ -110,6 +110,16 @@ int p2mt_debug_field_op(int op, const uint64_t *a, const uint64_t *b, size_t n, 
  * bits, or one of the rare borrows of the flag-form arithmetic): its value is then unspecified -- the kernels redo such a hash with
  * the exact permutation. */
 int p2mt_debug_partial_group(int group, const uint64_t *states, size_t n, uint64_t *out, uint8_t *flag_out);
+/* The Poseidon permutation on a HOST core (csrc/host_poseidon.hip; product code: single proves and verifications keep their
+ * transcript -- a chain of dependent permutations -- there, as plonky2 keeps its Challenger): n states of 12 words, in -> out (may
+ * alias), canonical output.  No device involved. */
+int p2mt_host_poseidon_permute(const uint64_t *in, uint64_t *out, size_t n);
+/* Test hook: the host Challenger (plonky2 iop/challenger.rs: duplex sponge, inputs absorbed 8 at a time, outputs popped from the back).
+ * Phase k observes n_obs[k] elements (consecutive in `elements`), then squeezes n_sq[k] challenges (consecutive in `out`). */
+int p2mt_debug_host_challenger(const uint64_t *elements, const uint32_t *n_obs, const uint32_t *n_sq, size_t n_phases, uint64_t *out);
+/* Where single proves / verifications run their transcript: 1 = host core (default; env P2MT_HOST_TRANSCRIPT), 0 = device (what the
+ * batched passes always do).  Results are identical; the knob exists for A/B measurements and tests. */
+int p2mt_debug_host_transcript(int on);
 /* One-launch tree builds (csrc/p2mt_plan.hip: stage 1 and every level above it as dependency-ordered workgroups of one grid).
  * Knobs for measurement (a negative argument keeps the current value; the environment sets the defaults: P2MT_PLAN, P2MT_PLAN_MIN_LOG,
  * P2MT_PLAN_ORDER, P2MT_PLAN_TQ, P2MT_PLAN_TW): enabled 0/1; min_log: smallest subtree (log2 leaves) that takes the one-launch path;

@@ -43,6 +43,9 @@ SIGNATURES = {
     "p2mt_debug_fail_allocs": (C.c_int, [C.c_int]),
     "p2mt_debug_field_op": (C.c_int, [C.c_int, voidp, voidp, C.c_size_t, voidp, voidp]),
     "p2mt_debug_partial_group": (C.c_int, [C.c_int, voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_host_poseidon_permute": (C.c_int, [voidp, voidp, C.c_size_t]),
+    "p2mt_debug_host_transcript": (C.c_int, [C.c_int]),
+    "p2mt_debug_host_challenger": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp]),
     "p2mt_debug_plan_knobs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "p2mt_debug_plan_profile": (C.c_int, [C.c_int]),
     "p2mt_debug_plan_profile_read": (C.c_int64, [voidp, C.c_size_t]),

@@ -17,6 +17,7 @@
 #include "tree_common.hip.h"
 #include "circuit_types.h"
 #include "gates_recursion.hip.h"
+#include "host_poseidon.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -95,6 +96,8 @@ struct p2mt_circuit_data {
   u64* d_verify = nullptr;
   void* vstreams = nullptr;  // side streams + events of the staged verifier (p2mt_verify_dev.hip)
   const void* vconst_in[2] = {nullptr, nullptr};
+  u64* h_vpin = nullptr;  // pinned staging of the host-side verifier transcript: [pi hash 4 | FriOpenings order | challenges]
+  size_t h_vpin_words = 0;
   unsigned vconst_B[2] = {0, 0};  // the block (single / batch) that holds this circuit's digest and constants cap already
   // batched verifier (p2mt_circuit_verify_batch): one block of the same layout per proof, a challenger state behind each
   u64* d_trace = nullptr;  // debug (p2mt_debug_witness_trace): completion tick of every generator of the dataflow interpreter
@@ -1934,6 +1937,7 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (c->vch) p2mt_challenger_destroy(c->vch);
   if (c->d_verify) (void)hipFree(c->d_verify);
   if (c->vstreams) p2mt::verify_streams_destroy(c->vstreams);
+  if (c->h_vpin) (void)hipHostFree(c->h_vpin);
   if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->vbch) p2mt::challenger_unwrap(c->vbch);
   if (c->d_vbatch) (void)hipFree(c->d_vbatch);
@@ -2527,6 +2531,16 @@ VLayout verify_layout(const p2mt_circuit_data* c) {
   L.words = L.o_dig + 4 * L.max_items;
   return L;
 }
+// single verifications / proves keep their transcript on a host core (host_poseidon.h); env P2MT_HOST_TRANSCRIPT=0 or
+// p2mt_debug_host_transcript(0) puts it back on the device (A/B, and what the batched passes always do)
+int& host_transcript_flag() {
+  static int v = [] {
+    const char* e = getenv("P2MT_HOST_TRANSCRIPT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+bool host_transcript_on() { return host_transcript_flag() != 0; }
 constexpr int kFlagClear = 0x7F7F7F7F;  // "no failing Merkle path" (the kernel keeps the smallest failing item + 1)
 
 // One pass over B proofs (B = 1: dv is the circuit's own block and no batch context is active; B > 1: dv is block 0 of B blocks
@@ -2594,6 +2608,60 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   }
   P2MT_TRY(p2mt::batch_fill(d_flag, 0x7F, 16));  // flag word and result word: "nothing failed / nothing reported yet"
   P2MT_TRY(p2mt::verify_dev_begin(c->vstreams, dv, dv + L.o_dig, va));
+  if (B == 1 && live[0] && host_transcript_on()) {
+    // ONE verification: the transcript is a chain of ~100 dependent permutations of words the host already holds -- 6.9 us each on
+    // a lone wavefront, ~1.5 us on a host core (host_poseidon.h).  The host derives every challenge while the proof goes up and the
+    // row sponges run, sends them up in one small copy, and the three checks that need them run side by side.
+    namespace hp = host_poseidon;
+    const size_t n_fo = 2 * L.n_open, vwords = 4 + n_fo + L.n_out;
+    if (c->h_vpin_words < vwords) {
+      if (c->h_vpin) (void)hipHostFree(c->h_vpin);
+      c->h_vpin = nullptr, c->h_vpin_words = 0;
+      if (hipHostMalloc((void**)&c->h_vpin, vwords * 8, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return p2mt::fail(P2MT_ENOMEM, "hipHostMalloc(verify transcript) failed");
+      }
+      c->h_vpin_words = vwords;
+    }
+    u64* h_pi = c->h_vpin;
+    u64* h_fo = c->h_vpin + 4;
+    u64* h_out = h_fo + n_fo;
+    const uint64_t* pr = proofs;
+    {
+      u64 pi[4] = {0, 0, 0, 0};
+      if (c->n_pi) hp::hash_no_pad(pr + L.off_pi, c->n_pi, pi);
+      memcpy(h_pi, pi, 32);
+    }
+    {  // FriOpenings order from the proof's OpeningSet order (k_opening_unset)
+      const u32 a = 2 * (n_cs + kNumWires + kNumCh), tail = 2 * (kNumCh * kNumProds + kNumQuot), total = a + 2 * kNumCh + tail;
+      const uint64_t* set_order = pr + L.off_open;
+      for (u32 t = 0; t < total; ++t) {
+        const u32 dst = t < a ? t : (t < a + 2 * kNumCh ? a + tail + (t - a) : t - 2 * kNumCh);
+        h_fo[dst] = set_order[t];
+      }
+    }
+    hp::Challenger hc;
+    hc.observe(c->digest, 4);
+    hc.observe(h_pi, 4);
+    hc.observe(pr, 64);                          // wires cap
+    hc.squeeze(h_out, 2 * kNumCh);               // betas, gammas
+    hc.observe(pr + 64, 64);                     // Z / partial-products cap
+    hc.squeeze(h_out + 2 * kNumCh, kNumCh);      // alphas
+    hc.observe(pr + 128, 64);                    // quotient cap
+    hc.squeeze(h_out + 3 * kNumCh, 2);           // zeta
+    hc.observe(h_fo, n_fo);
+    hc.squeeze(h_out + 8, 2);                    // FRI alpha
+    for (u32 l = 0; l < nred; ++l) {
+      hc.observe(pr + L.off_fri + 64 * l, 64);
+      hc.squeeze(h_out + 10 + 2 * l, 2);         // FRI betas
+    }
+    hc.observe(pr + L.off_final, 2 * L.final_len + 1);
+    hc.squeeze(h_out + 26, 1);                   // PoW response
+    hc.squeeze(h_out + 27, nq);                  // query indices
+    P2MT_HIP(hipMemcpyAsync(dv + 4, h_pi, 32, hipMemcpyHostToDevice, st));
+    P2MT_HIP(hipMemcpyAsync(dv + L.o_fo, h_fo, (n_fo + L.n_out) * 8, hipMemcpyHostToDevice, st));
+    P2MT_TRY(p2mt::verify_dev_with_challenges(c->vstreams, dv, dv + L.o_dig, d_flag, d_res, c->d_kis, va));
+  } else {
   if (c->n_pi) P2MT_TRY(p2mt::launch_hash_rows_dev(dv + L.o_proof + L.off_pi, 1, c->n_pi, 0, dv + 4));
   else P2MT_TRY(p2mt::batch_fill(dv + 4, 0, 32));
   // the whole transcript depends only on the proof: enqueue it in one go
@@ -2611,6 +2679,7 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   P2MT_TRY(p2mt_challenger_duplex_dev(ch, dv + L.o_proof + L.off_final, 2 * L.final_len + 1, d_out + 26, 1));    // PoW response
   P2MT_TRY(p2mt_challenger_get_challenges_dev(ch, nq, d_out + 27));                                           // query indices
   P2MT_TRY(p2mt::verify_dev_finish(c->vstreams, dv, dv + L.o_items, dv + L.o_dig, d_flag, d_res, va));
+  }
   // results, gathered per proof in ONE copy: {Merkle flag, -} {openings ok, FRI} {proof-of-work response} -- three consecutive words
   // (k_verify_fri leaves a copy of the response next to its own result)
   struct Verdict {
@@ -2640,6 +2709,13 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   return P2MT_OK;
 }
 }  // namespace
+
+extern "C" int p2mt_debug_host_transcript(int on) {
+  return p2mt::abi_guard([&]() -> int {
+  host_transcript_flag() = on ? 1 : 0;
+  return P2MT_OK;
+  });
+}
 
 extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, size_t proof_len, int* accepted, int* reason) {
   return p2mt::abi_guard([&]() -> int {

@@ -609,3 +609,28 @@ int p2mt::verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const u
   P2MT_HIP(hipStreamWaitEvent(st, v->e_open, 0));
   return P2MT_OK;
 }
+
+// The host derived every challenge (host_poseidon.h) and sent them up on the library stream: the three checks that need them start
+// together -- the vanishing-polynomial check on its side stream, the path folds behind the row sponges on theirs, the FRI arithmetic
+// on the library stream, which then waits for both.  After this call one copy of {d_flag, d_res} tells the verdict.
+int p2mt::verify_dev_with_challenges(void* vs, const uint64_t* dv, const uint64_t* d_digests, int* d_flag, int* d_res,
+                                     const uint64_t* d_k_is, const VerifyDevArgs& a) {
+  VerifyStreams* v = static_cast<VerifyStreams*>(vs);
+  hipStream_t st = p2mt::rt().stream;
+  const unsigned nq = a.fri.num_query_rounds, n_items = nq * (4 + a.fri.num_reductions);
+  P2MT_HIP(hipEventRecord(v->e_zeta, st));  // "the challenges are on the device"
+  P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_zeta, 0));
+  hipLaunchKernelGGL(k_verify_openings, bgrid(1), dim3(kOpenBlock), 0, v->s_open, dv, d_res, d_k_is, a, barg());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipEventRecord(v->e_open, v->s_open));
+  P2MT_HIP(hipStreamWaitEvent(v->s_leaf, v->e_zeta, 0));  // (behind k_verify_leaf_digests on that stream)
+  hipLaunchKernelGGL(k_verify_paths, bgrid((n_items + kMerkleBlock / 64 - 1) / (kMerkleBlock / 64)), dim3(kMerkleBlock), 0, v->s_leaf, dv,
+                     a, d_digests, n_items, d_flag, barg(), p2mt::perm_ctx());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipEventRecord(v->e_leaf, v->s_leaf));
+  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, st, dv, d_res + 1, a, barg());
+  P2MT_LAUNCH_CHECK();
+  P2MT_HIP(hipStreamWaitEvent(st, v->e_open, 0));
+  P2MT_HIP(hipStreamWaitEvent(st, v->e_leaf, 0));
+  return P2MT_OK;
+}

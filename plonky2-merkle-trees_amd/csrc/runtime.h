@@ -226,6 +226,9 @@ int verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const Ve
 int verify_dev_after_zeta(void* vs, const uint64_t* dv, int* d_res, const uint64_t* d_k_is, const VerifyDevArgs& a);
 int verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const uint64_t* d_digests, int* d_flag, int* d_res,
                       const VerifyDevArgs& a);
+// the transcript was computed on the host and its challenges are on the device: everything behind them in one go
+int verify_dev_with_challenges(void* vs, const uint64_t* dv, const uint64_t* d_digests, int* d_flag, int* d_res,
+                               const uint64_t* d_k_is, const VerifyDevArgs& a);
 }  // namespace p2mt
 
 #define P2MT_HIP(x)                                                           \

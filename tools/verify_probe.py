@@ -31,10 +31,28 @@ pkg.synthetic.assign_mmr_proof(leaf_t, proof_ts, peak_ts, cd.prover_only.public_
 proof = cd.prove(pw)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 acc, reason = C.c_int(0), C.c_int(0)
-for _ in range(5):
-    Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
-assert acc.value == 1
+out = {"reps": reps}
+for name, on in (("verify_ms", 1), ("verify_ms_device_transcript", 0), ("verify_ms_again", 1)):
+    Nn.check(lib.p2mt_debug_host_transcript(on))
+    for _ in range(5):
+        Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
+    assert acc.value == 1
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
+    out[name] = (time.perf_counter() - t0) * 1e3 / reps
+    bad = proof.copy()
+    bad[200] ^= np.uint64(1)
+    Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(bad), bad.size, C.byref(acc), C.byref(reason)))
+    out[name + "_tampered"] = [acc.value, reason.value]
+Nn.check(lib.p2mt_debug_host_transcript(1))
+st = np.arange(12, dtype=np.uint64)
 t0 = time.perf_counter()
-for _ in range(reps):
-    Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
-print(json.dumps({"verify_ms": (time.perf_counter() - t0) * 1e3 / reps, "reps": reps}))
+for _ in range(2000):
+    Nn.check(lib.p2mt_host_poseidon_permute(Nn.ptr(st), Nn.ptr(st), 1))
+out["host_permutation_us_incl_ctypes"] = (time.perf_counter() - t0) * 1e6 / 2000
+big = np.tile(np.arange(12, dtype=np.uint64), 20000)
+t0 = time.perf_counter()
+Nn.check(lib.p2mt_host_poseidon_permute(Nn.ptr(big), Nn.ptr(big), 20000))
+out["host_permutation_us"] = (time.perf_counter() - t0) * 1e6 / 20000
+print(json.dumps(out))
