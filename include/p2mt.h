@@ -207,6 +207,16 @@ size_t p2mt_mmr_num_leaves(const p2mt_mmr *m);
 size_t p2mt_mmr_len(const p2mt_mmr *m);                 /* elements.len() = 2N - popcount(N) */
 const uint64_t *p2mt_mmr_elements_dev(const p2mt_mmr *m); /* device pointer to elements[0] */
 int p2mt_mmr_copy_elements(const p2mt_mmr *m, size_t first, size_t count, uint64_t *out /*[count][4]*/);
+/* Getting `elements` (1.07 GB at 2^24 leaves) to the host at the link's rate instead of a pageable copy's: page-locked host memory from
+ * the library (what a Rust caller wraps in a slice), an enqueue-only copy into it (complete after p2mt_sync()), and an extend that
+ * streams the elements it appends -- MMR.elements is append-only in post-order, so an extend of leaves [n0, n1) creates exactly
+ * elements [len(n0), len(n1)) -- to out[0 .. 4 * (len after - len before)) chunk by chunk (2^chunk_log leaves) on the copy engines
+ * while later chunks are still being hashed.  Enqueue only: the buffer is complete after p2mt_sync().  The caller keeps `out` alive
+ * and does not free it before that. */
+int p2mt_host_alloc_pinned(size_t bytes, void **out);
+int p2mt_host_free_pinned(void *p);
+int p2mt_mmr_copy_elements_async(const p2mt_mmr *m, size_t first, size_t count, uint64_t *out_pinned /*[count][4]*/);
+int p2mt_mmr_extend_dev_to_host(p2mt_mmr *m, const uint64_t *d_leaves, size_t k, unsigned chunk_log, uint64_t *out_pinned);
 /* MMR::get_peaks (:179-200).  P2MT_EINVAL on the empty MMR, P2MT_ERANGE for len >= 2^32 (Quirk Q6). */
 int p2mt_mmr_peaks(const p2mt_mmr *m, uint64_t *peaks_out /*[<=64][4]*/, int *n_peaks);
 /* MMR::bagging_the_peaks (:122-127): hash_or_noop over all peak elements (one peak => the peak). */

@@ -18,7 +18,7 @@ from .commit import MerkleCapTree, PolynomialBatch, coset_lde, fft, ifft
 from .distributed import ShardedMMR
 from .fri import Challenger, FriParams, eval_polys_ext, prove_openings
 from .plonk import all_wires_permutation_partial_products
-from .mmr import (MMR, MMR_proof, get_heights_bitmap_for_mmr_size, get_mmr_index, verify_proof_batch)
+from .mmr import (PinnedBuffer, MMR, MMR_proof, get_heights_bitmap_for_mmr_size, get_mmr_index, verify_proof_batch)
 
 GOLDILOCKS_FIELD_ORDER = 18446744069414584321  # src/mmr/common.rs:3
 

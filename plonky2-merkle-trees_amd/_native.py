@@ -82,6 +82,10 @@ SIGNATURES = {
     "p2mt_mmr_len": (C.c_size_t, [voidp]),
     "p2mt_mmr_elements_dev": (voidp, [voidp]),
     "p2mt_mmr_copy_elements": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_host_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(voidp)]),
+    "p2mt_host_free_pinned": (C.c_int, [voidp]),
+    "p2mt_mmr_copy_elements_async": (C.c_int, [voidp, C.c_size_t, C.c_size_t, voidp]),
+    "p2mt_mmr_extend_dev_to_host": (C.c_int, [voidp, voidp, C.c_size_t, C.c_uint, voidp]),
     "p2mt_mmr_save": (C.c_int, [voidp, C.c_char_p]),
     "p2mt_mmr_load": (C.c_int, [voidp, C.c_char_p]),
     "p2mt_mmr_peaks": (C.c_int, [voidp, voidp, intp]),

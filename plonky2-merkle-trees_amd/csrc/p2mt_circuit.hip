@@ -96,6 +96,7 @@ struct p2mt_circuit_data {
   u64* d_verify = nullptr;
   void* vstreams = nullptr;  // side streams + events of the staged verifier (p2mt_verify_dev.hip)
   const void* vconst_in[2] = {nullptr, nullptr};
+  p2mt::HostLink* link = nullptr;  // single proves with the transcript on the host: caps down, challenges up (runtime.h)
   u64* h_vpin = nullptr;  // pinned staging of the host-side verifier transcript: [pi hash 4 | FriOpenings order | challenges]
   size_t h_vpin_words = 0;
   unsigned vconst_B[2] = {0, 0};  // the block (single / batch) that holds this circuit's digest and constants cap already
@@ -1368,8 +1369,8 @@ __global__ __launch_bounds__(kBlock) void k_opening_unset(const u64* __restrict_
   out[dst] = set_order[t];
 }
 
-// one (query, tree) pair of a proof under verification: where its opened row, its path and its cap sit in the proof block (built and
-// consumed on the device: p2mt_verify_dev.hip k_verify_items / k_verify_paths; the layout below reserves their space)
+// one (query, tree) pair of a proof under verification: where its opened row, its path and its cap sit in the proof block.  (Reserved:
+// since round 4 every wavefront of k_verify_paths works its own triple out; the layout below still keeps the space, nothing writes it.)
 struct VItem {
   u32 leaf_off, width, index, sib_off, n_sib, cap_off;
 };
@@ -1938,6 +1939,7 @@ extern "C" int p2mt_circuit_destroy(p2mt_circuit_data* c) {
   if (c->d_verify) (void)hipFree(c->d_verify);
   if (c->vstreams) p2mt::verify_streams_destroy(c->vstreams);
   if (c->h_vpin) (void)hipHostFree(c->h_vpin);
+  p2mt::hostlink_destroy(c->link);
   if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->vbch) p2mt::challenger_unwrap(c->vbch);
   if (c->d_vbatch) (void)hipFree(c->d_vbatch);
@@ -2349,6 +2351,19 @@ extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_pa
   });
 }
 
+namespace {
+// single verifications / proves keep their transcript on a host core (host_poseidon.h); env P2MT_HOST_TRANSCRIPT=0 or
+// p2mt_debug_host_transcript(0) puts it back on the device (A/B, and what the batched passes always do)
+int& host_transcript_flag() {
+  static int v = [] {
+    const char* e = getenv("P2MT_HOST_TRANSCRIPT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+bool host_transcript_on() { return host_transcript_flag() != 0; }
+}  // namespace
+
 static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, unsigned B, uint64_t* proofs_out,
                       size_t proof_stride, int* status_out, int* gave_up);
 
@@ -2393,15 +2408,41 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* p
   else P2MT_TRY(p2mt::batch_fill(d_pi_hash, 0, 32));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_w_vals, 1, kNumWires, log_n, kRateBits, kCapHeight, c->d_w_coeffs, c->d_w_lde, c->d_w_leaves,
                                   c->n_digests ? c->d_w_dig : nullptr, d_w_cap));
-  // challenger: circuit digest, public-input hash, wires cap -> betas, gammas
-  P2MT_TRY(p2mt_challenger_restart_duplex_dev(c->ch, d_digest, 8 + 64, c->d_chal, 2 * kNumCh));
+  // challenger: circuit digest, public-input hash, wires cap -> betas, gammas.
+  // ONE proof: the transcript is a chain of ~100 dependent permutations (6.9 us each on a lone wavefront: 44 % of a prove) and plonky2
+  // keeps it on the host; so does this path (host_poseidon.h, ~1.4 us each): at every phase the cap comes down through the host link
+  // and the challenges go back up as kernel arguments.  A batch keeps the device transcript (one lane-parallel launch for all proofs).
+  const bool host_tr = B == 1 && host_transcript_on();
+  host_poseidon::Challenger hc;
+  const size_t n_open_words = 2 * (size_t)(n_cs + kNumWires + 2 * kNumCh + kNumCh * kNumProds + kNumQuot);
+  if (host_tr) {
+    if (!c->link) P2MT_TRY(p2mt::hostlink_create(&c->link, n_open_words + 256));
+    const uint64_t* h;
+    P2MT_TRY(p2mt::hostlink_fetch(c->link, d_pi_hash, 4 + 64, &h));  // [public-input hash | wires cap]: contiguous in the proof block
+    hc.observe(c->digest, 4);
+    hc.observe(h, 4 + 64);
+    u64 bg[2 * kNumCh];
+    hc.squeeze(bg, 2 * kNumCh);
+    P2MT_TRY(p2mt::hostlink_put(bg, 2 * kNumCh, c->d_chal));
+  } else {
+    P2MT_TRY(p2mt_challenger_restart_duplex_dev(c->ch, d_digest, 8 + 64, c->d_chal, 2 * kNumCh));
+  }
   // Z and partial products, committed with Z at the front
   P2MT_TRY(p2mt::partial_products_async_dev(c->d_w_vals, c->d_cs_vals + (size_t)(c->num_selectors + kNumConsts) * n, c->d_kis,
                                             c->d_chal, c->d_chal + kNumCh, kNumCh, kNumRouted, log_n, kQF, c->d_pp_q, c->d_z_vals,
                                             c->d_err + 1));
   P2MT_TRY(p2mt::commit_batch_dev(c->d_z_vals, 1, kNumZs, log_n, kRateBits, kCapHeight, c->d_z_coeffs, c->d_z_lde, c->d_z_leaves,
                                   c->n_digests ? c->d_z_dig : nullptr, d_z_cap));
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_z_cap, 64, c->d_chal + 2 * kNumCh, kNumCh));  // alphas
+  if (host_tr) {
+    const uint64_t* h;
+    P2MT_TRY(p2mt::hostlink_fetch(c->link, d_z_cap, 64, &h));
+    hc.observe(h, 64);
+    u64 al[kNumCh];
+    hc.squeeze(al, kNumCh);
+    P2MT_TRY(p2mt::hostlink_put(al, kNumCh, c->d_chal + 2 * kNumCh));
+  } else {
+    P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_z_cap, 64, c->d_chal + 2 * kNumCh, kNumCh));  // alphas
+  }
   // quotient polynomials
   QDesc qd{};
   qd.log_n = log_n;
@@ -2435,7 +2476,16 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* p
   // zeta stays on the device: the openings, the FRI quotients and plonky2's `ensure!(zeta^n != 1)` (a flag that comes back with
   // the proof) all read it there
   u64* d_zeta = c->d_chal + 3 * kNumCh;
-  P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_q_cap, 64, d_zeta, 2));
+  if (host_tr) {
+    const uint64_t* h;
+    P2MT_TRY(p2mt::hostlink_fetch(c->link, d_q_cap, 64, &h));
+    hc.observe(h, 64);
+    u64 z[2];
+    hc.squeeze(z, 2);
+    P2MT_TRY(p2mt::hostlink_put(z, 2, d_zeta));
+  } else {
+    P2MT_TRY(p2mt_challenger_duplex_dev(c->ch, d_q_cap, 64, d_zeta, 2));
+  }
   // openings at zeta (every polynomial) and g zeta (the Z's), observed; then the FRI proof
   p2mt_fri_oracle oracles[4] = {{c->d_cs_coeffs, c->d_cs_leaves, c->d_cs_dig, n_cs},
                                 {c->d_w_coeffs, c->d_w_leaves, c->d_w_dig, kNumWires},
@@ -2457,13 +2507,19 @@ static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* p
   pts.scale[0] = 1;
   pts.scale[1] = h_root_of_unity(log_n);
   P2MT_TRY(p2mt::fri_openings_points_dev(oracles, 4, batches, 2, pts, log_n, c->d_open));
-  P2MT_TRY(p2mt_challenger_observe_dev(c->ch, c->d_open, 2 * n_open));
+  if (!host_tr) P2MT_TRY(p2mt_challenger_observe_dev(c->ch, c->d_open, 2 * n_open));
   hipLaunchKernelGGL(k_opening_set, bgrid(grid_for(2 * n_open)), dim3(kBlock), 0, st, (const u64*)c->d_open, d_open_set, n_cs,
                      (const u64*)d_zeta, log_n, c->d_err, barg());
   P2MT_LAUNCH_CHECK();
   // the proofs (with the error flags right behind them) ride back on the FRI prover's own final synchronisation
+  if (host_tr) {  // (behind k_opening_set, which is queued already: the openings come down while it runs)
+    const uint64_t* h;
+    P2MT_TRY(p2mt::hostlink_fetch(c->link, c->d_open, 2 * n_open, &h));
+    hc.observe(h, 2 * n_open);
+  }
   P2MT_TRY(p2mt::fri_prove_openings_epilogue_dev(oracles, 4, batches, 2, pts, &c->fri, c->ch, d_fri, c->h_pin + 8, d_proof,
-                                                 (c->proof_len + 2) * 8, c->pin_pitch * 8));
+                                                 (c->proof_len + 2) * 8, c->pin_pitch * 8, host_tr ? &hc : nullptr,
+                                                 host_tr ? c->link : nullptr));
   int rc = P2MT_OK;
   for (unsigned bi = 0; bi < B; ++bi) {
     const u64* h = c->h_pin + (size_t)bi * c->pin_pitch + 8;
@@ -2531,16 +2587,6 @@ VLayout verify_layout(const p2mt_circuit_data* c) {
   L.words = L.o_dig + 4 * L.max_items;
   return L;
 }
-// single verifications / proves keep their transcript on a host core (host_poseidon.h); env P2MT_HOST_TRANSCRIPT=0 or
-// p2mt_debug_host_transcript(0) puts it back on the device (A/B, and what the batched passes always do)
-int& host_transcript_flag() {
-  static int v = [] {
-    const char* e = getenv("P2MT_HOST_TRANSCRIPT");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-bool host_transcript_on() { return host_transcript_flag() != 0; }
 constexpr int kFlagClear = 0x7F7F7F7F;  // "no failing Merkle path" (the kernel keeps the smallest failing item + 1)
 
 // One pass over B proofs (B = 1: dv is the circuit's own block and no batch context is active; B > 1: dv is block 0 of B blocks
@@ -2608,6 +2654,15 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   }
   P2MT_TRY(p2mt::batch_fill(d_flag, 0x7F, 16));  // flag word and result word: "nothing failed / nothing reported yet"
   P2MT_TRY(p2mt::verify_dev_begin(c->vstreams, dv, dv + L.o_dig, va));
+  // from here on kernels are in flight on the side streams: whatever fails below, they are joined before this function returns, so
+  // that the next pass on this block does not refill the flag words or the proof under them
+  struct JoinSideStreams {
+    void* vs;
+    bool armed = true;
+    ~JoinSideStreams() {
+      if (armed) p2mt::verify_streams_join(vs);
+    }
+  } join{c->vstreams};
   if (B == 1 && live[0] && host_transcript_on()) {
     // ONE verification: the transcript is a chain of ~100 dependent permutations of words the host already holds -- 6.9 us each on
     // a lone wavefront, ~1.5 us on a host core (host_poseidon.h).  The host derives every challenge while the proof goes up and the
@@ -2691,6 +2746,7 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
   if (B > 1) P2MT_HIP(hipMemcpy2DAsync(vr.data(), 24, dv + L.o_flag, stride, 24, B, hipMemcpyDeviceToHost, st));
   else P2MT_HIP(hipMemcpyAsync(vr.data(), dv + L.o_flag, 24, hipMemcpyDeviceToHost, st));
   P2MT_HIP(hipStreamSynchronize(st));
+  join.armed = false;  // the library stream waited for both side streams before the verdict copy
   for (unsigned b = 0; b < B; ++b) {
     if (!live[b]) continue;  // reason 10
     if (vr[b].ok != 1) {
@@ -2736,8 +2792,8 @@ extern "C" int p2mt_circuit_verify(p2mt_circuit_data* c, const uint64_t* proof, 
 }
 
 // circuit_data.verify for n proofs of this circuit, proofs[i] at proofs + i * proof_stride words: passes of up to 256 proofs with
-// the proof index in a grid dimension of every launch (one transcript replay and one Merkle-path launch per pass), the field
-// arithmetic of each proof on a few host threads.  accepted[i] / reason[i] as p2mt_circuit_verify.
+// the proof index in a grid dimension of every launch (one transcript replay, one row-sponge, one openings-check, one FRI and one
+// Merkle-path launch per pass: transcript and field arithmetic on the device).  accepted[i] / reason[i] as p2mt_circuit_verify.
 extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* proofs, size_t n, size_t proof_stride, int* accepted,
                                          int* reason) {
   return p2mt::abi_guard([&]() -> int {
@@ -2751,6 +2807,10 @@ extern "C" int p2mt_circuit_verify_batch(p2mt_circuit_data* c, const uint64_t* p
   const size_t want = std::min(n, kMaxPass);
   const size_t stride = ((L.words * 8 + p2mt::kChallengerStateBytes + 8) + 255) & ~(size_t)255;
   if (c->vbatch_cap < want) {
+    // (the upload-once cache of the circuit's own words is keyed on the block pointer: forget both slots -- a one-proof pass runs on
+    // this block under slot 0, and hipMalloc may hand the same address out again)
+    c->vconst_in[0] = c->vconst_in[1] = nullptr;
+    c->vconst_B[0] = c->vconst_B[1] = 0;
     if (c->d_vbatch) {
       (void)hipStreamSynchronize(rt().stream);
       (void)hipFree(c->d_vbatch);

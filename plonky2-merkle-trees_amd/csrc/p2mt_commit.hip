@@ -252,11 +252,14 @@ __global__ __launch_bounds__(kBlock) void k_ifft_coset_lde_wave64(const u64* __r
 // transform's ~100.
 __global__ __launch_bounds__(kBlock) void k_coset_scale_rows(const u64* __restrict__ coeffs, unsigned log_n, unsigned rate_bits, u64 shift,
                                                              u64 w_big, u64* __restrict__ out) {
-  const size_t m = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  const unsigned row = blockIdx.y, poly = row >> rate_bits, c = row & ((1u << rate_bits) - 1), j = brev32(c, rate_bits);
+  // (the row rides in grid.x, which goes to 2^31 - 1: grid.y stops at 65 535 and 8192 polynomials x 8 cosets are more rows than that)
+  const unsigned bpr = (unsigned)((((size_t)1 << log_n) + kBlock - 1) / kBlock);  // blocks per row
+  const unsigned row = blockIdx.x / bpr, blk = blockIdx.x % bpr;
+  const size_t m = (size_t)blk * kBlock + threadIdx.x;
+  const unsigned poly = row >> rate_bits, c = row & ((1u << rate_bits) - 1), j = brev32(c, rate_bits);
   if (m >= ((size_t)1 << log_n)) return;
   const u64 base = gl::mul(shift, gl::pow(w_big, j));
-  const u64 pw = gl::mul(gl::pow(base, (u64)blockIdx.x * kBlock), gl::pow(base, threadIdx.x));
+  const u64 pw = gl::mul(gl::pow(base, (u64)blk * kBlock), gl::pow(base, threadIdx.x));
   out[((size_t)row << log_n) + m] = cmul(coeffs[((size_t)poly << log_n) + m], pw);
 }
 
@@ -1251,9 +1254,9 @@ int p2mt::coset_lde_leaf_order_dev(const u64* d_coeffs, unsigned log_n, unsigned
     if (p2mt::batch_B() != 1) return p2mt::fail(P2MT_EINVAL, "coset_lde: log_n > 12 inside a batched pass");
     const u64 w_big = h_root_of_unity(log_n + rate_bits);
     const size_t rows = n_polys << rate_bits;
-    if (rows >= ((size_t)1 << 31)) return p2mt::fail(P2MT_EINVAL, "coset_lde: too many rows");
+    if (rows * grid_for((size_t)1 << log_n) >= ((size_t)1 << 31)) return p2mt::fail(P2MT_EINVAL, "coset_lde: too many rows for one launch");
     const int slot = p2mt::prof_begin();
-    hipLaunchKernelGGL(k_coset_scale_rows, dim3(grid_for((size_t)1 << log_n), (unsigned)rows), dim3(kBlock), 0, rt().stream, d_coeffs, log_n,
+    hipLaunchKernelGGL(k_coset_scale_rows, dim3((unsigned)(rows * grid_for((size_t)1 << log_n))), dim3(kBlock), 0, rt().stream, d_coeffs, log_n,
                        rate_bits, shift % gl::P, w_big, d_out);
     p2mt::prof_end(slot);
     P2MT_LAUNCH_CHECK();

@@ -19,6 +19,7 @@
 // HBM layout: extension polynomials are two base-field arrays (component-major) while they are transformed, and
 // (a, b) pairs once they become Merkle leaves / proof words.
 #include "tree_common.hip.h"
+#include "host_poseidon.h"
 
 #include <string.h>
 
@@ -1025,7 +1026,7 @@ extern "C" int p2mt_fri_prove_openings_dev(const p2mt_fri_oracle* oracles, size_
 int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                           size_t n_batches, const FriPointsDev& pts, const p2mt_fri_params* p,
                                           p2mt_challenger* ch, uint64_t* d_proof, void* epi_dst, const void* epi_src,
-                                          size_t epi_bytes, size_t epi_dpitch) {
+                                          size_t epi_bytes, size_t epi_dpitch, host_poseidon::Challenger* hch, HostLink* link) {
   P2MT_TRY(p2mt::ensure_init());
   if (!oracles || !batches || !ch || !d_proof || n_oracles == 0 || n_batches == 0) return p2mt::fail(P2MT_EINVAL, "fri: null argument");
   if (n_batches > (size_t)kMaxFriBatches) return p2mt::fail(P2MT_EINVAL, "fri: too many batches");
@@ -1084,7 +1085,15 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
   const unsigned B = p2mt::batch_B();
 
   // ---- alpha, composition, quotients
-  P2MT_TRY(launch_challenger(ch->d, nullptr, 0, ws + o_alpha, 2));
+  const bool host_tr = hch != nullptr && link != nullptr;
+  if (host_tr && B != 1) return p2mt::fail(P2MT_EINVAL, "fri: the host transcript serves single proofs only");
+  if (host_tr) {
+    u64 a[2];
+    hch->squeeze(a, 2);
+    P2MT_TRY(p2mt::hostlink_put(a, 2, ws + o_alpha));
+  } else {
+    P2MT_TRY(launch_challenger(ch->d, nullptr, 0, ws + o_alpha, 2));
+  }
   hipLaunchKernelGGL(k_ext_powers, bgrid(grid_for(max_cnt + 1)), dim3(kBlock), 0, st, (const u64*)(ws + o_alpha),
                      (u32)max_cnt + 1, ws + o_apow, barg());
   P2MT_LAUNCH_CHECK();
@@ -1144,7 +1153,16 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     hipLaunchKernelGGL(k_fri_pairs, bgrid(grid_for(sz)), dim3(kBlock), 0, st, (const u64*)vals, (u32)sz, leaves, barg());
     P2MT_LAUNCH_CHECK();
     P2MT_TRY(p2mt_merkle_cap_commit_dev(leaves, rows, (size_t)2 << ab, p->cap_height, dig, d_proof + l * cap_words));
-    P2MT_TRY(launch_challenger(ch->d, d_proof + l * cap_words, cap_words, ws + o_betas + 2 * l, 2));
+    if (host_tr) {
+      const uint64_t* h_cap;
+      P2MT_TRY(p2mt::hostlink_fetch(link, d_proof + l * cap_words, cap_words, &h_cap));
+      hch->observe(h_cap, cap_words);
+      u64 b2[2];
+      hch->squeeze(b2, 2);
+      P2MT_TRY(p2mt::hostlink_put(b2, 2, ws + o_betas + 2 * l));
+    } else {
+      P2MT_TRY(launch_challenger(ch->d, d_proof + l * cap_words, cap_words, ws + o_betas + 2 * l, 2));
+    }
     hipLaunchKernelGGL(k_fri_fold, bgrid(grid_for((size_t)1 << (log_deg - ab))), dim3(kBlock), 0, st, (const u64*)cur, 1u << log_deg,
                        ab, (const u64*)(ws + o_betas + 2 * l), nxt, barg());
     P2MT_LAUNCH_CHECK();
@@ -1160,8 +1178,21 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
                      d_proof + off_final, barg());
   P2MT_LAUNCH_CHECK();
   // (the same launch keeps a copy of the transcript for the proof-of-work rollback and marks "no witness yet")
+  if (host_tr) {
+    const uint64_t* h_fin;
+    P2MT_TRY(p2mt::hostlink_fetch(link, d_proof + off_final, 2 * final_len, &h_fin));
+    hch->observe(h_fin, 2 * final_len);
+    // the grind kernels read the transcript's state from the device: send it up (29 words), and mark "no witness yet"
+    static_assert(sizeof(host_poseidon::Challenger) == sizeof(ChState), "host and device transcript states share one layout");
+    u64 stw[30];
+    memcpy(stw, hch, sizeof(ChState));
+    stw[29] = ~0ull;
+    P2MT_TRY(p2mt::hostlink_put(stw, 29, reinterpret_cast<u64*>(ch->d)));
+    P2MT_TRY(p2mt::hostlink_put(stw + 29, 1, d_proof + total - 1));
+  } else {
   P2MT_TRY(launch_challenger(ch->d, d_proof + off_final, 2 * final_len, nullptr, 0, false,
                              reinterpret_cast<ChState*>(ws + o_chsave), reinterpret_cast<unsigned long long*>(d_proof + total - 1)));
+  }
 
   // ---- fri_proof_of_work (smallest witness, searched in chunks) + fri_prover_query_rounds.
   // The rest of the proof is enqueued behind each chunk's grind on the assumption that it finds a witness (it does with
@@ -1239,6 +1270,32 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
       P2MT_TRY(tail());
       if (epi_dst && epi_bytes)
         P2MT_HIP(hipMemcpy2DAsync(epi_dst, epi_dpitch, epi_src, p2mt::batch().arg.stride, epi_bytes, B, hipMemcpyDeviceToHost, st));
+      P2MT_HIP(hipStreamSynchronize(st));
+      return P2MT_OK;
+    }
+    if (host_tr) {
+      // the host waits for the witness (one word through the link), observes it, derives the proof-of-work response and the query
+      // indices and sends them up in front of the query rounds; a chunk without a witness (probability e^-2) just grinds the next one
+      for (u64 base = 0;; base += chunk) {
+        if (base >= ((u64)1 << 48)) return p2mt::fail(P2MT_EHIP, "fri: proof-of-work search exhausted");
+        P2MT_TRY(grind(base));
+        const uint64_t* h_wit;
+        P2MT_TRY(p2mt::hostlink_fetch(link, d_proof + total - 1, 1, &h_wit));
+        if (h_wit[0] == ~0ull) continue;
+        hch->observe(h_wit[0]);
+        u64 q[32];
+        const size_t nq1 = 1 + p->num_query_rounds;
+        if (nq1 > 32) return p2mt::fail(P2MT_EINVAL, "fri: more than 31 query rounds");
+        hch->squeeze(q, nq1);
+        P2MT_TRY(p2mt::hostlink_put(q, nq1, ws + o_qch));
+        if (p->num_query_rounds) {
+          hipLaunchKernelGGL(k_fri_queries, bgrid(p->num_query_rounds), dim3(kBlock), 0, st, qa, (const u64*)(ws + o_qch + 1),
+                             d_proof + p->num_reductions * cap_words, barg());
+          P2MT_LAUNCH_CHECK();
+        }
+        break;
+      }
+      if (epi_dst && epi_bytes) P2MT_HIP(hipMemcpyAsync(epi_dst, epi_src, epi_bytes, hipMemcpyDeviceToHost, st));
       P2MT_HIP(hipStreamSynchronize(st));
       return P2MT_OK;
     }

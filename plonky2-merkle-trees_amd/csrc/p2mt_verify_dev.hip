@@ -534,7 +534,16 @@ struct VerifyStreams {
 };
 bool args_ok(const VerifyDevArgs& a) {
   const unsigned chunks = (a.d.num_routed + a.d.quotient_degree_factor - 1) / a.d.quotient_degree_factor;
-  return a.d.num_challenges <= 2 && a.d.num_wires <= p2mt_cb::kNumWires && a.d.n_kinds <= p2mt_cb::kMaxGateTypes &&
+  // fail closed on everything the kernels hard-code (none of it reachable with standard_recursion_config): k_verify_fri runs 16 lanes
+  // per query and shifts by 4 - arity_bits; cap strides are 64 words (cap height 4); the final polynomial and the query list are
+  // indexed from length - 1; k_verify_openings gives the gate kinds from BaseSum on one wave each, waves 3..15
+  if (a.fri.num_query_rounds == 0 || a.final_len == 0 || a.fri.cap_height != 4 || a.fri.num_reductions > 8) return false;
+  for (uint32_t l = 0; l < a.fri.num_reductions; ++l)
+    if (a.fri.reduction_arity_bits[l] == 0 || a.fri.reduction_arity_bits[l] > 4) return false;
+  unsigned wide_kinds = 0;
+  for (uint32_t g = 0; g < a.d.n_kinds && g < 16; ++g) wide_kinds += a.d.kind[g] >= p2mt_cb::G_BASE_SUM;
+  if (wide_kinds > 13) return false;
+  return a.d.num_challenges <= 2 && a.d.num_wires <= p2mt_cb::kNumWires && a.d.n_kinds <= p2mt_cb::kMaxGateTypes && a.d.n_kinds <= 16 &&
          a.d.num_challenges * chunks <= 32 && a.d.num_challenges * (1 + chunks) + p2mt_cb::kNumGateConstraints <= kMaxTerms;
 }
 }  // namespace
@@ -559,6 +568,14 @@ void p2mt::verify_streams_destroy(void* p) {
   for (hipEvent_t e : {v->e_proof, v->e_zeta, v->e_leaf, v->e_open})
     if (e) (void)hipEventDestroy(e);
   delete v;
+}
+
+// wait (host) for whatever is in flight on the side streams: error paths of the caller
+void p2mt::verify_streams_join(void* p) {
+  VerifyStreams* v = static_cast<VerifyStreams*>(p);
+  if (!v) return;
+  (void)hipStreamSynchronize(v->s_leaf);
+  (void)hipStreamSynchronize(v->s_open);
 }
 
 // (1) the proof is on the device: the row sponges start on their own stream

@@ -11,6 +11,10 @@
 
 #include "../../include/p2mt.h"
 
+namespace host_poseidon {
+struct Challenger;
+}
+
 namespace p2mt {
 
 // What every hashing kernel needs besides its data: the round-constant table in global memory (wide scalar
@@ -148,6 +152,19 @@ struct DevBuf {
   }
 };
 
+// Host link (runtime.hip): what a single prove's host-side transcript (host_poseidon.h) talks to the device through.  fetch: a small
+// kernel behind the producer copies `n` words into mapped pinned host memory and raises a sequence word at system scope; the host spins
+// on that word (no hipStreamSynchronize: ~2-3 us from the producer's last store instead of ~20).  put: up to 32 words travel as kernel
+// arguments and a one-wave kernel stores them where the consumers read (no staging copy, ~5 us from enqueue to visible).
+struct HostLink;
+int hostlink_create(HostLink** out, size_t max_words);
+void hostlink_destroy(HostLink* l);
+// enqueue the copy of d_src[0..n) on rt().stream and wait for it; *h_out points into the link's buffer (valid until the next fetch)
+int hostlink_fetch(HostLink* l, const uint64_t* d_src, size_t n, const uint64_t** h_out);
+// two sources in one go (n0 + n1 <= max_words); *h_out = [src0 words | src1 words]
+int hostlink_fetch2(HostLink* l, const uint64_t* d_src0, size_t n0, const uint64_t* d_src1, size_t n1, const uint64_t** h_out);
+int hostlink_put(const uint64_t* vals, size_t n, uint64_t* d_dst);  // n <= 32
+
 // p2mt_plan.hip: a whole perfect subtree of 2^H leaves in ONE launch (stage 1 and every level above it as dependency-ordered
 // workgroups of one grid).  Where the nodes go: kind 0 = MMR.elements (post-order; `base` = element 0, node indices are global),
 // kind 1 = MerkleTree.tree of an n-leaf tree (level-major; `base` = leaf digest 0, the root goes to `root`).
@@ -199,9 +216,13 @@ int fri_openings_points_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, co
                             const FriPointsDev& pts, unsigned degree_bits, uint64_t* d_out);
 // p2mt_fri_prove_openings_dev + one device-to-host copy that rides on its final synchronisation.  Inside a batch (runtime.h
 // BatchCtx) epi_dst / epi_src are per-proof with the pitches epi_dpitch (host) and the batch stride (device).
+// hch / link (both or neither; single proofs only): the transcript runs on the host (host_poseidon.h) -- caps, the final polynomial
+// and the proof-of-work witness come down through the link, challenges go up as kernel arguments; `ch` then only lends its device
+// state to the grind kernels.
 int fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t n_oracles, const p2mt_fri_batch* batches,
                                     size_t n_batches, const FriPointsDev& pts, const p2mt_fri_params* p, p2mt_challenger* ch,
-                                    uint64_t* d_proof, void* epi_dst, const void* epi_src, size_t epi_bytes, size_t epi_dpitch);
+                                    uint64_t* d_proof, void* epi_dst, const void* epi_src, size_t epi_bytes, size_t epi_dpitch,
+                                    host_poseidon::Challenger* hch = nullptr, HostLink* link = nullptr);
 // a challenger over caller-owned device state (the batched prover keeps one state per proof block)
 int challenger_wrap(void* d_state, p2mt_challenger** out);
 void challenger_unwrap(p2mt_challenger* c);
@@ -222,6 +243,7 @@ struct VerifyDevArgs {
 // staged behind the transcript (see p2mt_verify_dev.hip): begin after the proof upload, after_zeta once zeta is squeezed, finish at the end
 int verify_streams_create(void** out);
 void verify_streams_destroy(void* vs);
+void verify_streams_join(void* vs);  // host wait for both side streams (error paths)
 int verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const VerifyDevArgs& a);
 int verify_dev_after_zeta(void* vs, const uint64_t* dv, int* d_res, const uint64_t* d_k_is, const VerifyDevArgs& a);
 int verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const uint64_t* d_digests, int* d_flag, int* d_res,

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <thread>
@@ -580,3 +581,84 @@ extern "C" int p2mt_timer_stop(float* elapsed_ms) {
   return P2MT_OK;
   });
 }
+
+// ---------------------------------------------------------------------------------------------------- host link (runtime.h)
+namespace p2mt {
+struct HostLink {
+  uint64_t* h_buf = nullptr;  // mapped pinned, coherent: [max_words data | sequence word]
+  size_t max_words = 0;
+  uint32_t seq = 0;
+};
+namespace {
+typedef __attribute__((address_space(1))) uint32_t hl_gu32;
+__global__ __launch_bounds__(256) void k_hostlink_publish(const uint64_t* __restrict__ src0, uint32_t n0, const uint64_t* __restrict__ src1,
+                                                          uint32_t n1, uint64_t* __restrict__ h_dst, uint32_t* __restrict__ h_seq, uint32_t seq) {
+  for (uint32_t k = threadIdx.x; k < n0 + n1; k += 256) h_dst[k] = k < n0 ? src0[k] : src1[k - n0];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct PutVals {
+  uint64_t v[32];
+};
+__global__ __launch_bounds__(64) void k_hostlink_put(PutVals pv, uint32_t n, uint64_t* __restrict__ dst) {
+  if (threadIdx.x < n) dst[threadIdx.x] = pv.v[threadIdx.x];
+}
+}  // namespace
+
+int hostlink_create(HostLink** out, size_t max_words) {
+  HostLink* l = new (std::nothrow) HostLink();
+  if (!l) return fail(P2MT_ENOMEM, "host link: out of host memory");
+  if (hipHostMalloc((void**)&l->h_buf, (max_words + 2) * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    delete l;
+    return fail(P2MT_ENOMEM, "host link: hipHostMalloc failed");
+  }
+  memset(l->h_buf, 0, (max_words + 2) * 8);
+  l->max_words = max_words;
+  *out = l;
+  return P2MT_OK;
+}
+void hostlink_destroy(HostLink* l) {
+  if (!l) return;
+  if (l->h_buf) (void)hipHostFree(l->h_buf);
+  delete l;
+}
+int hostlink_fetch2(HostLink* l, const uint64_t* d_src0, size_t n0, const uint64_t* d_src1, size_t n1, const uint64_t** h_out) {
+  if (!l || n0 + n1 > l->max_words) return fail(P2MT_EINVAL, "host link: fetch larger than the link's buffer");
+  const uint32_t seq = ++l->seq;
+  uint32_t* h_seq = reinterpret_cast<uint32_t*>(l->h_buf + l->max_words);
+  hipLaunchKernelGGL(k_hostlink_publish, dim3(1), dim3(256), 0, rt().stream, d_src0, (uint32_t)n0, d_src1, (uint32_t)n1, l->h_buf, h_seq, seq);
+  P2MT_LAUNCH_CHECK();
+  // spin on the sequence word; every ~50 us ask the runtime whether the stream died (a failed launch would never raise it)
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) == seq) break;
+    __builtin_ia32_pause();
+    if ((spins & 0xFFFF) == 0xFFFF) {
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) > 20) return fail(P2MT_EHIP, "host link: the device never delivered (20 s)");
+      const hipError_t e = hipStreamQuery(rt().stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery(host link)", __FILE__, __LINE__);
+      if (e == hipSuccess && __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq)
+        return fail(P2MT_EHIP, "host link: the stream drained without delivering");
+    }
+  }
+  *h_out = l->h_buf;
+  return P2MT_OK;
+}
+int hostlink_fetch(HostLink* l, const uint64_t* d_src, size_t n, const uint64_t** h_out) {
+  return hostlink_fetch2(l, d_src, n, nullptr, 0, h_out);
+}
+int hostlink_put(const uint64_t* vals, size_t n, uint64_t* d_dst) {
+  if (n > 32 || !d_dst) return fail(P2MT_EINVAL, "host link: put of more than 32 words");
+  if (n == 0) return P2MT_OK;
+  PutVals pv;
+  memcpy(pv.v, vals, n * 8);
+  hipLaunchKernelGGL(k_hostlink_put, dim3(1), dim3(64), 0, rt().stream, pv, (uint32_t)n, d_dst);
+  P2MT_LAUNCH_CHECK();
+  return P2MT_OK;
+}
+}  // namespace p2mt

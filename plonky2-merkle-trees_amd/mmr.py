@@ -137,6 +137,15 @@ class MMR:
         N.check(N.lib().p2mt_mmr_copy_elements(self._h, first, count, N.ptr(out)))
         return out
 
+    def copy_elements_async(self, first, count, pinned):
+        """enqueue-only copy of elements [first, first + count) into a PinnedBuffer; complete after sync()"""
+        N.check(N.lib().p2mt_mmr_copy_elements_async(self._h, first, count, pinned.ptr))
+
+    def extend_dev_to_host(self, d_leaves, k, pinned, chunk_log=22):
+        """extend from device-resident leaves while streaming the appended elements into a PinnedBuffer (chunks of 2^chunk_log
+        leaves: the copy of one chunk overlaps the hashing of the next); complete after sync()"""
+        N.check(N.lib().p2mt_mmr_extend_dev_to_host(self._h, N.ptr(d_leaves), k, chunk_log, pinned.ptr))
+
     def save(self, path):
         """checkpoint: header + `elements` as LE u64x4 records (post-order)"""
         N.check(N.lib().p2mt_mmr_save(self._h, os.fsencode(path)))
@@ -161,6 +170,29 @@ class MMR:
             if self._h:
                 N.lib().p2mt_mmr_destroy(self._h)
                 self._h = None
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """page-locked host memory from the library (p2mt_host_alloc_pinned) viewed as a numpy array of u64"""
+
+    def __init__(self, n_words):
+        p = C.c_void_p()
+        N.check(N.lib().p2mt_host_alloc_pinned(n_words * 8, C.byref(p)))
+        self.ptr = p
+        self.n_words = n_words
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n_words,))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            N.check(N.lib().p2mt_host_free_pinned(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass
 

@@ -320,7 +320,7 @@ def test_mfma_mds_variant(pkg, oracle):
 def test_mfma32_default_and_valu_forms(pkg, oracle, variant):
     """The default of the fast path puts every 12-row dense MDS layer on ONE v_mfma_i32_32x32x32_i8 per 8-bit limb (block-structured A
     operand, one hash per lane, no cross-lane movement: poseidon_fast::mds_layer_mfma32) and multiplies in four mads with the
-    carry folded into the reduction, and runs the 22 partial rounds as four groups of four and two of three with one MDS application
+    carry folded into the reduction, and runs the 22 partial rounds as five groups of four and one of three with one MDS application
     each; variant (2, 5) keeps the MDS on the VALU, (2, 6) additionally the previous multiply, (2, 7) is the default with the partial
     rounds in groups of three, (2, 8) the default with the flag-form folds in its MDS layers.  All five are the same function: every node equals the oracle's on a ragged size (partial waves: an MFMA ignores EXEC, so the
     kernels keep every lane in the permutation and only predicate the stores), on limb patterns that stress the signed-byte
