@@ -169,8 +169,37 @@ def transfer_times(torch, host_leaves, mmr):
     got = mmr.copy_elements(0, count)
     d2h = (time.perf_counter() - t0) * 1e3
     assert got.shape == out.shape
+    # the same bytes into page-locked memory of the library, and the extend that streams what it appends while it hashes
+    # (p2mt_mmr_extend_dev_to_host: chunks of 2^20 leaves, copies on the copy engines): a whole build WITH the node array on the host
+    import hashlib
+    pkg = ge.load_package()
+    Nn, lib = pkg._native, pkg._native.lib()
+    pin = pkg.mmr.PinnedBuffer(4 * count)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mmr.copy_elements_async(0, count, pin)
+    Nn.check(lib.p2mt_sync())
+    d2h_pinned = (time.perf_counter() - t0) * 1e3
+    want = hashlib.sha256(got.tobytes()).hexdigest()
+    assert hashlib.sha256(pin.array.tobytes()).hexdigest() == want
+    d3 = torch.from_numpy(host_leaves.view(np.int64)).cuda()
+    m2 = pkg.mmr.MMR()
+    m2.reserve(n)
+    over = []
+    for _ in range(3):
+        pin.array[:8] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m2.reset()
+        m2.extend_dev_to_host(d3, n, pin, chunk_log=min(20, n.bit_length() - 1))
+        Nn.check(lib.p2mt_sync())
+        over.append((time.perf_counter() - t0) * 1e3)
+    assert hashlib.sha256(pin.array.tobytes()).hexdigest() == want
+    del m2, d3
+    pin.free()
     return {"h2d_ms_leaves_pinned": h2d_pinned, "h2d_ms_leaves_pageable": h2d_pageable, "leaves_bytes": int(n * 8),
-            "d2h_ms_elements_pageable": d2h, "elements_bytes": int(count * 32),
+            "d2h_ms_elements_pageable": d2h, "d2h_ms_elements_pinned": d2h_pinned,
+            "build_plus_elements_on_host_overlapped_ms": float(np.median(over)), "elements_bytes": int(count * 32),
             "note": "not part of `value`: leaves are resident in HBM when the timed region starts and only the root comes back; "
                     "D2H includes allocating and faulting in the destination (what MMR.elements costs a caller)"}
 

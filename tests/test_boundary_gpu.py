@@ -312,3 +312,34 @@ def test_bench_rccl_exchange_one_rank(pkg, oracle):
     leaves = pkg.synthetic.bench_leaves(16, 0)
     assert [int(x) for x in oracle.mmr(leaves).bagging_the_peaks()] == out["root"]
     assert out["config"]["exchange"].startswith("device")
+
+
+def test_elements_to_pinned_host_memory(pkg, oracle):
+    """p2mt_mmr_copy_elements_async and p2mt_mmr_extend_dev_to_host (the extend that streams the elements it appends, chunk by chunk,
+    while later chunks hash): on an empty and on a non-empty MMR, ragged sizes, chunk sizes that do and do not divide the extend --
+    every element == the oracle's `for leaf { add_leaf }` (merkle_mountain_ranges.rs:89-120)"""
+    import torch
+    N, lib = pkg._native, pkg._native.lib()
+    first, more = 12345, (1 << 17) + 4099
+    leaves = pkg.synthetic.splitmix_leaves(first + more, 0x5EED0707)
+    om = oracle.mmr(leaves)
+    d = torch.from_numpy(leaves.view(np.int64)).cuda()
+    for chunk_log in (10, 14, 20):
+        m = pkg.MMR.from_leaves(leaves[:first])
+        len0 = len(m)
+        pin = pkg.mmr.PinnedBuffer(4 * (len(om.elements) - len0))
+        m.extend_dev_to_host(d[first:], more, pin, chunk_log=chunk_log)
+        N.check(lib.p2mt_sync())
+        assert len(m) == len(om.elements)
+        assert np.array_equal(pin.array.reshape(-1, 4), om.elements[len0:])
+        assert np.array_equal(m.bagging_the_peaks(), om.bagging_the_peaks())
+        whole = pkg.mmr.PinnedBuffer(4 * len(m))
+        m.copy_elements_async(0, len(m), whole)
+        N.check(lib.p2mt_sync())
+        assert np.array_equal(whole.array.reshape(-1, 4), om.elements)
+        with pytest.raises(pkg.P2mtPanic):
+            m.copy_elements_async(len(m), 1, whole)
+        with pytest.raises(pkg.P2mtPanic):
+            m.extend_dev_to_host(d, 16, whole, chunk_log=9)
+        pin.free()
+        whole.free()
