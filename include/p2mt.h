@@ -265,6 +265,38 @@ int p2mt_mmr_combine_shard_roots(const uint64_t *shard_roots /*[world][4]*/, siz
  * the sharded build is build -> p2mt_mmr_root_dev -> all-gather (RCCL) -> this -> one 32-byte read-back.  world <= 1024. */
 int p2mt_mmr_combine_shard_roots_dev(const uint64_t *d_shard_roots /*[world][4]*/, size_t world,
                                      uint64_t *d_top_nodes_out /*[world-1][4] or NULL*/, uint64_t *d_root_out /*[4]*/);
+/* The whole sharded build behind the ABI (csrc/p2mt_sharded.hip; north_star: "a single RCCL all-gather over xGMI of the per-shard
+ * subtree roots", replacing the serial loop merkle_mountain_ranges.rs:89-120 on N GPUs): one process per GPU, rank r of `world` (a
+ * power of two <= 1024) owns leaves [r * n_local, (r + 1) * n_local), n_local a power of two.  A build = reset + extend of the local
+ * shard + p2mt_mmr_root_dev -> ONE ncclAllGather of world x 32 bytes -> the log2(world) top levels (one launch), all enqueued on the
+ * library stream; nothing visits the host until p2mt_sharded_mmr_root.  RCCL is loaded on first use (dlopen "librccl.so.1": the copy
+ * the process already holds, if any); machines without it get P2MT_EHIP here and lose nothing else.
+ * COMMUNICATOR OWNERSHIP.  p2mt_sharded_mmr_create takes an ncclComm_t the CALLER made (as void*; its size and rank must equal
+ * world / rank; NULL allowed when world == 1): the library uses it for that one collective per build, on its own stream, and never
+ * destroys or aborts it; the caller keeps it alive until p2mt_sharded_mmr_destroy and does not run other collectives on it
+ * concurrently from another thread.  p2mt_sharded_mmr_create_with_id makes a communicator of the library's own (ncclCommInitRank --
+ * collective: every rank calls it with the 128-byte id rank 0 got from p2mt_nccl_unique_id) and destroys it with the handle.
+ * p2mt_sharded_mmr_set_exchange replaces RCCL by a host callback (an all-gather of 32 bytes over MPI, gloo, a socket: fill
+ * all[world][4] from every rank's mine[4], return 0); the roots then make one host round trip per build. */
+typedef struct p2mt_sharded_mmr p2mt_sharded_mmr;
+typedef int (*p2mt_allgather32_fn)(void *user, const uint64_t *mine /*[4]*/, uint64_t *all /*[world][4]*/);
+int p2mt_sharded_mmr_create(p2mt_sharded_mmr **out, size_t n_local, int rank, int world, void *nccl_comm);
+int p2mt_nccl_unique_id(void *id_out /*128 bytes*/);
+int p2mt_sharded_mmr_create_with_id(p2mt_sharded_mmr **out, size_t n_local, int rank, int world, const void *nccl_unique_id_128);
+int p2mt_sharded_mmr_create_exchange(p2mt_sharded_mmr **out, size_t n_local, int rank, int world, p2mt_allgather32_fn fn, void *user);
+int p2mt_sharded_mmr_set_exchange(p2mt_sharded_mmr *s, p2mt_allgather32_fn fn, void *user);
+int p2mt_sharded_mmr_destroy(p2mt_sharded_mmr *s);
+p2mt_mmr *p2mt_sharded_mmr_local(p2mt_sharded_mmr *s); /* this rank's shard, borrowed: proofs inside it, elements, checkpoints */
+int p2mt_sharded_mmr_build_dev(p2mt_sharded_mmr *s, const uint64_t *d_local_leaves /*[n_local], device*/);
+int p2mt_sharded_mmr_build(p2mt_sharded_mmr *s, const uint64_t *local_leaves /*[n_local], host*/);
+int p2mt_sharded_mmr_finish(p2mt_sharded_mmr *s); /* the exchange + top levels alone, behind a shard the caller extended itself */
+/* one read-back: the root of the whole MMR; optionally every shard's root and the world - 1 top nodes (level-major, bottom-up) */
+int p2mt_sharded_mmr_root(p2mt_sharded_mmr *s, uint64_t *root_out /*[4]*/, uint64_t *shard_roots_out /*[world][4] or NULL*/,
+                          uint64_t *top_nodes_out /*[world-1][4] or NULL*/);
+/* MMR::get_proof (:209-223) for a leaf (global index) THIS rank owns: log2(n_local) siblings from the shard + log2(world) from the
+ * gathered roots; the one peak is root_out.  P2MT_EINVAL for a leaf of another rank (the owner makes the < 2 KB proof). */
+int p2mt_sharded_mmr_proof(p2mt_sharded_mmr *s, size_t global_leaf, uint64_t *siblings_out /*[<=64][4]*/, uint8_t *lefts_out /*[<=64]*/,
+                           int *n_siblings, uint64_t *root_out /*[4]*/);
 /* post-order position of the first element of shard `rank` and of top node (height h above shard roots, index j) */
 size_t p2mt_mmr_shard_first_pos(size_t n_local, size_t rank);
 size_t p2mt_mmr_node_pos(size_t last_leaf, unsigned height); /* 2L - popcount(L) + h */

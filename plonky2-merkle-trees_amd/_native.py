@@ -101,6 +101,18 @@ SIGNATURES = {
                                               C.c_size_t, voidp]),
     "p2mt_mmr_combine_shard_roots": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
     "p2mt_mmr_combine_shard_roots_dev": (C.c_int, [voidp, C.c_size_t, voidp, voidp]),
+    "p2mt_sharded_mmr_create": (C.c_int, [C.POINTER(voidp), C.c_size_t, C.c_int, C.c_int, voidp]),
+    "p2mt_nccl_unique_id": (C.c_int, [voidp]),
+    "p2mt_sharded_mmr_create_with_id": (C.c_int, [C.POINTER(voidp), C.c_size_t, C.c_int, C.c_int, voidp]),
+    "p2mt_sharded_mmr_create_exchange": (C.c_int, [C.POINTER(voidp), C.c_size_t, C.c_int, C.c_int, voidp, voidp]),
+    "p2mt_sharded_mmr_set_exchange": (C.c_int, [voidp, voidp, voidp]),
+    "p2mt_sharded_mmr_destroy": (C.c_int, [voidp]),
+    "p2mt_sharded_mmr_local": (voidp, [voidp]),
+    "p2mt_sharded_mmr_build_dev": (C.c_int, [voidp, voidp]),
+    "p2mt_sharded_mmr_build": (C.c_int, [voidp, voidp]),
+    "p2mt_sharded_mmr_finish": (C.c_int, [voidp]),
+    "p2mt_sharded_mmr_root": (C.c_int, [voidp, voidp, voidp, voidp]),
+    "p2mt_sharded_mmr_proof": (C.c_int, [voidp, C.c_size_t, voidp, voidp, intp, voidp]),
     "p2mt_mmr_shard_first_pos": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "p2mt_mmr_node_pos": (C.c_size_t, [C.c_size_t, C.c_uint]),
     "p2mt_ntt_batch": (C.c_int, [voidp, C.c_uint, C.c_size_t, C.c_int]),

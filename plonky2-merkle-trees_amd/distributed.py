@@ -3,8 +3,10 @@
 One process per GPU.  Rank r of `world` (a power of two) owns leaves [r*n_local, (r+1)*n_local), builds that
 perfect subtree locally (no data-path collective), then ONE all-gather of the 32-byte shard roots
 (torch.distributed: backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests) and
-log2(world) top levels hashed redundantly on every rank.  With RCCL the roots never leave HBM: root -> all_gather_into_tensor ->
-one combine launch -> one 32-byte-scale read-back (`finish_dev`); with gloo the roots travel through the host (`finish`).  The exchange is latency-bound (world x 32 B);
+log2(world) top levels hashed redundantly on every rank.  With RCCL the whole build is ONE C-ABI call (`p2mt_sharded_mmr_build_dev`,
+csrc/p2mt_sharded.hip: extend -> root -> ncclAllGather -> combine launch, all on the library stream, the roots never leave HBM) and this
+class is a caller of it: it only gets the 128-byte ncclUniqueId from rank 0 to the other ranks over torch.distributed, once; with gloo
+(the CPU tests) the roots travel through the host (`gather_roots` / `finish`).  The exchange is latency-bound (world x 32 B);
 link bandwidth is irrelevant, so no ring/bucket tuning applies.
 
 Global post-order geometry (A.4): rank r's nodes occupy [first_pos(r), first_pos(r) + 2*n_local - 1) with
@@ -31,12 +33,51 @@ class ShardedMMR:
         self.top_nodes = None     # (world-1, 4) level-major bottom-up
         self.root = None
 
+    # ---- the C-ABI handle (device path): p2mt_sharded_mmr owns the local shard, the communicator and the exchange
+    def _c(self):
+        if getattr(self, "_ch", None) is not None:
+            return self._ch
+        import ctypes as C
+        lib = N.lib()
+        h = C.c_void_p()
+        if self.world == 1 and self.dist is None:  # no process group: nothing to exchange with
+            N.check(lib.p2mt_sharded_mmr_create(C.byref(h), self.n_local, 0, 1, None))
+        else:
+            # a communicator of the library's own: rank 0 draws the id, everybody gets it over the process group that exists anyway
+            uid = np.zeros(128, np.uint8)
+            if self.rank == 0:
+                N.check(lib.p2mt_nccl_unique_id(N.ptr(uid)))
+            if self.world > 1:
+                import torch
+                dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+                t = torch.from_numpy(uid).to(dev)
+                self.dist.broadcast(t, src=0)
+                uid = t.cpu().numpy().copy()
+            N.check(lib.p2mt_sharded_mmr_create_with_id(C.byref(h), self.n_local, self.rank, self.world, N.ptr(uid)))
+        self._ch = h
+        return h
+
     @property
     def local(self):
         if self._local is None:
-            self._local = MMR()
-            self._local.reserve(self.n_local)
+            if self._use_c():
+                self._local = MMR.borrowed(N.lib().p2mt_sharded_mmr_local(self._c()), keepalive=self)
+            else:
+                self._local = MMR()
+                self._local.reserve(self.n_local)
         return self._local
+
+    def close(self):
+        if getattr(self, "_ch", None) is not None:
+            self._local = None
+            N.check(N.lib().p2mt_sharded_mmr_destroy(self._ch))
+            self._ch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- geometry (pure index maths)
     def first_pos(self, rank=None):
@@ -71,58 +112,38 @@ class ShardedMMR:
         """True when the exchange can stay in HBM: RCCL ("nccl") moves device tensors, gloo needs host memory."""
         return self.dist is not None and self.dist.get_backend() == "nccl"
 
+    def _use_c(self):
+        """the whole build behind the C ABI: RCCL process groups, and the single process without a group"""
+        return self._device_exchange() or (self.dist is None and self.world == 1)
+
     def build_dev(self, d_leaves):
         """d_leaves: this rank's n_local leaves, resident in HBM (torch tensor or raw device pointer)."""
+        if self._use_c():
+            N.check(N.lib().p2mt_sharded_mmr_build_dev(self._c(), N.ptr(d_leaves)))
+            return self.finish_dev()
         self.local.reset()
         self.local.extend_dev(d_leaves, self.n_local)
-        if self._device_exchange():
-            return self.finish_dev()
         local_root = self.local.bagging_the_peaks()  # perfect subtree: one peak == its root
         return self.finish(local_root)
 
     def build(self, leaves):
+        if self._use_c():
+            leaves = N.as_u64(leaves).reshape(-1)
+            assert leaves.size == self.n_local
+            N.check(N.lib().p2mt_sharded_mmr_build(self._c(), N.ptr(leaves)))
+            return self.finish_dev()
         self.local.reset()
         self.local.extend(leaves)
-        if self._device_exchange():
-            return self.finish_dev()
         return self.finish(self.local.bagging_the_peaks())
 
     def finish_dev(self):
-        """The exchange without a host round trip (RCCL): root of the local subtree written to HBM by the library ->
-        ONE all_gather_into_tensor of world x 32 B on preallocated device tensors -> ONE launch for the log2(world) top
-        levels (p2mt_mmr_combine_shard_roots_dev) -> one read-back of [roots | top nodes | root].  The library enqueues on
-        the default stream, which is torch's current stream here, so the collective is ordered after the build and the
-        combine after the collective without any host synchronisation."""
-        import torch
+        """One read-back behind the C-ABI build: [shard roots | top nodes | root]."""
         w = self.world
-        if getattr(self, "_d_all", None) is None:
-            # [w roots | w-1 top nodes | root] x 4 words; the local root is all-gathered from its own slot's copy
-            self._d_all = torch.zeros(2 * w * 4, dtype=torch.int64, device="cuda")
-            self._d_mine = torch.zeros(4, dtype=torch.int64, device="cuda")
-            self._h_all = torch.zeros(2 * w * 4, dtype=torch.int64).pin_memory()
-        lib = N.lib()
-        # The library enqueues on ITS stream and torch.distributed on torch's current stream: nothing else orders the root kernel
-        # before the collective or the collective before the combine launch.  For the duration of the exchange the library is
-        # pointed at torch's current stream (whatever it is: the null stream, a torch.cuda.stream(...) context, a stream the
-        # caller installed with p2mt_set_stream earlier), after draining what it had queued on its own; restored afterwards.
-        import ctypes as C
-        cur = torch.cuda.current_stream().cuda_stream
-        saved = C.c_void_p()
-        N.check(lib.p2mt_get_stream(C.byref(saved)))
-        N.check(lib.p2mt_sync())
-        N.check(lib.p2mt_set_stream(cur))
-        try:
-            N.check(lib.p2mt_mmr_root_dev(self.local._h, N.ptr(self._d_mine)))
-            self.dist.all_gather_into_tensor(self._d_all[:4 * w], self._d_mine)
-            base = self._d_all.data_ptr()
-            N.check(lib.p2mt_mmr_combine_shard_roots_dev(base, w, base + 32 * w if w > 1 else None, base + 32 * (2 * w - 1)))
-            self._h_all.copy_(self._d_all)  # synchronises torch's current stream (device -> pinned host)
-        finally:
-            N.check(lib.p2mt_set_stream(saved))
-        host = self._h_all.numpy().view(np.uint64).reshape(2 * w, 4)
-        self.shard_roots = host[:w].copy()
-        self.top_nodes = host[w:2 * w - 1].copy()
-        self.root = host[2 * w - 1].copy()
+        roots = np.zeros((w, 4), np.uint64)
+        top = np.zeros((max(w - 1, 1), 4), np.uint64)
+        root = np.zeros(4, np.uint64)
+        N.check(N.lib().p2mt_sharded_mmr_root(self._c(), N.ptr(root), N.ptr(roots), N.ptr(top)))
+        self.shard_roots, self.top_nodes, self.root = roots, top[:w - 1].copy(), root
         return self.root
 
     def finish(self, local_root):

@@ -60,6 +60,15 @@ class MMR:
         N.check(N.lib().p2mt_mmr_create(C.byref(h)))
         self._h = h
 
+    @staticmethod
+    def borrowed(handle, keepalive=None):
+        """a view of a p2mt_mmr handle somebody else owns (p2mt_sharded_mmr_local): never destroyed from here"""
+        m = MMR.__new__(MMR)
+        m._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        m._borrowed = True
+        m._keepalive = keepalive
+        return m
+
     # ---- reference API
     @staticmethod
     def new():
@@ -167,9 +176,9 @@ class MMR:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and not getattr(self, "_borrowed", False):
                 N.lib().p2mt_mmr_destroy(self._h)
-                self._h = None
+            self._h = None
         except Exception:
             pass
 

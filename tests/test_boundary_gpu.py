@@ -217,56 +217,49 @@ def test_bench_prove_replicas_on_one_device(pkg):
 
 
 # ---------------------------------------------------------------- round 3: the exchange stays in HBM; bench.py starts its own ranks
-class _FakeRcclGroup:
-    """Stands in for torch.distributed with the RCCL backend on ONE device: all_gather_into_tensor fills the output from the
-    roots the other "ranks" (shards built in this process) left in device memory.  Everything else -- p2mt_mmr_root_dev, the
-    preallocated device tensors, the single combine launch, the one read-back -- is the product's finish_dev()."""
-
-    def __init__(self, d_roots, rank):
-        self.d_roots, self.rank = d_roots, rank
-
-    def get_backend(self):
-        return "nccl"
-
-    def all_gather_into_tensor(self, out, mine):
-        import torch
-        assert out.is_cuda and mine.is_cuda and out.numel() == self.d_roots.numel()
-        assert torch.equal(mine, self.d_roots[4 * self.rank:4 * self.rank + 4]), "local root handed to the collective"
-        out.copy_(self.d_roots)
-
-
 @pytest.mark.parametrize("world", [1, 2, 8, 64])
 def test_device_resident_exchange(pkg, oracle, world):
-    """finish_dev(): root -> (all-gather) -> p2mt_mmr_combine_shard_roots_dev -> read-back, all on device pointers, against the
-    oracle's monolithic MMR (roots, every top node at its post-order position, the root)."""
+    """p2mt_sharded_mmr_build_dev for ranks 0 and world - 1 of `world` shards on one device (the other ranks' roots arrive through the
+    host-transport callback): root -> exchange -> p2mt_mmr_combine_shard_roots_dev -> one read-back, against the oracle's monolithic
+    MMR (roots, every top node at its post-order position, the root)."""
+    import ctypes as C
     import torch
+    N, lib = pkg._native, pkg._native.lib()
     k = 12
     n, n_local = 1 << k, (1 << k) // world
     leaves = pkg.synthetic.splitmix_leaves(n, 1234 + world)
     d_all = torch.from_numpy(leaves.view(np.int64)).cuda()
     full = oracle.mmr(leaves)
     full_el = full.elements
+    geo = pkg.ShardedMMR(pkg, n_local, 0, world, None)
+    shard_roots = np.stack([full_el[geo.first_pos(q) + 2 * n_local - 2] for q in range(world)])
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+    def exchange(user, mine, all_out):
+        for q in range(4 * world):
+            all_out[q] = int(shard_roots.reshape(-1)[q])
+        return 0
+    cb = CB(exchange)
+    for r in sorted({0, world - 1}):
+        h = C.c_void_p()
+        if world == 1:
+            N.check(lib.p2mt_sharded_mmr_create(C.byref(h), n_local, 0, 1, None))
+        else:
+            N.check(lib.p2mt_sharded_mmr_create_exchange(C.byref(h), n_local, r, world, cb, None))
+        try:
+            N.check(lib.p2mt_sharded_mmr_build_dev(h, N.ptr(d_all[r * n_local:(r + 1) * n_local])))
+            root, roots, top = np.zeros(4, np.uint64), np.zeros((world, 4), np.uint64), np.zeros((max(world - 1, 1), 4), np.uint64)
+            N.check(lib.p2mt_sharded_mmr_root(h, N.ptr(root), N.ptr(roots), N.ptr(top)))
+            assert np.array_equal(root, full.bagging_the_peaks())
+            assert np.array_equal(roots, shard_roots)
+            off = 0
+            for hh in range(1, geo.g + 1):
+                for j in range(world >> hh):
+                    assert np.array_equal(full_el[geo.top_node_pos(hh, j)], top[off + j]), (hh, j)
+                off += world >> hh
+        finally:
+            N.check(lib.p2mt_sharded_mmr_destroy(h))
     d_roots = torch.zeros(4 * world, dtype=torch.int64, device="cuda")
-    shards = []
-    for r in range(world):
-        sh = pkg.ShardedMMR(pkg, n_local, r, world, None)
-        sh.local.reset()
-        sh.local.extend_dev(d_all[r * n_local:(r + 1) * n_local], n_local)
-        pkg._native.check(pkg.lib().p2mt_mmr_root_dev(sh.local._h, pkg._native.ptr(d_roots[4 * r:4 * r + 4])))
-        shards.append(sh)
-    torch.cuda.synchronize()
-    for r in (0, world - 1):
-        sh = shards[r]
-        sh.dist = _FakeRcclGroup(d_roots, r)
-        root = sh.finish_dev()
-        assert np.array_equal(root, full.bagging_the_peaks())
-        for q in range(world):
-            assert np.array_equal(sh.shard_roots[q], full_el[sh.first_pos(q) + 2 * n_local - 2])
-        off = 0
-        for h in range(1, sh.g + 1):
-            for j in range(world >> h):
-                assert np.array_equal(full_el[sh.top_node_pos(h, j)], sh.top_nodes[off + j]), (h, j)
-            off += world >> h
     # refusals of the device entry point
     lib, ptr = pkg.lib(), pkg._native.ptr
     assert lib.p2mt_mmr_combine_shard_roots_dev(ptr(d_roots), 3, None, ptr(d_roots)) == pkg._native.P2MT_EINVAL
@@ -343,3 +336,111 @@ def test_elements_to_pinned_host_memory(pkg, oracle):
             m.extend_dev_to_host(d, 16, whole, chunk_log=9)
         pin.free()
         whole.free()
+
+
+def test_sharded_mmr_behind_the_c_abi(pkg, oracle):
+    """p2mt_sharded_mmr_* (csrc/p2mt_sharded.hip): (1) a ONE-rank RCCL communicator made in C -- p2mt_nccl_unique_id +
+    ncclCommInitRank inside p2mt_sharded_mmr_create_with_id, no torch.distributed anywhere -- carries the all-gather of the build;
+    (2) world = 4 on one device through the host-exchange callback: every rank's handle gets the four shard roots from the callback,
+    hashes the top levels on the device and assembles proofs for the leaves it owns; root, top nodes and proofs == the oracle's
+    monolithic MMR (merkle_mountain_ranges.rs:89-120, :209-223)."""
+    import ctypes as C
+    import torch
+    N, lib = pkg._native, pkg._native.lib()
+    n_local = 1 << 12
+    # (1) one rank, real RCCL
+    leaves = pkg.synthetic.splitmix_leaves(n_local, 0x5EED0801)
+    d = torch.from_numpy(leaves.view(np.int64)).cuda()
+    uid = np.zeros(128, np.uint8)
+    N.check(lib.p2mt_nccl_unique_id(N.ptr(uid)))
+    assert uid.any()
+    h = C.c_void_p()
+    N.check(lib.p2mt_sharded_mmr_create_with_id(C.byref(h), n_local, 0, 1, N.ptr(uid)))
+    try:
+        om = oracle.mmr(leaves)
+        for _ in range(3):
+            N.check(lib.p2mt_sharded_mmr_build_dev(h, N.ptr(d)))
+        root, roots = np.zeros(4, np.uint64), np.zeros((1, 4), np.uint64)
+        N.check(lib.p2mt_sharded_mmr_root(h, N.ptr(root), N.ptr(roots), None))
+        assert np.array_equal(root, om.bagging_the_peaks()) and np.array_equal(roots[0], root)
+        sib, lefts, ns = np.zeros((64, 4), np.uint64), np.zeros(64, np.uint8), C.c_int(0)
+        N.check(lib.p2mt_sharded_mmr_proof(h, 777, N.ptr(sib), N.ptr(lefts), C.byref(ns), N.ptr(root)))
+        ref = om.get_proof_normal_index(777)
+        assert ns.value == 12 and np.array_equal(sib[:12], ref["siblings"]) and np.array_equal(lefts[:12], ref["lefts"])
+        assert lib.p2mt_sharded_mmr_proof(h, n_local, N.ptr(sib), N.ptr(lefts), C.byref(ns), N.ptr(root)) == N.P2MT_EINVAL
+    finally:
+        N.check(lib.p2mt_sharded_mmr_destroy(h))
+    # arguments
+    assert lib.p2mt_sharded_mmr_create(C.byref(h), n_local, 0, 2, None) == N.P2MT_EINVAL      # world > 1 without a communicator
+    assert lib.p2mt_sharded_mmr_create(C.byref(h), n_local + 1, 0, 1, None) == N.P2MT_EINVAL  # not a power of two
+    assert lib.p2mt_sharded_mmr_create(C.byref(h), n_local, 3, 2, None) == N.P2MT_EINVAL
+    # (2) four ranks on one device, roots through the callback
+    world = 4
+    all_leaves = pkg.synthetic.splitmix_leaves(n_local * world, 0x5EED0802)
+    full = oracle.mmr(all_leaves)
+    shard_roots = np.stack([oracle.mmr(all_leaves[r * n_local:(r + 1) * n_local]).bagging_the_peaks() for r in range(world)])
+    calls = []
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+    def exchange(user, mine, all_out):
+        r = len(calls) % world
+        calls.append([mine[k] for k in range(4)])
+        assert calls[-1] == [int(x) for x in shard_roots[r]]
+        for k in range(4 * world):
+            all_out[k] = int(shard_roots.reshape(-1)[k])
+        return 0
+    cb = CB(exchange)
+    handles = []
+    try:
+        for r in range(world):
+            hr = C.c_void_p()
+            # (world > 1 needs a transport: the unique-id constructor would wait for four real ranks, so these handles get the callback)
+            N.check(lib.p2mt_sharded_mmr_create_exchange(C.byref(hr), n_local, r, world, cb, None))
+            handles.append(hr)
+            mine = all_leaves[r * n_local:(r + 1) * n_local]
+            N.check(lib.p2mt_sharded_mmr_build(hr, N.ptr(mine)))
+            root, roots, top = np.zeros(4, np.uint64), np.zeros((world, 4), np.uint64), np.zeros((world - 1, 4), np.uint64)
+            N.check(lib.p2mt_sharded_mmr_root(hr, N.ptr(root), N.ptr(roots), N.ptr(top)))
+            assert np.array_equal(root, full.bagging_the_peaks()) and np.array_equal(roots, shard_roots)
+            for g in (r * n_local, r * n_local + 1234, (r + 1) * n_local - 1):
+                sib, lefts, ns = np.zeros((64, 4), np.uint64), np.zeros(64, np.uint8), C.c_int(0)
+                N.check(lib.p2mt_sharded_mmr_proof(hr, g, N.ptr(sib), N.ptr(lefts), C.byref(ns), N.ptr(root)))
+                ref = full.get_proof_normal_index(g)
+                assert ns.value == 14 and np.array_equal(sib[:14], ref["siblings"]) and np.array_equal(lefts[:14], ref["lefts"])
+                assert oracle.mmr_proof_verify(sib[:14], lefts[:14], root[None], all_leaves[g], root)
+            other = ((r + 1) % world) * n_local
+            assert lib.p2mt_sharded_mmr_proof(hr, other, N.ptr(sib), N.ptr(lefts), C.byref(ns), N.ptr(root)) == N.P2MT_EINVAL
+        assert len(calls) == world
+    finally:
+        for hr in handles:
+            N.check(lib.p2mt_sharded_mmr_destroy(hr))
+
+
+def test_device_exchange_through_a_process_group(pkg, oracle):
+    """ShardedMMR with an RCCL process group is a CALLER of the C ABI (p2mt_sharded_mmr_*): it ships the ncclUniqueId over the group
+    once and the build -- extend -> root -> ncclAllGather -> combine -- is one library call.  One rank on the loopback here (RCCL
+    takes one rank per device); root and proofs == oracle."""
+    import torch
+    import torch.distributed as dist
+    n = 1 << 13
+    leaves = pkg.synthetic.splitmix_leaves(n, 4321)
+    d = torch.from_numpy(leaves.view(np.int64)).cuda()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        sh = pkg.ShardedMMR(pkg, n, 0, 1, dist)
+        assert sh._use_c()
+        om = oracle.mmr(leaves)
+        for _ in range(3):
+            root = sh.build_dev(d)
+        assert np.array_equal(root, om.bagging_the_peaks())
+        assert np.array_equal(sh.shard_roots[0], root) and sh.top_nodes.shape == (0, 4)
+        pr = sh.get_proof_normal_index(777)
+        ref = om.get_proof_normal_index(777)
+        assert np.array_equal(pr.siblings, ref["siblings"]) and np.array_equal(pr.lefts, ref["lefts"])
+        assert np.array_equal(sh.local.elements, om.elements)  # the borrowed local shard is a full MMR handle
+        assert np.array_equal(sh.build(leaves), root)
+        sh.close()
+    finally:
+        dist.destroy_process_group()

@@ -84,6 +84,12 @@ def parse_header(text):
                     t = "[%s; %s]" % (t, alen)
                 fields.append((fname, t))
         structs.append((m.group(3), fields))
+    # function-pointer typedefs: typedef int (*name)(params);  (callbacks a caller hands to the library)
+    fnptrs = []
+    for m in re.finditer(r"typedef\s+(\w+)\s*\(\s*\*\s*(\w+)\s*\)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        ps = [parse_param(q) for q in " ".join(m.group(3).split()).split(",")]
+        fnptrs.append((m.group(2), [q for q in ps if q], rust_type(m.group(1), 0, False)))
+    text = re.sub(r"typedef\s+\w+\s*\(\s*\*\s*\w+\s*\)\s*\([^;]*?\)\s*;", " ", text, flags=re.S)
     body = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
     body = re.sub(r"typedef\s+enum\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", body, flags=re.S)
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(p2mt_\w+)\s*\(([^;{}]*?)\)\s*;", body, flags=re.S):
@@ -97,11 +103,11 @@ def parse_header(text):
         funcs.append((name, [p for p in ps if p], None if rust_ret == "c_void" else rust_ret))
     for m in re.finditer(r"^\s*(P2MT_\w+)\s*=\s*(-?\d+)", text, flags=re.M):
         consts.append((m.group(1), m.group(2)))
-    return opaque, structs, funcs, consts
+    return opaque, structs, funcs, consts, fnptrs
 
 
 def generate():
-    opaque, structs, funcs, consts = parse_header(open(HEADER).read())
+    opaque, structs, funcs, consts, fnptrs = parse_header(open(HEADER).read())
     struct_names = {s[0] for s in structs}
     out = ["//! GENERATED by tools/gen_rust_ffi.py from include/p2mt.h -- do not edit; `python tools/gen_rust_ffi.py` rewrites it and",
            "//! tests/test_abi_cpu.py::test_rust_ffi_matches_header fails when it is stale.",
@@ -124,6 +130,11 @@ def generate():
             out.append("    pub %s: %s," % (f, t))
         out.append("}")
     out.append("")
+    for name, params, ret in fnptrs:
+        sig = ", ".join("%s: %s" % q for q in params)
+        out.append('pub type %s = Option<unsafe extern "C" fn(%s)%s>;' % (name, sig, " -> " + ret if ret != "c_void" else ""))
+    if fnptrs:
+        out.append("")
     out.append('#[link(name = "p2mt_hip")]')
     out.append('extern "C" {')
     for name, params, ret in funcs:
