@@ -1,34 +1,24 @@
 //! The reference crate's module layout (/root/reference/src/lib.rs:1-2) over the MI355X library:
 //! `simple_merkle_tree::simple_merkle_tree::{MerkleTree, verify_merkle_proof}` and
 //! `mmr::merkle_mountain_ranges::{MMR, MMR_proof, get_mmr_index, get_heights_bitmap_for_mmr_size}` keep their names and
-//! signatures; every hash runs in libp2mt_hip.so.  `mmr::{common, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion}` keep the
-//! reference's circuit constructors (names, arguments, tuple returns) over `plonk::CircuitBuilder` / `CircuitData::prove` /
-//! `verify`, which forward to the library's prover.  A caller switches by changing the crate name in its `use` lines; the two
+//! signatures; every hash runs in libp2mt_hip.so.  A caller switches by changing the crate name in its `use` lines; the two
 //! call-site edits that remain are listed in INTEGRATION.md (the `elements` field, by-reference getters).
-pub mod ffi;
+//! The circuit modules of the reference (`mmr::{common, mmr_plonky2_verifier, mmr_plonky2_verifier_1_recursion}`) are NOT re-hosted
+//! here: they compile unchanged against `shim/plonky2`.
+pub use p2mt_sys as ffi;
 
 pub mod simple_merkle_tree {
     pub mod simple_merkle_tree;
 }
-pub mod plonk;
 pub mod mmr {
-    pub mod common;
     pub mod merkle_mountain_ranges;
-    pub mod mmr_plonky2_verifier;
-    pub mod mmr_plonky2_verifier_1_recursion;
 }
 
 use plonky2::field::goldilocks_field::GoldilocksField;
 use plonky2::field::types::{Field, PrimeField64};
 use plonky2::hash::hash_types::HashOut;
 
-/// Status code -> the reference's error convention (panic), with the library's message.
-pub(crate) fn ok(rc: i32) {
-    if rc != ffi::P2MT_OK {
-        let msg = unsafe { std::ffi::CStr::from_ptr(ffi::p2mt_last_error()) }.to_string_lossy().into_owned();
-        panic!("p2mt status {rc}: {msg}");
-    }
-}
+pub(crate) use p2mt_sys::ok;
 
 /// One-time device selection (p2mt_init(0) happens implicitly on first use; call this to pick another GPU).
 pub fn init(device: i32) {
