@@ -179,22 +179,47 @@ __global__ __launch_bounds__(kBlock, 4) void k_merkle_level(const u64* __restric
 template <unsigned LV>
 __global__ __launch_bounds__(256, 4) void k_merkle_subtree(const u64* __restrict__ leaves, u64* __restrict__ levels, size_t n, PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][256 * 4];
+  // (k_mmr_subtree, p2mt_mmr.hip, has the measurements behind the two things below: a whole 64-byte sector of leaves per fetch with the
+  // other pairs parked in LDS, and the lane's indices worked out afresh in every step instead of living -- spilled -- across the hashes)
+  constexpr unsigned kG = LV >= 3 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) u64 lcache[kG - 1][256 * 2];
   poseidon_fast::MfmaCtx mc;
   poseidon_fast::mfma32_ctx_init(mc);
   const size_t n_blocks = n >> LV;
-  size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = blk < n_blocks;
-  blk = live ? blk : n_blocks - 1;
-  const size_t first_leaf = blk << LV;
-  const u64* lp = leaves + first_leaf;
+  const unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63u;
+  auto thread_index = [&]() -> unsigned {
+    unsigned t = wave_base + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(t));
+    return t;
+  };
   auto level_at = [&](unsigned h) -> u64* { return levels + 4 * (2 * n - ((2 * n) >> h)); };
   u64 cur[4] = {0, 0, 0, 0};
   unsigned pairs_done = 0, h = 0, merges = 0;
 #pragma unroll 1
   for (unsigned step = 0; step < (1u << LV) - 1; ++step) {
+    const unsigned tid = thread_index();
+    size_t blk = (size_t)blockIdx.x * 256 + tid;
+    const bool live = blk < n_blocks;
+    blk = live ? blk : n_blocks - 1;
+    const size_t first_leaf = blk << LV;
+    const u64* lp = leaves + first_leaf;
     u64 o[4];
     if (merges == 0) {  // hash the next leaf pair
-      const u64 a = gl::canon(lp[2 * pairs_done]), b = gl::canon(lp[2 * pairs_done + 1]);
+      const unsigned slot = pairs_done % kG;  // wave-uniform
+      u64 a, b;
+      if (slot == 0) {
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(lp + 2 * pairs_done);
+        ulonglong2 pr[kG];
+#pragma unroll
+        for (unsigned k = 0; k < kG; ++k) pr[k] = q[k];
+        a = pr[0].x, b = pr[0].y;
+#pragma unroll
+        for (unsigned k = 1; k < kG; ++k) reinterpret_cast<ulonglong2*>(&lcache[k - 1][tid * 2])[0] = pr[k];
+      } else {
+        const ulonglong2 pr = reinterpret_cast<const ulonglong2*>(&lcache[slot - 1][tid * 2])[0];
+        a = pr.x, b = pr.y;
+      }
+      a = gl::canon(a), b = gl::canon(b);
       const size_t leaf = first_leaf + 2 * pairs_done;
       if (live) {
         const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
@@ -202,27 +227,32 @@ __global__ __launch_bounds__(256, 4) void k_merkle_subtree(const u64* __restrict
         store_hash(levels + 4 * (leaf + 1), lb);
       }
       two_to_one_r<IMPL_FAST, 5, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
-        ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
-        rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
+        ll[0] = a; ll[1] = ll[2] = ll[3] = 0;
+        rr[0] = b; rr[1] = rr[2] = rr[3] = 0;
       }, &mc);
       merges = (unsigned)__builtin_ctz(~pairs_done);
       pairs_done += 1;
       h = 1;
-      if (live) store_hash(level_at(1) + 4 * (leaf >> 1), o);
     } else {  // merge the pending left sibling of height h with cur
-      const u64* sp = &stack[h - 1][threadIdx.x * 4];
       two_to_one_r<IMPL_FAST, 5>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
-        load_hash(sp, ll);
+        load_hash(&stack[h - 1][thread_index() * 4], ll);
 #pragma unroll
         for (int k = 0; k < 4; ++k) rr[k] = cur[k];
       }, &mc);
       merges -= 1;
       h += 1;
-      if (live) store_hash(level_at(h) + 4 * (((first_leaf + 2 * pairs_done) >> h) - 1), o);
     }
+    {
+      const unsigned tid2 = thread_index();
+      size_t blk2 = (size_t)blockIdx.x * 256 + tid2;
+      const bool live2 = blk2 < n_blocks;
+      blk2 = live2 ? blk2 : n_blocks - 1;
+      // the node just made: height h, index ((first leaf + 2 * pairs_done) >> h) - 1 of its level
+      if (live2) store_hash(level_at(h) + 4 * ((((blk2 << LV) + 2 * pairs_done) >> h) - 1), o);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cur[k] = o[k];
-    if (merges == 0 && h < LV) store_hash(&stack[h - 1][threadIdx.x * 4], cur);
+      for (int k = 0; k < 4; ++k) cur[k] = o[k];
+      if (merges == 0 && h < LV) store_hash(&stack[h - 1][tid2 * 4], cur);
+    }
   }
 }
 

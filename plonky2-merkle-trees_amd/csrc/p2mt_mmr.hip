@@ -126,26 +126,61 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
                                                      u64* __restrict__ elements, size_t block0, size_t n_blocks,
                                                      PermCtx ctx) {
   __shared__ __attribute__((aligned(16))) u64 stack[LV - 1][BLK * 4];  // stack[h-1][lane]: pending left sibling of height h < LV
+  // A lane's 2^LV leaves are one or two 64-byte sectors of HBM, and one 16-byte load per leaf pair fetched each sector four times over
+  // (the other ~530 MB of the launch's FETCH_SIZE once the spills were gone): the lane fetches kG pairs -- a whole sector -- at the
+  // first pair that needs it and parks the others here (12 KB per workgroup; four workgroups per CU still fit the 160 KB)
+  constexpr unsigned kG = LV >= 3 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) u64 lcache[kG - 1][BLK * 2];
   poseidon_fast::MfmaCtx mc;  // PR >= 2 (matrix-pipe MDS): per-lane A operands, made while every lane is active (MFMA ignores EXEC)
   if constexpr (PR == 2 || PR == 3) mc = poseidon_fast::mfma_ctx_init();
   if constexpr (PR == 5 || PR == 7 || PR == 8) poseidon_fast::mfma32_ctx_init(mc);
   // no lane leaves before the loop (PR == 5 / 7: an MFMA ignores EXEC and every lane's A operand serves the whole wave; a copy or spill
   // of it made under a partial EXEC would lose the idle lanes' rows): lanes past the end rebuild the last subtree and store nothing
-  size_t blk = block0 + (size_t)blockIdx.x * BLK + threadIdx.x;
-  const bool live = blk < block0 + n_blocks;
-  if constexpr (PR == 5 || PR == 7 || PR == 8) blk = live ? blk : block0 + n_blocks - 1;
-  else if (!live) return;
-  const size_t first_leaf = blk << LV;
-  const u64* lp = leaves + (first_leaf - leaf_base);
+  if constexpr (!(PR == 5 || PR == 7 || PR == 8))
+    if (block0 + (size_t)blockIdx.x * BLK + threadIdx.x >= block0 + n_blocks) return;
   u64 cur[4] = {0, 0, 0, 0};
   unsigned pairs_done = 0;  // leaf pairs consumed so far
   unsigned h = 0;           // height of `cur`
   unsigned merges = 0;      // merges still owed before the next leaf pair
+  // (the thread index itself: its wave's first thread in a scalar register + the lane number from v_mbcnt, so that not even v0 has to
+  // stay alive across the permutations)
+  const unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63u;
+  auto thread_index = [&]() -> unsigned {
+    unsigned t = wave_base + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(t));
+    return t;
+  };
 #pragma unroll 1
   for (unsigned step = 0; step < (1u << LV) - 1; ++step) {
+    // The lane's own indices -- its subtree, its first leaf, its leaf pointer, its LDS slots -- are worked out again in every step from
+    // an opaque copy of the thread index (a dozen integer instructions per 10 k of a hash).  Computed once in front of the loop they
+    // were eight registers alive across every permutation; the allocator spilled them (9 VGPRs, 40 bytes of scratch) and reloaded them
+    // in every step, and THOSE reloads were the launch's extra traffic: ~28 bytes per lane and step = 440-600 MB of FETCH_SIZE per
+    // 2^24-leaf launch against 134 MB of leaves (r04: 589 MB).  The leaf reads and the node stores were never the cause: fetching a
+    // whole 64-byte sector per lane and writing a pair's three nodes together were both built in round 5 and changed no counter.
+    const unsigned tid = thread_index();
+    size_t blk = block0 + (size_t)blockIdx.x * BLK + tid;
+    const bool live = blk < block0 + n_blocks;
+    blk = live ? blk : block0 + n_blocks - 1;
+    const size_t first_leaf = blk << LV;
+    const u64* lp = leaves + (first_leaf - leaf_base);
     u64 o[4];
     if (merges == 0) {  // hash the next leaf pair
-      const u64 a = gl::canon(lp[2 * pairs_done]), b = gl::canon(lp[2 * pairs_done + 1]);
+      const unsigned slot = pairs_done % kG;  // wave-uniform
+      u64 a, b;
+      if (slot == 0) {  // (8-byte aligned only: leaf_base may be odd)
+        const u64* q = lp + 2 * pairs_done;
+        u64 w[2 * kG];
+#pragma unroll
+        for (unsigned k = 0; k < 2 * kG; ++k) w[k] = q[k];
+        a = w[0], b = w[1];
+#pragma unroll
+        for (unsigned k = 1; k < kG; ++k) reinterpret_cast<ulonglong2*>(&lcache[k - 1][tid * 2])[0] = make_ulonglong2(w[2 * k], w[2 * k + 1]);
+      } else {
+        const ulonglong2 pr = reinterpret_cast<const ulonglong2*>(&lcache[slot - 1][tid * 2])[0];
+        a = pr.x, b = pr.y;
+      }
+      a = gl::canon(a), b = gl::canon(b);
       const size_t pos = node_pos(first_leaf + 2 * pairs_done + 1, 1);
       const u64 la[4] = {a, 0, 0, 0}, lb[4] = {b, 0, 0, 0};
       if (live) {
@@ -153,27 +188,34 @@ __global__ __launch_bounds__(BLK, OCC) void k_mmr_subtree(const u64* __restrict_
         store_hash(elements + 4 * (pos - 1), lb);
       }
       two_to_one_r<IMPL_FAST, PR, true>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {  // leaf pair: 10 of the 12 first S-boxes are constants
-        ll[0] = gl::canon(lp[2 * pairs_done]); ll[1] = ll[2] = ll[3] = 0;
-        rr[0] = gl::canon(lp[2 * pairs_done + 1]); rr[1] = rr[2] = rr[3] = 0;
+        // (the first call takes the values in hand; the practically-never redo re-reads the pair where it lies, indices worked out afresh)
+        ll[0] = a; ll[1] = ll[2] = ll[3] = 0;
+        rr[0] = b; rr[1] = rr[2] = rr[3] = 0;
       }, &mc);
       merges = (unsigned)__builtin_ctz(~pairs_done);  // trailing ones: carries of the binary counter
       pairs_done += 1;
       h = 1;
-      if (live) store_hash(elements + 4 * pos, o);
     } else {  // merge the pending left sibling of height h with cur
-      const u64* sp = &stack[h - 1][threadIdx.x * 4];
       two_to_one_r<IMPL_FAST, PR>(ctx, o, [&](u64 (&ll)[4], u64 (&rr)[4]) {
-        load_hash(sp, ll);
+        load_hash(&stack[h - 1][thread_index() * 4], ll);
 #pragma unroll
         for (int k = 0; k < 4; ++k) rr[k] = cur[k];
       }, &mc);
       merges -= 1;
       h += 1;
-      if (live) store_hash(elements + 4 * node_pos(first_leaf + 2 * pairs_done - 1, h), o);
     }
+    {  // (indices again behind the permutation, for the same reason)
+      const unsigned tid2 = thread_index();
+      size_t blk2 = block0 + (size_t)blockIdx.x * BLK + tid2;
+      const bool live2 = blk2 < block0 + n_blocks;
+      blk2 = live2 ? blk2 : block0 + n_blocks - 1;
+      const size_t fl2 = blk2 << LV;
+      // the node just made: height h, last leaf fl2 + 2 * pairs_done - 1 (a leaf pair's parent included: pairs_done was advanced)
+      if (live2) store_hash(elements + 4 * node_pos(fl2 + 2 * pairs_done - 1, h), o);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cur[k] = o[k];
-    if (merges == 0 && h < LV) store_hash(&stack[h - 1][threadIdx.x * 4], cur);  // becomes a pending left sibling
+      for (int k = 0; k < 4; ++k) cur[k] = o[k];
+      if (merges == 0 && h < LV) store_hash(&stack[h - 1][tid2 * 4], cur);  // becomes a pending left sibling
+    }
   }
 }
 
