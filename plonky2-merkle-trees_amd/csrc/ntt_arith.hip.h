@@ -51,7 +51,8 @@ GL_DEV void bfly(u64 a, u64 b, u64& s_out, u64& d_out, u64& sticky) {
       "v_subbrev_co_u32_e64 %[dh], %[w], 0, %[dh], %[w]\n\t"
       "s_or_b64 %[st], %[st], %[w]"
       : [s] "=&v"(s), [dl] "=&v"(dl), [dh] "=&v"(dh), [ma] "=&v"(ma), [ms] "=&v"(ms), [c] "=&s"(c), [w] "=&s"(w), [st] "+s"(sticky)
-      : [a] "v"(a), [b] "v"(b), [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32)));
+      : [a] "v"(a), [b] "v"(b), [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+      : "scc");
   s_out = s;
   d_out = ((u64)dh << 32) | dl;
 }
@@ -67,7 +68,8 @@ GL_DEV u64 add(u64 a, u64 b, u64& sticky) {
       "v_mad_u64_u32 %[s], %[c], %[m], 1, %[s]\n\t"
       "s_or_b64 %[st], %[st], %[c]"
       : [s] "=&v"(s), [c] "=&s"(c), [m] "=&v"(m), [st] "+s"(sticky)
-      : [a] "v"(a), [b] "v"(b));
+      : [a] "v"(a), [b] "v"(b)
+      : "scc");
   return s;
 }
 
@@ -85,7 +87,8 @@ GL_DEV u64 sub(u64 a, u64 b, u64& sticky) {
       "v_subbrev_co_u32_e64 %[hi], %[w], 0, %[hi], %[w]\n\t"
       "s_or_b64 %[st], %[st], %[w]"
       : [lo] "=&v"(lo), [hi] "=&v"(hi), [m] "=&v"(m), [w] "=&s"(w), [st] "+s"(sticky)
-      : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32)));
+      : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+      : "scc");
   return ((u64)hi << 32) | lo;
 }
 
@@ -111,7 +114,8 @@ GL_DEV u64 sub32_flag(u64 d, u32 h, u64& sticky) {
       "v_subbrev_co_u32_e64 %[hi], %[w], 0, %[d1], %[w]\n\t"
       "s_or_b64 %[st], %[st], %[w]"
       : [lo] "=&v"(lo), [hi] "=&v"(hi), [w] "=&s"(w), [st] "+s"(sticky)
-      : [d0] "v"((u32)d), [d1] "v"((u32)(d >> 32)), [h] "v"(h));
+      : [d0] "v"((u32)d), [d1] "v"((u32)(d >> 32)), [h] "v"(h)
+      : "scc");
   return ((u64)hi << 32) | lo;
 }
 GL_DEV u64 sub32_flag_cin(u64 d, u32 h, u64 cin, u64& sticky) {
@@ -122,7 +126,8 @@ GL_DEV u64 sub32_flag_cin(u64 d, u32 h, u64 cin, u64& sticky) {
       "v_subbrev_co_u32_e64 %[hi], %[w], 0, %[d1], %[w]\n\t"
       "s_or_b64 %[st], %[st], %[w]"
       : [lo] "=&v"(lo), [hi] "=&v"(hi), [w] "=&s"(w), [st] "+s"(sticky)
-      : [d0] "v"((u32)d), [d1] "v"((u32)(d >> 32)), [h] "v"(h), [cin] "s"(cin));
+      : [d0] "v"((u32)d), [d1] "v"((u32)(d >> 32)), [h] "v"(h), [cin] "s"(cin)
+      : "scc");
   return ((u64)hi << 32) | lo;
 }
 
@@ -162,7 +167,8 @@ GL_DEV u64 mul_pow2(u64 x, u64& sticky) {
         "v_subb_co_u32_e64 %[hi], %[w], -1, %[q1], %[w]\n\t"
         "s_or_b64 %[st], %[st], %[w]"
         : [lo] "=&v"(nlo), [hi] "=&v"(nhi), [w] "=&s"(w), [st] "+s"(sticky)
-        : [q0] "v"((u32)q), [q1] "v"((u32)(q >> 32)));  // p - Q; Q > p (Q within 2^32 of 2^64) -> sticky
+        : [q0] "v"((u32)q), [q1] "v"((u32)(q >> 32))
+      : "scc");  // p - Q; Q > p (Q within 2^32 of 2^64) -> sticky
     return fold96(l, ((u64)nhi << 32) | nlo);             // l EPS + (p - Q) < 2^64 + p: one wrap at most
   }
 }

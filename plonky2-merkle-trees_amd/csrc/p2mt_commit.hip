@@ -407,6 +407,9 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 typedef u64x2 __attribute__((address_space(1)))* gptr2;
 GL_DEV gcptr as_global(const u64* p) { return (gcptr)(unsigned long long)p; }
 GL_DEV gptr as_global(u64* p) { return (gptr)(unsigned long long)p; }
+// a wave-uniform base (an SGPR pair) plus a 32-bit per-lane byte offset: one VGPR of address per access instead of two
+GL_DEV u64 ld_at(gcptr base, u32 byte_off) { return *(gcptr)((const char __attribute__((address_space(1)))*)base + byte_off); }
+GL_DEV void st_at(gptr base, u32 byte_off, u64 v) { *(gptr)((char __attribute__((address_space(1)))*)base + byte_off) = v; }
 
 // ta[(r - 1) * 256 + t] = w_4096^(t brev4(r)), tb[(r - 1) * 16 + u] = w_4096^(16 u brev4(r)), r = 1..15
 __global__ __launch_bounds__(kBlock) void k_lde12_tables(const u64* __restrict__ tw_full, u64* __restrict__ ta, u64* __restrict__ tb) {
@@ -545,6 +548,8 @@ struct Tile {
 };
 
 constexpr unsigned brev4(unsigned r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+// the compile-time part of step C's output row: slot (bb, dd) of a thread
+constexpr unsigned kc(int bb, int dd) { return (((dd & 1) << 1) | (dd >> 1)) * 256u + (((bb & 1) << 1) | (bb >> 1)) * 64u; }
 
 // x *= 2^E for an exponent modulo 192 (2^96 = -1: the upper half costs a negation p - y, y > p flags)
 template <int E>
@@ -561,7 +566,8 @@ GL_DEV u64 mul_pow2_mod192(u64 x, u64& sticky) {
         "v_subb_co_u32_e64 %[hi], %[w], -1, %[y1], %[w]\n\t"
         "s_or_b64 %[st], %[st], %[w]"
         : [lo] "=&v"(lo), [hi] "=&v"(hi), [w] "=&s"(w), [st] "+s"(sticky)
-        : [y0] "v"((u32)y), [y1] "v"((u32)(y >> 32)));
+        : [y0] "v"((u32)y), [y1] "v"((u32)(y >> 32))
+      : "scc");
     return ((u64)hi << 32) | lo;
   }
 }
@@ -599,23 +605,36 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
   constexpr int Z16 = DIR ? 36 : 156, Z4 = DIR ? 144 : 48;
   __shared__ __attribute__((aligned(16))) u64 buf[T::kLdsWords];
   const unsigned t = threadIdx.x;
-  const unsigned q0 = blockIdx.y * kTile;
+  // workgroup -> (polynomial, tile).  The column pass with 8-column tiles reads 64-byte halves of 128-byte lines: the two tiles that
+  // share the lines run back to back on the SAME XCD (workgroups go to the XCDs round-robin in linear order), so the second half is
+  // an L2 hit instead of a second fetch; consecutive pairs of an XCD are the same tiles of other polynomials (they share t4's rows).
+  unsigned poly = blockIdx.x, tile = blockIdx.y;
+  if constexpr (!ROW_IN && Q == 8) {
+    if (((gridDim.x * gridDim.y) & 15) == 0 && (gridDim.y & 1) == 0) {
+      const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, seq = lin >> 3, idx = (seq >> 1) * 8 + xcd;
+      poly = idx % gridDim.x;
+      tile = 2 * (idx / gridDim.x) + (seq & 1);
+    }
+  }
+  const unsigned q0 = tile * kTile;
   // log_c: log2 of the row pitch of in / out (the number of columns): 10 for a 2^20-point transform; the column pass of a
   // 2^(10 + log_c)-point transform runs with 3 <= log_c <= 10 (its rows are 2^log_c long, its columns 1024)
-  const gcptr in = as_global(in_) + ((size_t)blockIdx.x << (10 + log_c));
-  const gptr out = as_global(out_) + ((size_t)blockIdx.x << (10 + log_c));
+  const gcptr in = as_global(in_) + ((size_t)poly << (10 + log_c));
+  const gptr out = as_global(out_) + ((size_t)poly << (10 + log_c));
   const gcptr ta1 = as_global(ta1_), t4 = as_global(t4_);
   u64 sticky = 0;
   u64 x[16];
   // ---- load + step A
   const unsigned qa = ROW_IN ? (t >> 6) : (t & (Q - 1)), p_lo = ROW_IN ? (t & 63) : (t >> kLogQ);
+  // every address of the tile is (uniform base) + (one 32-bit lane offset): the tile spans < 2^23 bytes, and the 16 strided
+  // accesses of a thread differ by uniform amounts.  (Sixteen 64-bit lane addresses, kept for the redo path, were what spilled.)
+  const u32 src_off = (ROW_IN ? ((q0 + qa) << 10) + p_lo : (p_lo << log_c) + q0 + qa) * 8u;
   {
     u64 tw[16];
-    const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << log_c) + q0 + qa;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << log_c];
+    for (int k = 0; k < 16; ++k) x[k] = ld_at(ROW_IN ? in + 64 * k : in + ((size_t)(64 * k) << log_c), src_off);
 #pragma unroll
-    for (int a = 1; a < 16; ++a) tw[a] = ta1[(a - 1) * 64 + p_lo];
+    for (int a = 1; a < 16; ++a) tw[a] = ld_at(ta1 + (a - 1) * 64, p_lo * 8u);
     __builtin_amdgcn_sched_barrier(0);
     ntt::dif16<Z16>(x, sticky);
     poseidon::static_for<1, 16>([&](auto rc) {
@@ -631,34 +650,37 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
   u64* const plane = buf + ab * kRowA + q;
 #pragma unroll
   for (int b = 0; b < 16; ++b) x[b] = plane[(4 * b + d) * kStride];
-  {
-    // slot b' *= w_64^(d brev4(b')), wave-uniform.  (These are powers of two -- w_64 = 2^39 -- but selecting the shift amounts per
-    // wave takes a uniform branch around the asm blocks, and hipcc 7.2 drops the taken side's results there: the table costs
-    // 4 issue slots per point more and no control flow.)
-    u64 twb[16];
-#pragma unroll
-    for (int b = 1; b < 16; ++b) twb[b] = ta1[15 * 64 + d * 16 + b];
-    __builtin_amdgcn_sched_barrier(0);
-    ntt::dif16<Z16>(x, sticky);
-    poseidon::static_for<1, 16>([&](auto rc) {
-      constexpr int b = decltype(rc)::value;
-      x[b] = ntt::mul(x[b], twb[b], sticky);
-    });
+  // slot b' *= w_64^(d brev4(b')), d wave-uniform: w_64 = 2^39 (2^-39 = 2^153 for the inverse), so the factors are shifts picked by a
+  // scalar branch -- 0 slots for d = 0, 5..8 per point otherwise against 12 for a table multiply.  (Round 4 had this and saw wrong
+  // values: its field-arithmetic asm ran s_or_b64 without an "scc" clobber, and the compiler's s_cmp / s_cselect pair straddled it.)
+  ntt::dif16<Z16>(x, sticky);
+  if (d != 0) {
+    auto arm = [&](auto dc) {
+      asm volatile("" ::: "memory");  // (an arm is taken or skipped as a whole, never computed speculatively and selected)
+      poseidon::static_for<1, 16>([&](auto rc) {
+        constexpr int b = decltype(rc)::value, e = (DIR ? -39 : 39) * decltype(dc)::value * (int)brev4(b);
+        x[b] = mul_pow2_mod192<e>(x[b], sticky);
+      });
+    };
+    if (d == 1) arm(std::integral_constant<int, 1>{});
+    else if (d == 2) arm(std::integral_constant<int, 2>{});
+    else arm(std::integral_constant<int, 3>{});
   }
 #pragma unroll
   for (int b = 0; b < 16; ++b) plane[(4 * b + d) * kStride] = x[b];  // in place: the words this thread read
   __syncthreads();
   // ---- step C: thread (beta, a, q): b' = 4 beta + bb
+  // output row k = kc(bb, dd) + kl: kc = brev2(dd) * 256 + brev2(bb) * 64 known at compile time, kl = brev2(beta) * 16 + brev4(ab)
+  // the lane's part (brev4(4 beta + bb) = brev2(bb) * 4 + brev2(beta))
   const unsigned beta = d;
+  const unsigned kl = (((beta & 1) << 1) | (beta >> 1)) * 16 + (__builtin_bitreverse32(ab) >> 28);
+  const u32 dst_off = ((kl << log_c) + q0 + q) * 8u;
   u64 tw[16];
   if constexpr (TW) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-      for (int dd = 0; dd < 4; ++dd) {
-        const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
-        tw[4 * bb + dd] = t4[((size_t)k << log_c) + q0 + q];
-      }
+      for (int dd = 0; dd < 4; ++dd) tw[4 * bb + dd] = ld_at(t4 + ((size_t)kc(bb, dd) << log_c), dst_off);
   }
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb)
@@ -677,11 +699,12 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
     // DIF leaves frequency k at position brev10(k).
     u64* const flat = buf;
     __syncthreads();
-    {
-      const gcptr src = ROW_IN ? in + ((size_t)(q0 + qa) << 10) + p_lo : in + ((size_t)p_lo << log_c) + q0 + qa;
+    // (offsets made opaque here: otherwise the 16 + 16 lane addresses of the fast path are kept alive -- spilled -- for this one)
+    u32 src_off2 = src_off, dst_off2 = dst_off;
+    asm volatile("" : "+v"(src_off2), "+v"(dst_off2));
 #pragma unroll
-      for (int k = 0; k < 16; ++k) flat[qa * 1024 + 64 * k + p_lo] = gl::canon(ROW_IN ? src[64 * k] : src[(size_t)(64 * k) << log_c]);
-    }
+    for (int k = 0; k < 16; ++k)
+      flat[qa * 1024 + 64 * k + p_lo] = gl::canon(ld_at(ROW_IN ? in + 64 * k : in + ((size_t)(64 * k) << log_c), src_off2));
     __syncthreads();
     for (unsigned s = 0; s < 10; ++s) {
       const unsigned half = 512u >> s;
@@ -698,10 +721,10 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
     for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
       for (int dd = 0; dd < 4; ++dd) {
-        const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
+        const unsigned k = kc(bb, dd) + kl;
         u64 v = flat[q * 1024 + brev32(k, 10)];
-        if constexpr (TW) v = cmul(v, t4[((size_t)k << log_c) + q0 + q]);
-        out[((size_t)k << log_c) + q0 + q] = v;
+        if constexpr (TW) v = cmul(v, ld_at(t4 + ((size_t)kc(bb, dd) << log_c), dst_off2));
+        st_at(out + ((size_t)kc(bb, dd) << log_c), dst_off2, v);
       }
     return;
   }
@@ -709,8 +732,8 @@ __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ i
   for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd) {
-      const unsigned k = (dd == 0 ? 0 : dd == 1 ? 512 : dd == 2 ? 256 : 768) + brev4(4 * beta + bb) * 16 + brev4(ab);
-      out[((size_t)k << log_c) + q0 + q] = gl::canon(x[4 * bb + dd]);
+      // pass 1 writes the scratch array pass 2 reads: any u64 representative will do there (the arithmetic is the same loose one)
+      st_at(out + ((size_t)kc(bb, dd) << log_c), dst_off, TW ? x[4 * bb + dd] : gl::canon(x[4 * bb + dd]));
     }
 }
 
@@ -1057,13 +1080,13 @@ int ntt_fourstep_natural_dev(u64* d_data, u64* d_tmp, unsigned log_n, size_t n_p
   P2MT_TRY(get_twiddles(m, inverse, &twm));
   hipStream_t st = p2mt::rt().stream;
   const unsigned force = p2mt::rt().force_fallback ? 1u : 0u;
-  // Tile width per pass, measured at 2^20 (profiles/r04_commit_phase.txt): the column pass is faster with 16 transforms per workgroup
-  // (0.87 ms against 1.16 ms: its loads, twiddle loads and stores are all granules, and 64-byte ones double the cache lines a
-  // wave-load touches), the row pass with 8 (0.58 ms against 0.74 ms: two workgroups per CU cover each other's memory phases).
-  // P2MT_LDE12=3 / 4 force 16 / 8 for both (A/B).  Rows of 8 points leave room for 8 columns only.
+  // Tile width, measured at 2^20 x 128 (profiles/r05_ntt_passes.txt): 8 transforms per workgroup for both passes -- two 512-thread
+  // workgroups per CU cover each other's memory phases (column pass 0.77 ms against 0.82-0.88 with 16, row pass 0.58 against 0.74).
+  // Until round 5 the column pass took 159 VGPRs at this width (one workgroup per CU, 1.16 ms) and 16 was the faster one.
+  // P2MT_LDE12=3 forces 16 for both (A/B).
   const int mode = p2mt::rt().use_lde12;
   {
-    const bool wide = m >= 4 && mode != 4;
+    const bool wide = m >= 4 && mode == 3;
     const dim3 grid((unsigned)n_polys, (1u << m) / (wide ? 16 : 8)), block(wide ? 1024 : 512);
     const int slot = p2mt::prof_begin();
     if (wide && !inverse) hipLaunchKernelGGL((k_ntt20_pass<0, false, true, 16>), grid, block, 0, st, (const u64*)d_data, d_tmp, ta1, t4, twh, m, force);
