@@ -542,9 +542,14 @@ namespace ntt20 {
 //           the exchanges through LDS one 32-bit half at a time halves the array, but a second workgroup of 1024 threads also needs
 //           the kernel in 64 VGPRs and it has 128 + 34 spilled: built in round 4, 102 spills and 412 B of scratch, dropped);
 //   Q = 8:   64-byte granules,  75 KB of LDS, two workgroups of 512 threads per CU (one computes while the other loads / stores).
-template <unsigned Q>
+// The row pass's step-A writers have lanes along p_lo (odd stride Q + 1); the column pass's have lanes along q, then p_lo: stride Q puts a
+// half-wave's 32 words on 32 different double-banks (with Q + 1 it measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.20; the launch
+// time did not move with it: LDS is 5.6 M of the pass's 227 M wave instructions).  Either
+// way rowA = Q mod 32 keeps the (a, q)-lane accesses of steps B and C conflict-free.
+template <unsigned Q, bool ROW_IN>
 struct Tile {
-  static constexpr unsigned kThreads = 64 * Q, kStride = Q + 1, kRowA = 64 * (Q + 1) + Q, kLdsWords = 16 * kRowA;
+  static constexpr unsigned kThreads = 64 * Q, kStride = ROW_IN ? Q + 1 : Q, kRowA = 64 * kStride + Q, kLdsWords = 16 * kRowA;
+  static_assert(kLdsWords >= Q * 1024, "the redo path lays the tile out flat in the same array");
 };
 
 constexpr unsigned brev4(unsigned r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
@@ -600,7 +605,7 @@ template <int DIR, bool ROW_IN, bool TW, unsigned Q>
 __global__ __launch_bounds__(64 * Q) void k_ntt20_pass(const u64* __restrict__ in_, u64* __restrict__ out_, const u64* __restrict__ ta1_,
                                                      const u64* __restrict__ t4_, const u64* __restrict__ tw_half, unsigned log_c, unsigned force) {
   using namespace ntt20;
-  using T = Tile<Q>;  // (ROW_IN: rows of 1024 points, i.e. log_c == 10)
+  using T = Tile<Q, ROW_IN>;  // (ROW_IN: rows of 1024 points, i.e. log_c == 10)
   constexpr unsigned kRowA = T::kRowA, kStride = T::kStride, kTile = Q, kLogQ = Q == 16 ? 4 : 3;
   constexpr int Z16 = DIR ? 36 : 156, Z4 = DIR ? 144 : 48;
   __shared__ __attribute__((aligned(16))) u64 buf[T::kLdsWords];

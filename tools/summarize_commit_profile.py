@@ -2,7 +2,7 @@
 """profiles/r04_commit_phase.txt + the transform kernels' entries of profiles/pmc_summary.json from two tools/profile_cmd.sh runs
 (tools/ntt_lde_probe.py --what lde / --what ntt):
 
-  python tools/summarize_commit_profile.py gpurun_out/<lde dir> gpurun_out/<ntt dir> > profiles/r04_commit_phase.txt
+  python tools/summarize_commit_profile.py gpurun_out/<lde dir> gpurun_out/<ntt dir> [profiles/rNN_commit_phase.txt] > profiles/rNN_commit_phase.txt
 
 Counters follow /opt/skills/guides/MI355X_MICROARCH.md: one counter set per pass; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE reported
 at half the bytes of a wide streaming read on gfx950 (x2 below); GRBM_GUI_ACTIVE sums the 8 XCDs."""
@@ -63,6 +63,9 @@ def section(title, k, points, algo_bytes, per_point_name):
     return lines, summary
 
 
+OUT_NAME = "profiles/r04_commit_phase.txt"
+
+
 def main(lde_dir, ntt_dir):
     lde = parse(os.path.join(lde_dir, "summary.txt"))
     ntt = parse(os.path.join(ntt_dir, "summary.txt"))
@@ -76,7 +79,7 @@ def main(lde_dir, ntt_dir):
     l, s = section("== k_coset_lde12_v2: one launch = 34 560 workgroups (polynomial, coset); 72 B per coefficient (8 read + 64 written)", k,
                    4320 * 4096 * 8, 4320 * 4096 * 72, "wave of 64 output points")
     out += l
-    s["source"] = "profiles/r04_commit_phase.txt (tools/profile_cmd.sh: one --pmc pass per counter set; traffic = 2 x FETCH_SIZE + WRITE_SIZE)"
+    s["source"] = OUT_NAME + " (tools/profile_cmd.sh: one --pmc pass per counter set; traffic = 2 x FETCH_SIZE + WRITE_SIZE)"
     pj["k_coset_lde12_v2@4320x2^12"] = s
     for sub, title, key in (("k_ntt20_pass<0, false, true", "== k_ntt20_pass<forward, columns in, twiddle>: pass 1 (reads 16 B-granule columns... see DESIGN.md); 16 B per point", "pass1"),
                             ("k_ntt20_pass<0, true, false", "== k_ntt20_pass<forward, rows in>: pass 2 (reads whole rows, writes the result transposed = natural order); 16 B per point", "pass2")):
@@ -85,13 +88,13 @@ def main(lde_dir, ntt_dir):
             continue
         l, s = section(title, k, 128 * (1 << 20), 128 * (1 << 20) * 16, "wave of 64 points")
         out += l
-        s["source"] = "profiles/r04_commit_phase.txt"
+        s["source"] = OUT_NAME
         pj["k_ntt20_pass@128x2^20:" + key] = s
     if "k_ntt20_pass@128x2^20:pass1" in pj and "k_ntt20_pass@128x2^20:pass2" in pj:
         a, b = pj["k_ntt20_pass@128x2^20:pass1"], pj["k_ntt20_pass@128x2^20:pass2"]
         pj["k_ntt20_pass@128x2^20"] = {"valu_instr_per_point": round((a["valu_instr_per_point"] + b["valu_instr_per_point"]) / 2, 1),
                                        "hbm_bytes_per_launch": (a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"]) / 2,
-                                       "source": "profiles/r04_commit_phase.txt (mean of the two passes)"}
+                                       "source": OUT_NAME + " (mean of the two passes)"}
     out += ["== reference points (tools/ubench_granule.hip, same bytes, no arithmetic)",
             "  plain copy, 16 B per lane: 4.8 TB/s; 1024-row x 16-column tiles read and written as 128-byte granules one row apart (pass 1's pattern): 5.2 TB/s;",
             "  rows in / granules out (pass 2's): 5.3 TB/s; with 64-byte granules 4.7 / 4.0 TB/s.  The access patterns are not what bounds the passes."]
@@ -103,4 +106,6 @@ def main(lde_dir, ntt_dir):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3:
+        OUT_NAME = sys.argv[3]  # the file the caller redirects stdout to (recorded as `source` in pmc_summary.json)
     main(sys.argv[1], sys.argv[2])
