@@ -120,6 +120,12 @@ int p2mt_debug_host_challenger(const uint64_t *elements, const uint32_t *n_obs, 
 /* Where single proves / verifications run their transcript: 1 = host core (default; env P2MT_HOST_TRANSCRIPT), 0 = device (what the
  * batched passes always do).  Results are identical; the knob exists for A/B measurements and tests. */
 int p2mt_debug_host_transcript(int on);
+/* Single proves with the transcript on the host also evaluate their long dependency chains of PoseidonGate rows there before the
+ * launch (the recursion's outer circuit: the inner proof's 105-row transcript; csrc/p2mt_circuit.hip select_host_chain) and hand the
+ * outputs down with the witness inputs: 1 = on (default; env P2MT_HOST_CHAIN), 0 = every generator on the device.  Proofs are identical. */
+int p2mt_debug_host_chain(int on);
+/* The generator schedule of the last prove: dependency levels on the device, PoseidonGate rows evaluated on the host. */
+int p2mt_circuit_schedule_info(const struct p2mt_circuit_data *c, uint32_t *n_levels, uint32_t *host_rows);
 /* One-launch tree builds (csrc/p2mt_plan.hip: stage 1 and every level above it as dependency-ordered workgroups of one grid).
  * Knobs for measurement (a negative argument keeps the current value; the environment sets the defaults: P2MT_PLAN, P2MT_PLAN_MIN_LOG,
  * P2MT_PLAN_ORDER, P2MT_PLAN_TQ, P2MT_PLAN_TW): enabled 0/1; min_log: smallest subtree (log2 leaves) that takes the one-launch path;

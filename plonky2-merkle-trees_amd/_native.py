@@ -45,6 +45,8 @@ SIGNATURES = {
     "p2mt_debug_partial_group": (C.c_int, [C.c_int, voidp, C.c_size_t, voidp, voidp]),
     "p2mt_host_poseidon_permute": (C.c_int, [voidp, voidp, C.c_size_t]),
     "p2mt_debug_host_transcript": (C.c_int, [C.c_int]),
+    "p2mt_debug_host_chain": (C.c_int, [C.c_int]),
+    "p2mt_circuit_schedule_info": (C.c_int, [voidp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "p2mt_debug_host_challenger": (C.c_int, [voidp, voidp, voidp, C.c_size_t, voidp]),
     "p2mt_debug_plan_knobs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "p2mt_debug_plan_profile": (C.c_int, [C.c_int]),

@@ -78,6 +78,15 @@ struct p2mt_circuit_data {
   std::vector<u32> sched_inputs;
   bool sched_valid = false;
   u32 n_levels = 0;
+  // PoseidonGate rows the HOST evaluates before the launch (single proves; see select_host_chain): in evaluation order
+  struct HostRow {
+    u32 in[12], swap, out[12];
+    u32 check_mask;  // bit k: out[k] holds a value already when this row runs (compared, as a second set_target would be)
+  };
+  std::vector<HostRow> host_chain;
+  std::vector<u64> h_vals;           // slot -> value for the slots the host chain reads and writes (constants written once)
+  std::vector<u32> memo_input_slots; // the input-slot set of the memoised target sequence (to re-schedule when the mode changes)
+  bool sched_host_chain = false;
   // device memory: one allocation, carved
   u64* d_base = nullptr;
   u64 *d_cs_vals = nullptr, *d_cs_coeffs = nullptr, *d_cs_lde = nullptr, *d_cs_leaves = nullptr, *d_cs_dig = nullptr;
@@ -164,7 +173,14 @@ u32 cb_add_gate(p2mt_circuit_builder* b, int kind, u64 c0, u64 c1) {
     Gen g{};
     g.kind = gk;
     g.row = row;
-    b->gens.push_back(g);
+    // PoseidonMdsGenerator writes 12 extension elements, each a 12-term sum of its own: one record per output element (i = r), so that
+    // they run on 12 lanes side by side -- as ONE lane generator it took ~18 us, and the in-circuit evaluation of the inner PoseidonGate
+    // constraint chains 21 of them (round 5: the witness's critical path once the transcript had left the device)
+    const u32 parts = gk == GEN_POSEIDON_MDS ? 12 : 1;
+    for (u32 r = 0; r < parts; ++r) {
+      g.i = r;
+      b->gens.push_back(g);
+    }
   }
   return row;
 }
@@ -697,20 +713,25 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 #pragma unroll
       for (u32 i = 0; i < 24; ++i) sl[i] = S[i];
       get_many(m, sl, in);
-      u32 os[24];
-#pragma unroll
-      for (u32 i = 0; i < 24; ++i) os[i] = S[24 + i];
+      const u32 r = op.b;  // this record's output element: sum_i circ[i] * state[(i + r) % 12] (+ diag[0] * state[0] for r = 0)
+      const u32 os0 = S[24 + 2 * r], os1 = S[25 + 2 * r];
       DE st[12];
 #pragma unroll
       for (u32 i = 0; i < 12; ++i) st[i] = DE{in[2 * i], in[2 * i + 1]};
+      DE acc = r == 0 ? de_scale(st[0], 8) : DE{0, 0};
+      // state word j meets circ[(j - r) mod 12]: the state stays in registers under static indices, the small constants (< 64) are
+      // picked from two packed words by the run-time r
+      u64 lo = 0, hi = 0;
 #pragma unroll
-      for (u32 r = 0; r < 12; ++r) {
-        DE acc = r == 0 ? de_scale(st[0], 8) : DE{0, 0};
+      for (int k = 0; k < 6; ++k) lo |= (u64)gates_rec::mds_circ(k) << (6 * k), hi |= (u64)gates_rec::mds_circ(6 + k) << (6 * k);
 #pragma unroll
-        for (u32 i = 0; i < 12; ++i) acc = de_add(acc, de_scale(st[(i + r) % 12], gates_rec::mds_circ((int)i)));
-        put_out(m, os[2 * r], acc.a, fr.at(2 * r), err, o);
-        put_out(m, os[2 * r + 1], acc.b, fr.at(2 * r + 1), err, o);
+      for (u32 j = 0; j < 12; ++j) {
+        const u32 idx = j >= r ? j - r : j + 12 - r;
+        const u64 cj = ((idx < 6 ? lo >> (6 * idx) : hi >> (6 * (idx - 6)))) & 63;
+        acc = de_add(acc, de_scale(st[j], cj));
       }
+      put_out(m, os0, acc.a, fr.at(0), err, o);
+      put_out(m, os1, acc.b, fr.at(1), err, o);
       break;
     }
     default: break;
@@ -1452,19 +1473,134 @@ void gen_targets(const Gen& g, std::vector<u64>& ins, std::vector<u64>& outs) {
       for (u32 k = 0; k < 35; ++k) ins.push_back(W(k));
       for (u32 k = 35; k < 47; ++k) outs.push_back(W(k));
       break;
-    case GEN_POSEIDON_MDS:
+    case GEN_POSEIDON_MDS:  // (one record per output element g.i)
       for (u32 k = 0; k < 24; ++k) ins.push_back(W(k));
-      for (u32 k = 24; k < 48; ++k) outs.push_back(W(k));
+      outs = {W(24 + 2 * g.i), W(25 + 2 * g.i)};
       break;
     default: break;
   }
 }
 
+// single verifications / proves keep their transcript on a host core (host_poseidon.h); env P2MT_HOST_TRANSCRIPT=0 or
+// p2mt_debug_host_transcript(0) puts it back on the device (A/B, and what the batched passes always do)
+int& host_transcript_flag() {
+  static int v = [] {
+    const char* e = getenv("P2MT_HOST_TRANSCRIPT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+bool host_transcript_on() { return host_transcript_flag() != 0; }
+// ... and with it their long PoseidonGate chains (select_host_chain below); env P2MT_HOST_CHAIN=0 / p2mt_debug_host_chain(0): A/B
+int& host_chain_flag() {
+  static int v = [] {
+    const char* e = getenv("P2MT_HOST_CHAIN");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+// Which PoseidonGate rows the HOST evaluates before the launch (single proves with the transcript on the host, csrc/host_poseidon.hip).
+// A dependency chain of L PoseidonGate rows costs L x ~10 us on a wavefront and L x 1.35 us on a host core, and the recursion's outer
+// circuit has one of 105-110 rows -- the inner proof's transcript: it was the critical path of the witness (tools/critical_path.py).
+// Every input of such a row is a witness input, a constant or an output of an earlier row of the chain, i.e. something the host holds
+// or can derive before anything is launched; its outputs then go down WITH the witness inputs, the row leaves the device schedule, and
+// what depended on the challenges starts at level 1.  Structural (values do not matter), decided with the schedule:
+//   evaluable   all 13 inputs (state + swap) are constants, witness inputs or outputs of evaluable rows;
+//   length      rows on the longest evaluable chain through the row (depth from the inputs + height to the last consumer - 1);
+//   chosen      every row of length >= T and its ancestors, for the smallest T >= kHostChainMinLen whose set stays within kHostChainCap
+//               rows (the host is one core: 28 x 4 leaf sponges of 17 rows are evaluable too, and are better left to 112 wavefronts).
+// k_poseidon_rows still fills the non-routed wires of every row from the wire matrix, chosen or not.
+constexpr u32 kHostChainMinLen = 8, kHostChainCap = 192;
+void select_host_chain(p2mt_circuit_data* c, const std::vector<u32>& io, const std::vector<u32>& io_off, const std::vector<u32>& n_ins,
+                       const std::vector<int>& set_level, std::vector<char>& on_host) {
+  const size_t n_gens = c->gens.size();
+  std::vector<char> known(c->n_slots, 0);
+  for (u32 s = 0; s < c->n_slots; ++s) known[s] = set_level[s] == 0;
+  std::vector<int> producer(c->n_slots, -1), depth(n_gens, 0), height(n_gens, 0);
+  std::vector<u32> missing(n_gens, 0), order;
+  std::vector<std::vector<u32>> watchers(c->n_slots);
+  for (size_t gi = 0; gi < n_gens; ++gi) {
+    if (c->gens[gi].kind != GEN_POSEIDON) continue;
+    const u32* in = io.data() + io_off[gi];
+    for (u32 k = 0; k < n_ins[gi]; ++k) {
+      bool dup = false;
+      for (u32 j = 0; j < k; ++j) dup |= in[j] == in[k];
+      if (!dup && in[k] != kNoSlot && !known[in[k]]) {
+        ++missing[gi];
+        watchers[in[k]].push_back((u32)gi);
+      }
+    }
+    if (!missing[gi]) order.push_back((u32)gi);
+  }
+  for (size_t head = 0; head < order.size(); ++head) {
+    const u32 gi = order[head];
+    const u32 *in = io.data() + io_off[gi], *out = in + n_ins[gi];
+    int d = 0;
+    for (u32 k = 0; k < n_ins[gi]; ++k)
+      if (producer[in[k]] >= 0) d = std::max(d, depth[producer[in[k]]]);
+    depth[gi] = d + 1;
+    for (u32 k = 0; k < 12; ++k) {
+      if (known[out[k]]) continue;  // (not its first writer)
+      known[out[k]] = 1;
+      producer[out[k]] = (int)gi;
+      for (u32 w : watchers[out[k]])
+        if (--missing[w] == 0) order.push_back(w);
+    }
+  }
+  int longest = 0;
+  for (size_t k = order.size(); k-- > 0;) {  // consumers come later in `order`: their heights are final when a producer is visited
+    const u32 gi = order[k];
+    height[gi] = std::max(height[gi], 1);
+    const u32* in = io.data() + io_off[gi];
+    for (u32 j = 0; j < n_ins[gi]; ++j)
+      if (producer[in[j]] >= 0) height[producer[in[j]]] = std::max(height[producer[in[j]]], height[gi] + 1);
+  }
+  for (u32 gi : order) longest = std::max(longest, depth[gi] + height[gi] - 1);
+  std::vector<char> best;
+  for (int T = longest; T >= (int)kHostChainMinLen; --T) {
+    std::vector<char> pick(n_gens, 0);
+    size_t n = 0;
+    for (size_t k = order.size(); k-- > 0;) {  // reverse order: a picked row picks its producers
+      const u32 gi = order[k];
+      if (!pick[gi] && depth[gi] + height[gi] - 1 >= T) pick[gi] = 1;
+      if (!pick[gi]) continue;
+      ++n;
+      const u32* in = io.data() + io_off[gi];
+      for (u32 j = 0; j < n_ins[gi]; ++j)
+        if (producer[in[j]] >= 0) pick[producer[in[j]]] = 1;
+    }
+    if (n > kHostChainCap) break;
+    best.swap(pick);
+  }
+  if (best.empty()) return;
+  // an output is a first write on the host unless the host holds the slot already (an input, a constant, an earlier chosen row): then
+  // it is compared.  (A slot whose first writer stays on the device becomes a check THERE: it is set before the launch.)
+  std::vector<char> held(c->n_slots, 0);
+  for (u32 s = 0; s < c->n_slots; ++s) held[s] = set_level[s] == 0;
+  for (u32 gi : order) {
+    if (!best[gi]) continue;
+    const u32 *in = io.data() + io_off[gi], *out = in + n_ins[gi];
+    p2mt_circuit_data::HostRow r{};
+    for (u32 k = 0; k < 12; ++k) {
+      r.in[k] = in[k], r.out[k] = out[k];
+      if (held[out[k]]) r.check_mask |= 1u << k;
+      held[out[k]] = 1;
+    }
+    r.swap = in[12];
+    c->host_chain.push_back(r);
+    on_host[gi] = 1;
+  }
+  c->h_vals.assign(c->n_slots, 0);
+  for (const auto& ci : c->const_inits) c->h_vals[ci.first] = ci.second;
+}
+
 // Order the generators into levels for the given set of externally set slots (generate_partial_witness's watch lists,
 // resolved ahead of time: readiness does not depend on values).  Returns P2MT_EINVAL if some generator can never run.
-int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
-  if (c->sched_valid && c->sched_inputs == input_slots) return P2MT_OK;
+int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots, bool host_chain) {
+  if (c->sched_valid && c->sched_inputs == input_slots && c->sched_host_chain == host_chain) return P2MT_OK;
   c->sched_valid = false;
+  c->host_chain.clear();
   std::vector<int> set_level(c->n_slots, -1);
   for (const auto& ci : c->const_inits) set_level[ci.first] = 0;
   for (u32 s : input_slots) set_level[s] = 0;
@@ -1483,11 +1619,20 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
       io_off[gi + 1] = (u32)io.size();
     }
   }
+  std::vector<char> on_host(n_gens, 0);
+  size_t n_on_host = 0;
+  if (host_chain) {
+    select_host_chain(c, io, io_off, n_ins, set_level, on_host);
+    n_on_host = c->host_chain.size();
+    for (const auto& r : c->host_chain)
+      for (u32 k = 0; k < 12; ++k) set_level[r.out[k]] = 0;  // known before the launch, like a witness input
+  }
   // worklist: a generator becomes ready when its last unset input slot gets a level
   std::vector<u32> missing(n_gens, 0);
   std::vector<std::vector<u32>> watchers(c->n_slots);
   std::vector<u32> ready;
   for (size_t gi = 0; gi < n_gens; ++gi) {
+    if (on_host[gi]) continue;
     const u32* in = io.data() + io_off[gi];
     for (u32 k = 0; k < n_ins[gi]; ++k) {
       if (in[k] == kNoSlot) return p2mt::fail(P2MT_EINVAL, "internal: a generator input has no value slot");
@@ -1567,7 +1712,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
     }
     items.push_back(Item{level, op});
   }
-  if (items.size() != n_gens) return p2mt::fail(P2MT_EINVAL, "prove: some generators weren't run (a target they depend on was never set)");
+  if (items.size() + n_on_host != n_gens) return p2mt::fail(P2MT_EINVAL, "prove: some generators weren't run (a target they depend on was never set)");
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
     return a.level != b.level ? a.level < b.level : ((a.op.kind & 0xFF) == GEN_POSEIDON) > ((b.op.kind & 0xFF) == GEN_POSEIDON);
   });
@@ -1635,6 +1780,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots) {
   if (!pslots.empty()) P2MT_HIP(hipMemcpy(c->d_pslots, pslots.data(), pslots.size() * 4, hipMemcpyHostToDevice));
   if (!args.empty()) P2MT_HIP(hipMemcpy(c->d_args, args.data(), args.size() * 4, hipMemcpyHostToDevice));
   c->sched_inputs = input_slots;
+  c->sched_host_chain = host_chain;
   c->sched_valid = true;
   return P2MT_OK;
 }
@@ -1657,6 +1803,9 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
   // The proofs of a batch must all set that one sequence.
   const p2mt_partial_witness* pw = pws[0];
   const size_t n_sets = pw->sets.size();
+  // single proves with the transcript on the host also take their long PoseidonGate chains there (select_host_chain); the proofs of a
+  // batch keep everything on the device.  The schedule differs (the chosen rows are not in it): switching re-schedules.
+  const bool want_host_chain = B == 1 && host_chain_flag() != 0 && host_transcript_on();
   bool same = c->memo_valid && c->memo_targets.size() == n_sets;
   for (size_t k = 0; same && k < n_sets; ++k) same = c->memo_targets[k] == pw->sets[k].first;
   if (!same) {
@@ -1683,11 +1832,16 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
       }
     }
     std::sort(input_slots.begin(), input_slots.end());
-    P2MT_TRY(schedule(c, input_slots));
+    c->memo_input_slots = input_slots;
+    P2MT_TRY(schedule(c, input_slots, want_host_chain));
     c->memo_const_value.clear();
     for (const auto& ci : c->const_inits) c->memo_const_value[ci.first] = ci.second;
     c->memo_valid = true;
+  } else if (c->sched_host_chain != want_host_chain) {
+    P2MT_TRY(schedule(c, c->memo_input_slots, want_host_chain));
   }
+  const bool on_host = want_host_chain && !c->host_chain.empty();
+  u64* const hv = on_host ? c->h_vals.data() : nullptr;
   // (slot, value) pairs straight into the pinned staging area: constants first, then every first assignment
   size_t np2 = 0;
   for (unsigned bi = 0; bi < B; ++bi) {
@@ -1709,9 +1863,38 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
       if (first == -2) {
         pairs[np2++] = c->memo_slot[k];
         pairs[np2++] = v;
+        if (hv) hv[c->memo_slot[k]] = v;
       } else {  // PartitionWitness::set_target on an already set partition: the values must agree
         const u64 prev = first >= 0 ? w->sets[(size_t)first].second : c->memo_const_value[c->memo_slot[k]];
         if (prev != v) return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values");
+      }
+    }
+  }
+  if (on_host) {
+    // PoseidonGenerator on the host core, row after row: the state with the swap applied as the gate's own linear form (any swap value),
+    // the permutation, the outputs appended to the assignments (or compared where the slot holds a value already)
+    u64* pairs = c->h_pin + c->pin_pairs_off;
+    for (const auto& r : c->host_chain) {
+      u64 x[12];
+      for (u32 k = 0; k < 12; ++k) x[k] = hv[r.in[k]];
+      const u64 sw = hv[r.swap];
+      if (sw) {
+        for (u32 k = 0; k < 4; ++k) {
+          const u64 a = x[k], b = x[k + 4];
+          x[k] = h_add(a, h_mul(sw, h_sub(b, a)));
+          x[k + 4] = h_sub(b, h_mul(sw, h_sub(b, a)));
+        }
+      }
+      host_poseidon::permute(x);
+      for (u32 k = 0; k < 12; ++k) {
+        if ((r.check_mask >> k) & 1) {
+          if (hv[r.out[k]] != x[k])
+            return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
+        } else {
+          hv[r.out[k]] = x[k];
+          pairs[np2++] = r.out[k];
+          pairs[np2++] = x[k];
+        }
       }
     }
   }
@@ -2163,7 +2346,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   const size_t o_qvals = carve(kNumCh * big), o_ppq = carve((size_t)kNumCh * kNumChunks * n);
   const size_t o_head = carve(8 + c->proof_len + 2), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
   const size_t o_vals = carve(c->n_slots), o_set = carve((c->n_slots + 1) / 2);
-  c->init_cap = c->const_inits.size() + n_targets;
+  c->init_cap = c->const_inits.size() + n_targets + 12 * kHostChainCap;  // (+ the outputs of the host-evaluated PoseidonGate rows)
   const size_t o_init = carve(2 * c->init_cap);
   const size_t o_wslot = carve(n * kNumWires + 1), o_pislot = carve((c->n_pi + 2) / 2);
   c->ops_cap = c->gens.size() + (c->has_recursion_gates ? 3 * c->gens.size() + 8192 : 0);  // room for the schedule's padding records
@@ -2350,19 +2533,6 @@ extern "C" int p2mt_circuit_generate_witness(p2mt_circuit_data* c, const p2mt_pa
   return witness_status(c, err);
   });
 }
-
-namespace {
-// single verifications / proves keep their transcript on a host core (host_poseidon.h); env P2MT_HOST_TRANSCRIPT=0 or
-// p2mt_debug_host_transcript(0) puts it back on the device (A/B, and what the batched passes always do)
-int& host_transcript_flag() {
-  static int v = [] {
-    const char* e = getenv("P2MT_HOST_TRANSCRIPT");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-bool host_transcript_on() { return host_transcript_flag() != 0; }
-}  // namespace
 
 static int prove_once(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, unsigned B, uint64_t* proofs_out,
                       size_t proof_stride, int* status_out, int* gave_up);
@@ -2769,6 +2939,22 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
 extern "C" int p2mt_debug_host_transcript(int on) {
   return p2mt::abi_guard([&]() -> int {
   host_transcript_flag() = on ? 1 : 0;
+  return P2MT_OK;
+  });
+}
+
+extern "C" int p2mt_debug_host_chain(int on) {
+  return p2mt::abi_guard([&]() -> int {
+  host_chain_flag() = on ? 1 : 0;
+  return P2MT_OK;
+  });
+}
+extern "C" int p2mt_circuit_schedule_info(const p2mt_circuit_data* c, uint32_t* n_levels, uint32_t* host_rows) {
+  return p2mt::abi_guard([&]() -> int {
+  if (!c || !n_levels || !host_rows) return p2mt::fail(P2MT_EINVAL, "null pointer");
+  if (!c->sched_valid) return p2mt::fail(P2MT_EINVAL, "no schedule yet: prove once first");
+  *n_levels = c->n_levels;
+  *host_rows = (uint32_t)c->host_chain.size();
   return P2MT_OK;
   });
 }

@@ -138,6 +138,41 @@ def test_outer_witness_rejects_a_tampered_inner_proof(pkg, oracle):
         go.prove(pwo)
 
 
+def test_host_evaluated_poseidon_chain_same_proof(pkg, oracle):
+    """Single proves evaluate the long PoseidonGate chain of the outer circuit (the inner proof's transcript) on the host before the
+    launch (p2mt_circuit.hip select_host_chain): the proof is the same words with it, without it, and from the batched prover (which
+    never uses it and re-schedules); the schedule loses the chain's levels."""
+    import ctypes as C
+    lib = pkg.lib()
+
+    def info(cd):
+        lv, rows = C.c_uint32(), C.c_uint32()
+        pkg._native.check(lib.p2mt_circuit_schedule_info(cd._h, C.byref(lv), C.byref(rows)))
+        return lv.value, rows.value
+
+    case = mmr_case(oracle, 8, 3)
+    gi, pwi, oi, opwi = inner_both(pkg, oracle, case)
+    inner_proof = gi.prove(pwi)
+    assert info(gi)[1] == 0  # the inner circuit's chains need swap bits that generators produce: nothing for the host there
+    go, pwo, oo, opwo = outer_both(pkg, oracle, case, gi, oi, inner_proof)
+    try:
+        a = go.prove(pwo)
+        lv_on, rows_on = info(go)
+        pkg._native.check(lib.p2mt_debug_host_chain(0))
+        b = go.prove(pwo)
+        lv_off, rows_off = info(go)
+        batch = pkg.BatchProver(go, 2).prove([pwo, pwo])
+        pkg._native.check(lib.p2mt_debug_host_chain(1))
+        c = go.prove(pwo)
+    finally:
+        pkg._native.check(lib.p2mt_debug_host_chain(1))
+    assert rows_off == 0 and 90 <= rows_on <= 192, (rows_on, rows_off)
+    assert lv_on + 40 < lv_off, (lv_on, lv_off)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert all(np.array_equal(a, x) for x in batch)
+    assert oo.verify(a) == (True, 0)
+
+
 @pytest.mark.parametrize("mode", ["1", "0"])
 def test_outer_witness_interpreters_agree(mode):
     """The three interpreters of the generator schedule (dataflow = default, level-synchronous over the grid, one workgroup)
