@@ -79,11 +79,14 @@ struct p2mt_circuit_data {
   bool sched_valid = false;
   u32 n_levels = 0;
   // PoseidonGate rows the HOST evaluates before the launch (single proves; see select_host_chain): in evaluation order
-  struct HostRow {
-    u32 in[12], swap, out[12];
-    u32 check_mask;  // bit k: out[k] holds a value already when this row runs (compared, as a second set_target would be)
+  struct HostOp {
+    bool poseidon;   // PoseidonGenerator (in: 12 state words + swap, out: 12) or ArithmeticBaseGenerator (in: m0, m1, addend; out: 1)
+    u32 n_in, n_out, in[13], out[12];
+    u32 check_mask;  // bit k: out[k] holds a value already when this runs (compared, as a second set_target would be)
+    u64 c0, c1;
   };
-  std::vector<HostRow> host_chain;
+  std::vector<HostOp> host_chain;
+  u32 host_rows = 0;                 // PoseidonGate rows among them
   std::vector<u64> h_vals;           // slot -> value for the slots the host chain reads and writes (constants written once)
   std::vector<u32> memo_input_slots; // the input-slot set of the memoised target sequence (to re-schedule when the mode changes)
   bool sched_host_chain = false;
@@ -1511,22 +1514,30 @@ int& host_chain_flag() {
 //   chosen      every row of length >= T and its ancestors, for the smallest T >= kHostChainMinLen whose set stays within kHostChainCap
 //               rows (the host is one core: 28 x 4 leaf sponges of 17 rows are evaluable too, and are better left to 112 wavefronts).
 // k_poseidon_rows still fills the non-routed wires of every row from the wire matrix, chosen or not.
-constexpr u32 kHostChainMinLen = 8, kHostChainCap = 192;
+constexpr u32 kHostChainMinLen = 8, kHostChainCap = 192, kHostChainArithCap = 2048;
 void select_host_chain(p2mt_circuit_data* c, const std::vector<u32>& io, const std::vector<u32>& io_off, const std::vector<u32>& n_ins,
                        const std::vector<int>& set_level, std::vector<char>& on_host) {
   const size_t n_gens = c->gens.size();
+  auto is_p = [&](u32 gi) { return c->gens[gi].kind == GEN_POSEIDON; };
+  auto n_outs = [&](u32 gi) { return io_off[gi + 1] - io_off[gi] - n_ins[gi]; };
   std::vector<char> known(c->n_slots, 0);
   for (u32 s = 0; s < c->n_slots; ++s) known[s] = set_level[s] == 0;
+  // depth / height count the PoseidonGate rows on the longest evaluable path up to / from a generator (itself included)
   std::vector<int> producer(c->n_slots, -1), depth(n_gens, 0), height(n_gens, 0);
   std::vector<u32> missing(n_gens, 0), order;
   std::vector<std::vector<u32>> watchers(c->n_slots);
   for (size_t gi = 0; gi < n_gens; ++gi) {
-    if (c->gens[gi].kind != GEN_POSEIDON) continue;
+    // PoseidonGenerator, and ArithmeticBaseGenerator: the selects between two hashes (pick_hash of the reference's inner circuit,
+    // common.rs:42-58) sit between the rows of its chain
+    if (c->gens[gi].kind != GEN_POSEIDON && c->gens[gi].kind != GEN_ARITH) continue;
     const u32* in = io.data() + io_off[gi];
+    bool usable = true;
+    for (u32 k = 0; k < io_off[gi + 1] - io_off[gi]; ++k) usable &= in[k] != kNoSlot;
+    if (!usable) continue;
     for (u32 k = 0; k < n_ins[gi]; ++k) {
       bool dup = false;
       for (u32 j = 0; j < k; ++j) dup |= in[j] == in[k];
-      if (!dup && in[k] != kNoSlot && !known[in[k]]) {
+      if (!dup && !known[in[k]]) {
         ++missing[gi];
         watchers[in[k]].push_back((u32)gi);
       }
@@ -1539,8 +1550,8 @@ void select_host_chain(p2mt_circuit_data* c, const std::vector<u32>& io, const s
     int d = 0;
     for (u32 k = 0; k < n_ins[gi]; ++k)
       if (producer[in[k]] >= 0) d = std::max(d, depth[producer[in[k]]]);
-    depth[gi] = d + 1;
-    for (u32 k = 0; k < 12; ++k) {
+    depth[gi] = d + (is_p(gi) ? 1 : 0);
+    for (u32 k = 0; k < n_outs(gi); ++k) {
       if (known[out[k]]) continue;  // (not its first writer)
       known[out[k]] = 1;
       producer[out[k]] = (int)gi;
@@ -1551,44 +1562,53 @@ void select_host_chain(p2mt_circuit_data* c, const std::vector<u32>& io, const s
   int longest = 0;
   for (size_t k = order.size(); k-- > 0;) {  // consumers come later in `order`: their heights are final when a producer is visited
     const u32 gi = order[k];
-    height[gi] = std::max(height[gi], 1);
+    height[gi] = std::max(height[gi], is_p(gi) ? 1 : 0);
     const u32* in = io.data() + io_off[gi];
-    for (u32 j = 0; j < n_ins[gi]; ++j)
-      if (producer[in[j]] >= 0) height[producer[in[j]]] = std::max(height[producer[in[j]]], height[gi] + 1);
+    for (u32 j = 0; j < n_ins[gi]; ++j) {
+      const int pr = producer[in[j]];
+      if (pr >= 0) height[pr] = std::max(height[pr], height[gi] + (is_p((u32)pr) ? 1 : 0));
+    }
   }
-  for (u32 gi : order) longest = std::max(longest, depth[gi] + height[gi] - 1);
+  auto length = [&](u32 gi) { return depth[gi] + height[gi] - (is_p(gi) ? 1 : 0); };
+  for (u32 gi : order) longest = std::max(longest, length(gi));
   std::vector<char> best;
   for (int T = longest; T >= (int)kHostChainMinLen; --T) {
     std::vector<char> pick(n_gens, 0);
-    size_t n = 0;
-    for (size_t k = order.size(); k-- > 0;) {  // reverse order: a picked row picks its producers
+    size_t n_rows = 0, n_arith = 0;
+    for (size_t k = order.size(); k-- > 0;) {  // reverse order: a picked generator picks its producers
       const u32 gi = order[k];
-      if (!pick[gi] && depth[gi] + height[gi] - 1 >= T) pick[gi] = 1;
+      if (!pick[gi] && is_p(gi) && length(gi) >= T) pick[gi] = 1;
       if (!pick[gi]) continue;
-      ++n;
+      (is_p(gi) ? n_rows : n_arith) += 1;
       const u32* in = io.data() + io_off[gi];
       for (u32 j = 0; j < n_ins[gi]; ++j)
         if (producer[in[j]] >= 0) pick[producer[in[j]]] = 1;
     }
-    if (n > kHostChainCap) break;
+    if (n_rows > kHostChainCap || n_arith > kHostChainArithCap) break;
     best.swap(pick);
   }
   if (best.empty()) return;
-  // an output is a first write on the host unless the host holds the slot already (an input, a constant, an earlier chosen row): then
-  // it is compared.  (A slot whose first writer stays on the device becomes a check THERE: it is set before the launch.)
+  // an output is a first write on the host unless the host holds the slot already (an input, a constant, an earlier chosen generator):
+  // then it is compared.  (A slot whose first writer stays on the device becomes a check THERE: it is set before the launch.)
   std::vector<char> held(c->n_slots, 0);
   for (u32 s = 0; s < c->n_slots; ++s) held[s] = set_level[s] == 0;
   for (u32 gi : order) {
     if (!best[gi]) continue;
     const u32 *in = io.data() + io_off[gi], *out = in + n_ins[gi];
-    p2mt_circuit_data::HostRow r{};
-    for (u32 k = 0; k < 12; ++k) {
-      r.in[k] = in[k], r.out[k] = out[k];
+    p2mt_circuit_data::HostOp r{};
+    r.poseidon = is_p(gi);
+    r.n_in = n_ins[gi];
+    r.n_out = n_outs(gi);
+    r.c0 = c->gens[gi].c0;
+    r.c1 = c->gens[gi].c1;
+    for (u32 k = 0; k < r.n_in; ++k) r.in[k] = in[k];
+    for (u32 k = 0; k < r.n_out; ++k) {
+      r.out[k] = out[k];
       if (held[out[k]]) r.check_mask |= 1u << k;
       held[out[k]] = 1;
     }
-    r.swap = in[12];
     c->host_chain.push_back(r);
+    c->host_rows += r.poseidon;
     on_host[gi] = 1;
   }
   c->h_vals.assign(c->n_slots, 0);
@@ -1601,6 +1621,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots, bool hos
   if (c->sched_valid && c->sched_inputs == input_slots && c->sched_host_chain == host_chain) return P2MT_OK;
   c->sched_valid = false;
   c->host_chain.clear();
+  c->host_rows = 0;
   std::vector<int> set_level(c->n_slots, -1);
   for (const auto& ci : c->const_inits) set_level[ci.first] = 0;
   for (u32 s : input_slots) set_level[s] = 0;
@@ -1625,7 +1646,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots, bool hos
     select_host_chain(c, io, io_off, n_ins, set_level, on_host);
     n_on_host = c->host_chain.size();
     for (const auto& r : c->host_chain)
-      for (u32 k = 0; k < 12; ++k) set_level[r.out[k]] = 0;  // known before the launch, like a witness input
+      for (u32 k = 0; k < r.n_out; ++k) set_level[r.out[k]] = 0;  // known before the launch, like a witness input
   }
   // worklist: a generator becomes ready when its last unset input slot gets a level
   std::vector<u32> missing(n_gens, 0);
@@ -1876,17 +1897,21 @@ int fill_witness(p2mt_circuit_data* c, const p2mt_partial_witness* const* pws, u
     u64* pairs = c->h_pin + c->pin_pairs_off;
     for (const auto& r : c->host_chain) {
       u64 x[12];
-      for (u32 k = 0; k < 12; ++k) x[k] = hv[r.in[k]];
-      const u64 sw = hv[r.swap];
-      if (sw) {
-        for (u32 k = 0; k < 4; ++k) {
-          const u64 a = x[k], b = x[k + 4];
-          x[k] = h_add(a, h_mul(sw, h_sub(b, a)));
-          x[k + 4] = h_sub(b, h_mul(sw, h_sub(b, a)));
+      if (r.poseidon) {
+        for (u32 k = 0; k < 12; ++k) x[k] = hv[r.in[k]];
+        const u64 sw = hv[r.in[12]];
+        if (sw) {
+          for (u32 k = 0; k < 4; ++k) {
+            const u64 a = x[k], b = x[k + 4], d = h_mul(sw, h_sub(b, a));
+            x[k] = h_add(a, d);
+            x[k + 4] = h_sub(b, d);
+          }
         }
+        host_poseidon::permute(x);
+      } else {  // const_0 * m0 * m1 + const_1 * addend
+        x[0] = h_add(h_mul(h_mul(hv[r.in[0]], hv[r.in[1]]), r.c0), h_mul(hv[r.in[2]], r.c1));
       }
-      host_poseidon::permute(x);
-      for (u32 k = 0; k < 12; ++k) {
+      for (u32 k = 0; k < r.n_out; ++k) {
         if ((r.check_mask >> k) & 1) {
           if (hv[r.out[k]] != x[k])
             return p2mt::fail(P2MT_EINVAL, "prove: partition was set twice with different values (the witness contradicts the circuit)");
@@ -2346,7 +2371,7 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   const size_t o_qvals = carve(kNumCh * big), o_ppq = carve((size_t)kNumCh * kNumChunks * n);
   const size_t o_head = carve(8 + c->proof_len + 2), o_open = carve(2 * n_open), o_chal = carve(8), o_kis = carve(kNumRouted);
   const size_t o_vals = carve(c->n_slots), o_set = carve((c->n_slots + 1) / 2);
-  c->init_cap = c->const_inits.size() + n_targets + 12 * kHostChainCap;  // (+ the outputs of the host-evaluated PoseidonGate rows)
+  c->init_cap = c->const_inits.size() + n_targets + 12 * kHostChainCap + kHostChainArithCap;  // (+ the outputs of the host-evaluated PoseidonGate rows)
   const size_t o_init = carve(2 * c->init_cap);
   const size_t o_wslot = carve(n * kNumWires + 1), o_pislot = carve((c->n_pi + 2) / 2);
   c->ops_cap = c->gens.size() + (c->has_recursion_gates ? 3 * c->gens.size() + 8192 : 0);  // room for the schedule's padding records
@@ -2954,7 +2979,7 @@ extern "C" int p2mt_circuit_schedule_info(const p2mt_circuit_data* c, uint32_t* 
   if (!c || !n_levels || !host_rows) return p2mt::fail(P2MT_EINVAL, "null pointer");
   if (!c->sched_valid) return p2mt::fail(P2MT_EINVAL, "no schedule yet: prove once first");
   *n_levels = c->n_levels;
-  *host_rows = (uint32_t)c->host_chain.size();
+  *host_rows = c->host_rows;
   return P2MT_OK;
   });
 }

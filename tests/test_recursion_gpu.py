@@ -153,7 +153,7 @@ def test_host_evaluated_poseidon_chain_same_proof(pkg, oracle):
     case = mmr_case(oracle, 8, 3)
     gi, pwi, oi, opwi = inner_both(pkg, oracle, case)
     inner_proof = gi.prove(pwi)
-    assert info(gi)[1] == 0  # the inner circuit's chains need swap bits that generators produce: nothing for the host there
+    assert info(gi)[1] == 0  # 3 path elements: a chain of 4 rows is below the threshold
     go, pwo, oo, opwo = outer_both(pkg, oracle, case, gi, oi, inner_proof)
     try:
         a = go.prove(pwo)
