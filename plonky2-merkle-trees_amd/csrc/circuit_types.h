@@ -109,7 +109,14 @@ enum {
   GEN_BASE_SPLIT = 10,    // row
   GEN_RANDOM_ACCESS = 11, // row, i = copy
   GEN_INTERPOLATION = 12, // row
-  GEN_POSEIDON_MDS = 13,  // row
+  GEN_POSEIDON_MDS = 13,  // row, i = output element
+  // The pre-pass of a ReducingGate / ReducingExtensionGate (round 5; not plonky2 generators: they set no wire the gate's own generator
+  // would not set to the same value).  A gate's output is old_acc * alpha^n + H(coefficients): LOCAL computes H and alpha^n without
+  // old_acc (t = 4 virtual targets), COMBINE the output from them -- so a chain of k gates hands its accumulator on after one short
+  // multiplication per gate instead of one n-step Horner chain per gate, while the gates' own generators fill the n - 1 intermediate wires side by side.
+  GEN_REDUCING_LOCAL = 14,      // row; t = H[2], alpha^n[2]
+  GEN_REDUCING_EXT_LOCAL = 15,  // row; t as above
+  GEN_REDUCING_COMBINE = 16,    // row; t as above
   GEN_KINDS
 };
 struct Gen {

@@ -184,6 +184,15 @@ u32 cb_add_gate(p2mt_circuit_builder* b, int kind, u64 c0, u64 c1) {
       g.i = r;
       b->gens.push_back(g);
     }
+    if (gk == GEN_REDUCING || gk == GEN_REDUCING_EXT) {  // the pre-pass (circuit_types.h): four virtual targets between its two halves
+      Gen l{};
+      l.row = row;
+      for (int k = 0; k < 4; ++k) l.t.push_back(cb_virtual(b));
+      l.kind = gk == GEN_REDUCING ? GEN_REDUCING_LOCAL : GEN_REDUCING_EXT_LOCAL;
+      b->gens.push_back(l);
+      l.kind = GEN_REDUCING_COMBINE;
+      b->gens.push_back(l);
+    }
   }
   return row;
 }
@@ -633,6 +642,72 @@ GL_DEV void run_recursion_generator(const Mem& m, const WOp& op, u32 o, const u3
 #pragma unroll
         for (u32 j = 0; j < 2 * kChunk; ++j) cur[j] = nxt[j], os_cur[j] = os_nxt[j];
       }
+      break;
+    }
+    // The pre-pass of the two reducing gates (circuit_types.h): H = Horner(coefficients) from a zero accumulator and alpha^n, without
+    // the gate's old_acc; then output = old_acc * alpha^n + H.  args: LOCAL alpha[2], coefficient words, then H[2], alpha^n[2];
+    // COMBINE old_acc[2], H[2], alpha^n[2], then the output wires.
+    case GEN_REDUCING_LOCAL:
+    case GEN_REDUCING_EXT_LOCAL: {
+      const bool ext = (op.kind & 0xFF) == GEN_REDUCING_EXT_LOCAL;
+      const u32* A = args + op.a;
+      const u32 n = ext ? kReducingExtCoeffs : kReducingCoeffs, words = ext ? 2 * kReducingExtCoeffs : kReducingCoeffs;
+      u32 sl[2] = {A[0], A[1]};
+      u64 al[2];
+      get_many(m, sl, al);
+      const DE a1{al[0], al[1]};
+      const DEFixed alpha = de_fix(a1);
+      constexpr u32 kChunk = 8;  // coefficient words per batch of loads
+      u32 cs[kChunk];
+      u64 cur[kChunk], nxt[kChunk];
+      auto load = [&](u32 base, u64 (&dst)[kChunk]) {
+#pragma unroll
+        for (u32 j = 0; j < kChunk; ++j) cs[j] = A[2 + (base + j < words ? base + j : words - 1)];
+        get_many(m, cs, dst);
+      };
+      DE acc{0, 0};
+      load(0, cur);
+#pragma unroll 1
+      for (u32 base = 0; base < words; base += kChunk) {
+        if (base + kChunk < words) load(base + kChunk, nxt);
+        if (ext) {
+#pragma unroll
+          for (u32 j = 0; j < kChunk; j += 2)
+            if (base + j < words) acc = de_add(de_mul_fixed(acc, alpha), DE{cur[j], cur[j + 1]});
+        } else {
+#pragma unroll
+          for (u32 j = 0; j < kChunk; ++j)
+            if (base + j < words) {
+              acc = de_mul_fixed(acc, alpha);
+              acc.a = gl::add(acc.a, cur[j]);
+            }
+        }
+#pragma unroll
+        for (u32 j = 0; j < kChunk; ++j) cur[j] = nxt[j];
+      }
+      DE pw{1, 0}, sq = a1;  // alpha^n, n = 43 or 32
+#pragma unroll 1
+      for (u32 e = n; e; e >>= 1) {
+        if (e & 1) pw = de_mul(pw, sq);
+        sq = de_mul(sq, sq);
+      }
+      const u32* O = A + 2 + words;
+      put_out(m, O[0], acc.a, fr.at(0), err, o);
+      put_out(m, O[1], acc.b, fr.at(1), err, o);
+      put_out(m, O[2], pw.a, fr.at(2), err, o);
+      put_out(m, O[3], pw.b, fr.at(3), err, o);
+      break;
+    }
+    case GEN_REDUCING_COMBINE: {
+      const u32* A = args + op.a;
+      u32 sl[6], os[2] = {A[6], A[7]};
+      u64 in[6];
+#pragma unroll
+      for (u32 i = 0; i < 6; ++i) sl[i] = A[i];
+      get_many(m, sl, in);
+      const DE r = de_add(de_mul(DE{in[0], in[1]}, DE{in[4], in[5]}), DE{in[2], in[3]});
+      put_out(m, os[0], r.a, fr.at(0), err, o);
+      put_out(m, os[1], r.b, fr.at(1), err, o);
       break;
     }
     case GEN_WIRE_SPLIT: {  // args: integer, then the sum wires of the BaseSumGates, low limbs first
@@ -1447,16 +1522,36 @@ void gen_targets(const Gen& g, std::vector<u64>& ins, std::vector<u64>& outs) {
       ins.assign(g.t.begin(), g.t.begin() + 4);
       outs.assign(g.t.begin() + 4, g.t.begin() + 6);
       break;
+    // (The two reducing generators list their OUTPUT wires among the inputs: the pre-pass's COMBINE is the first writer of those,
+    // as early as old_acc allows, and the gate's own generator -- which fills the n - 1 intermediate accumulators -- re-derives
+    // them at its end and compares.  Without this the scheduler, which orders by dependency depth, makes the one-level Horner
+    // chain the first writer and the two-level pre-pass the check.)
     case GEN_REDUCING:
+      ins = {W(0), W(1)};
       for (u32 k = 2; k < 6 + kReducingCoeffs; ++k) ins.push_back(W(k));
       outs = {W(0), W(1)};
       for (u32 k = 0; k + 1 < kReducingCoeffs; ++k) outs.push_back(W(6 + kReducingCoeffs + 2 * k)), outs.push_back(W(7 + kReducingCoeffs + 2 * k));
       break;
     case GEN_REDUCING_EXT:
+      ins = {W(0), W(1)};
       for (u32 k = 2; k < 6 + 2 * kReducingExtCoeffs; ++k) ins.push_back(W(k));
       outs = {W(0), W(1)};
       for (u32 k = 0; k + 1 < kReducingExtCoeffs; ++k)
         outs.push_back(W(6 + 2 * kReducingExtCoeffs + 2 * k)), outs.push_back(W(7 + 2 * kReducingExtCoeffs + 2 * k));
+      break;
+    case GEN_REDUCING_LOCAL:
+      ins = {W(2), W(3)};
+      for (u32 k = 0; k < kReducingCoeffs; ++k) ins.push_back(W(6 + k));
+      outs = g.t;
+      break;
+    case GEN_REDUCING_EXT_LOCAL:
+      ins = {W(2), W(3)};
+      for (u32 k = 0; k < 2 * kReducingExtCoeffs; ++k) ins.push_back(W(6 + k));
+      outs = g.t;
+      break;
+    case GEN_REDUCING_COMBINE:
+      ins = {W(4), W(5), g.t[0], g.t[1], g.t[2], g.t[3]};
+      outs = {W(0), W(1)};
       break;
     case GEN_WIRE_SPLIT:
       ins.push_back(g.t[0]);
@@ -1722,6 +1817,9 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots, bool hos
         break;
       case GEN_QUOTIENT_EXT:
       case GEN_WIRE_SPLIT:
+      case GEN_REDUCING_LOCAL:
+      case GEN_REDUCING_EXT_LOCAL:
+      case GEN_REDUCING_COMBINE:
         op.a = (u32)args.size();
         op.b = io_off[gi + 1] - io_off[gi];
         args.insert(args.end(), in, in + op.b);
@@ -1752,6 +1850,8 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots, bool hos
       case GEN_BASE_SPLIT: return 6;
       case GEN_WIRE_SPLIT: return 7;
       case GEN_RANDOM_ACCESS: return 8;
+      case GEN_REDUCING_LOCAL: return 9;
+      case GEN_REDUCING_EXT_LOCAL: return 10;
       default: return 0;
     }
   };
@@ -1773,7 +1873,7 @@ int schedule(p2mt_circuit_data* c, const std::vector<u32>& input_slots, bool hos
       lvl.push_back(np);
       for (size_t j = k; j < k + np; ++j) ops.push_back(items[j].op);
       const size_t base = ops.size();
-      for (int cls = 0; cls <= 8; ++cls) {
+      for (int cls = 0; cls <= 10; ++cls) {
         bool first = true;
         for (size_t j = k + np; j < k2; ++j) {
           if (weight_class(items[j].op.kind) != cls) continue;
@@ -2380,6 +2480,9 @@ extern "C" int p2mt_cb_build(p2mt_circuit_builder* b, p2mt_circuit_data** out) {
   c->args_cap = 0;
   for (const auto& g : c->gens)
     if (g.kind == GEN_QUOTIENT_EXT || g.kind == GEN_WIRE_SPLIT) c->args_cap += g.t.size();
+    else if (g.kind == GEN_REDUCING_LOCAL) c->args_cap += 2 + kReducingCoeffs + 4;
+    else if (g.kind == GEN_REDUCING_EXT_LOCAL) c->args_cap += 2 + 2 * kReducingExtCoeffs + 4;
+    else if (g.kind == GEN_REDUCING_COMBINE) c->args_cap += 8;
   const size_t o_slot_tab = carve((n * kNumWires + 1) / 2 + 1), o_args = carve(c->args_cap / 2 + 1), o_sync = carve(4);
   const size_t o_q_extra = c->has_recursion_gates ? carve((size_t)(G_KINDS - G_POSEIDON - 1) * kNumCh * big) : 0;
   if (hipMalloc((void**)&c->d_base, words * 8) != hipSuccess) return p2mt::fail(P2MT_ENOMEM, "hipMalloc(circuit) failed");

@@ -51,7 +51,7 @@ kind, level, tick = t[:, 0].astype(int), t[:, 1].astype(int), t[:, 2].astype(np.
 t0 = tick[tick > 0].min()
 us = (tick - t0) / 100.0
 names = ["poseidon", "arith", "equality", "const", "arith_ext", "mul_ext", "quotient_ext", "reducing", "reducing_ext", "wire_split",
-         "base_split", "random_access", "interpolation", "poseidon_mds"]
+         "base_split", "random_access", "interpolation", "poseidon_mds", "reducing_local", "reducing_ext_local", "reducing_combine"]
 print("# generators %d, levels %d, span %.1f us (first to last completion)" % (n.value, level.max() + 1, us.max()))
 print("# level: n_poseidon n_other | first / last completion (us) | last-completing kind")
 prev = 0.0
