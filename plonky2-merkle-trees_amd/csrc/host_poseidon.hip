@@ -158,6 +158,110 @@ void permute_bf(u64 (&s)[12]) { Ops<true>::permute(s); }
 __attribute__((target("bmi2"))) void permute_br_bmi2(u64 (&s)[12]) { Ops<false>::permute(s); }
 __attribute__((target("bmi2"))) void permute_bf_bmi2(u64 (&s)[12]) { Ops<true>::permute(s); }
 
+// ---- the eight FULL rounds on AVX-512, one permutation, the state across the lanes: words 0..7 in one zmm register, 8..11 in the low
+// half of another (upper lanes stay zero).  A transcript is a chain of dependent permutations, so what counts is the latency of ONE;
+// in the scalar code the full rounds are three quarters of it (48 field multiplications for the S-boxes and a 144-term MDS layer per
+// round).  Here a round is: + constants, x^7 as four lane-wise 64 x 64 -> 128 multiplications (four vpmuludq each) with the usual
+// two-correction reduction, and the circulant MDS layer as twelve lane rotations (vpermt2q) times small constants on 32-bit halves,
+// folded once.  Values between steps are any u64 representative, as in the scalar code.  The 22 partial rounds stay scalar (one
+// S-box and a dot product per round: nothing for eight lanes).  Used when the CPU has it and the timing below says it is faster.
+#if defined(__x86_64__)
+}  // namespace
+}  // namespace host_poseidon
+#include <immintrin.h>
+namespace host_poseidon {
+namespace {
+#define HP_V512 __attribute__((target("avx512f,avx512dq,avx512vl,bmi2")))
+#define HP_VINLINE static inline __attribute__((always_inline)) HP_V512
+namespace v512 {
+typedef __m512i V;
+HP_VINLINE V eps() { return _mm512_set1_epi64(0xFFFFFFFFll); }
+HP_VINLINE V shr32(V a) { return _mm512_srli_epi64(a, 32); }
+HP_VINLINE V shl32(V a) { return _mm512_slli_epi64(a, 32); }
+HP_VINLINE V add_canon(V a, V c) {  // a any u64, c canonical
+  const V t = _mm512_add_epi64(a, c);
+  return _mm512_mask_add_epi64(t, _mm512_cmplt_epu64_mask(t, a), t, eps());
+}
+HP_VINLINE V red128(V lo, V hi) {  // lo + hi 2^64 -> any u64 congruent (2^64 = 2^32 - 1, 2^96 = -1)
+  const V hh = shr32(hi), hl = _mm512_and_si512(hi, eps());
+  V t0 = _mm512_sub_epi64(lo, hh);
+  t0 = _mm512_mask_sub_epi64(t0, _mm512_cmplt_epu64_mask(lo, hh), t0, eps());
+  const V t1 = _mm512_sub_epi64(shl32(hl), hl);
+  const V t2 = _mm512_add_epi64(t0, t1);
+  return _mm512_mask_add_epi64(t2, _mm512_cmplt_epu64_mask(t2, t1), t2, eps());
+}
+HP_VINLINE V mul(V a, V b) {
+  const V ah = shr32(a), bh = shr32(b);
+  const V ll = _mm512_mul_epu32(a, b), lh = _mm512_mul_epu32(a, bh), hl = _mm512_mul_epu32(ah, b), hh = _mm512_mul_epu32(ah, bh);
+  const V mid = _mm512_add_epi64(lh, shr32(ll));
+  const V mid2 = _mm512_add_epi64(hl, _mm512_and_si512(mid, eps()));
+  const V lo = _mm512_add_epi64(ll, shl32(_mm512_add_epi64(lh, hl)));
+  const V hi = _mm512_add_epi64(hh, _mm512_add_epi64(shr32(mid), shr32(mid2)));
+  return red128(lo, hi);
+}
+HP_VINLINE V pow7(V x) {
+  const V x2 = mul(x, x), x3 = mul(x2, x), x4 = mul(x2, x2);
+  return mul(x3, x4);
+}
+// lane i of output register A is word i, of B word 8 + i; source index for rotation j: word (w + j) mod 12, which is lane w of the
+// (A, B) pair as vpermt2q numbers them (B's lane w - 8 has index w); B's upper output lanes read a zero lane (index 12)
+struct Idx {
+  alignas(64) long long a[12][8], b[12][8];
+  constexpr Idx() : a(), b() {
+    for (int j = 0; j < 12; ++j)
+      for (int i = 0; i < 8; ++i) {
+        a[j][i] = (i + j) % 12;
+        b[j][i] = i < 4 ? (8 + i + j) % 12 : 12;
+      }
+  }
+};
+static const Idx kIdx;
+// sum_j c_j * rot_j(state) on 32-bit halves (every term < 2^38, twelve of them and the diagonal < 2^42), then
+// L + H 2^32 = L + hL 2^32 + hH (2^32 - 1) with H = hH 2^32 + hL
+HP_VINLINE V fold(V L, V H) {
+  const V hL = _mm512_and_si512(H, eps()), hH = shr32(H);
+  const V x = shl32(hL), y = _mm512_add_epi64(L, _mm512_sub_epi64(shl32(hH), hH));
+  const V t = _mm512_add_epi64(x, y);
+  return _mm512_mask_add_epi64(t, _mm512_cmplt_epu64_mask(t, x), t, eps());
+}
+HP_VINLINE void mds(V& a, V& b) {
+  V la = _mm512_setzero_si512(), ha = la, lb = la, hb = la;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const V pa = j ? _mm512_permutex2var_epi64(a, _mm512_load_si512(kIdx.a[j]), b) : a;
+    const V pb = j ? _mm512_permutex2var_epi64(a, _mm512_load_si512(kIdx.b[j]), b) : b;
+    const V c = _mm512_set1_epi64((long long)POSEIDON_MDS_CIRC[j]);
+    la = _mm512_add_epi64(la, _mm512_mul_epu32(pa, c));
+    ha = _mm512_add_epi64(ha, _mm512_mul_epu32(shr32(pa), c));
+    lb = _mm512_add_epi64(lb, _mm512_mul_epu32(pb, c));
+    hb = _mm512_add_epi64(hb, _mm512_mul_epu32(shr32(pb), c));
+  }
+  const V d = _mm512_maskz_set1_epi64(1, (long long)POSEIDON_MDS_DIAG[0]);  // the diagonal is (8, 0, ..., 0)
+  la = _mm512_add_epi64(la, _mm512_mul_epu32(a, d));
+  ha = _mm512_add_epi64(ha, _mm512_mul_epu32(shr32(a), d));
+  a = fold(la, ha);
+  b = fold(lb, hb);
+}
+HP_VINLINE void full_rounds(u64 (&s)[12], int r0) {
+  V a = _mm512_loadu_si512(s), b = _mm512_maskz_loadu_epi64(0x0F, s + 8);
+  for (int r = r0; r < r0 + POSEIDON_HALF_FULL_ROUNDS; ++r) {
+    a = pow7(add_canon(a, _mm512_loadu_si512(POSEIDON_RC + 12 * r)));
+    b = pow7(add_canon(b, _mm512_maskz_loadu_epi64(0x0F, POSEIDON_RC + 12 * r + 8)));
+    mds(a, b);
+  }
+  _mm512_storeu_si512(s, a);
+  _mm512_mask_storeu_epi64(s + 8, 0x0F, b);
+}
+}  // namespace v512
+template <bool BF>
+HP_V512 void permute_v512(u64 (&s)[12]) {
+  v512::full_rounds(s, 0);
+  Ops<BF>::partial_rounds_fast(s);
+  v512::full_rounds(s, POSEIDON_HALF_FULL_ROUNDS + POSEIDON_PARTIAL_ROUNDS);
+  for (int i = 0; i < 12; ++i) s[i] = canon(s[i]);
+}
+#endif
+
 typedef void (*PermuteFn)(u64 (&)[12]);
 double time_chain(PermuteFn fn) {  // seconds per permutation of a dependent chain (what a transcript is)
   u64 s[12] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
@@ -175,12 +279,27 @@ double time_chain(PermuteFn fn) {  // seconds per permutation of a dependent cha
 PermuteFn pick() {
   __builtin_cpu_init();
   const bool bmi2 = __builtin_cpu_supports("bmi2");
-  PermuteFn cand[2] = {bmi2 ? permute_br_bmi2 : permute_br, bmi2 ? permute_bf_bmi2 : permute_bf};
-  if (const char* e = getenv("P2MT_HOST_POSEIDON")) {  // "br" / "bf": pin a spelling (A/B)
+  PermuteFn cand[4] = {bmi2 ? permute_br_bmi2 : permute_br, bmi2 ? permute_bf_bmi2 : permute_bf, nullptr, nullptr};
+#if defined(__x86_64__)
+  if (bmi2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl")) {
+    cand[2] = permute_v512<false>;
+    cand[3] = permute_v512<true>;
+  }
+#endif
+  if (const char* e = getenv("P2MT_HOST_POSEIDON")) {  // "br" / "bf" / "v512br" / "v512bf": pin a variant (A/B, tests)
     if (!strcmp(e, "br")) return cand[0];
     if (!strcmp(e, "bf")) return cand[1];
+    if (!strcmp(e, "v512br") && cand[2]) return cand[2];
+    if (!strcmp(e, "v512bf") && cand[3]) return cand[3];
   }
-  return time_chain(cand[0]) <= time_chain(cand[1]) ? cand[0] : cand[1];
+  PermuteFn best = cand[0];
+  double t_best = time_chain(cand[0]);
+  for (int k = 1; k < 4; ++k) {
+    if (!cand[k]) continue;
+    const double t = time_chain(cand[k]);
+    if (t < t_best) t_best = t, best = cand[k];
+  }
+  return best;
 }
 
 }  // namespace

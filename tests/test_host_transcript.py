@@ -56,3 +56,18 @@ def test_host_challenger_equals_oracle(oracle):
             at += int(n_obs[k])
             exp += [ch.get_challenge() for _ in range(int(n_sq[k]))]
         assert out[:-1].tolist() == [int(x) for x in exp]
+
+
+def test_every_host_permutation_variant_equals_oracle():
+    """The dispatcher times its candidates on the machine it runs on (scalar compare-and-branch / branch-free, and the AVX-512 full
+    rounds where the CPU has them); this pins each in turn (P2MT_HOST_POSEIDON, read once per process) and runs the two tests above."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    for variant in ("br", "bf", "v512br", "v512bf"):  # (the v512 names fall back to the timed choice on a CPU without AVX-512)
+        env = dict(os.environ, P2MT_HOST_POSEIDON=variant)
+        r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-k", "equals_oracle and not every"], env=env,
+                           capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
+        assert r.returncode == 0, (variant, r.stdout[-1500:], r.stderr[-500:])
+        assert "2 passed" in r.stdout, (variant, r.stdout[-500:])
