@@ -1212,6 +1212,11 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     auto grind = [&](u64 base) -> int {
       if (single_queue) {
         const u32 max_blocks = (u32)(chunk / kBlock);
+        // (Measured with tools/grind_probe.py under rocprofv3: this launch takes 56-58 us in an inner prove, ~70 us in an outer one -- the
+        // same code at the clock the heavier prove leaves the chip at -- and 115-140 us in about one launch in five: a wavefront whose
+        // rare-carry flag is set redoes its 64 candidates with the exact permutation, ~70 us on a lone wavefront, and the launch waits
+        // for it.  Which launches those are is a function of the transcript, so a benchmark that proves one statement sees it always
+        // or never.)
         hipLaunchKernelGGL((k_fri_pow_queue<2, 5>), dim3(max_blocks), dim3(kBlock), 0, st, (const ChState*)ch->d,
                            (u32)p->proof_of_work_bits, base, max_blocks, d_wit, (u32*)nullptr, 1u, barg(), p2mt::perm_ctx());
         P2MT_LAUNCH_CHECK();
