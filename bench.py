@@ -808,8 +808,11 @@ def run_prove(args, torch, pkg, lib, cpu_seconds=10.0):
                        "achieved": 1e6 / perm_us, "peak": peak_perms, "unit": "wave-permutations/s per wavefront",
                        "frac": (1e6 / perm_us) / peak_perms, "traffic": None, "kernel": "k_challenger (permute_wave)",
                        "us_per_permutation": perm_us, "permutations_timed": 1024,
-                       "note": "a 64-row proof chains ~180 wave-permutations (transcript 106, witness 21, leaf sponges 22, "
-                               "Merkle levels ~20, FRI ~10) plus ~30 small launches; per-kernel split in profiles/"}
+                       "note": "this is the DEVICE transcript's permutation (what the batched passes run); a single prove keeps its "
+                               "transcript (~110 permutations) and its witness's PoseidonGate chain (41 rows) on a host core "
+                               "(csrc/host_poseidon.hip, 0.86 us per permutation with AVX-512) and chains ~60 wave-permutations on the "
+                               "device (leaf sponges 22, Merkle levels ~20, FRI ~10) plus ~40 small launches; per-kernel split in "
+                               "profiles/r05_prove_timeline_d6_hostchain.txt"}
     acc, reason = C.c_int(0), C.c_int(0)
     Nn.check(lib.p2mt_circuit_verify(cd._h, Nn.ptr(proof), proof.size, C.byref(acc), C.byref(reason)))
     assert acc.value == 1, "the product's verifier rejects the product's proof (reason %d)" % reason.value
@@ -1003,8 +1006,8 @@ def run_recursion(args, torch, pkg, lib, cpu_baseline=True):
                            "poseidon_mds"))}},
            "verify_outer_ms": verify_ms, "public_inputs": [int(x) for x in final_proof[-4:]],
            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                        "note": "dependency chains (witness levels, transcript, Merkle levels), not bandwidth: per-kernel split in "
-                                "profiles/r03_prove_timeline_recursion.txt"}}
+                        "note": "dependency chains (witness levels, leaf sponges, Merkle levels, host transcript phases), not bandwidth: "
+                                "per-kernel split in profiles/r05_prove_timeline_recursion_hostchain.txt"}}
     if getattr(args, "workload", "") in ("recursion", "mmr"):
         # throughput through the batched prover (its own process: ~3.7 GB of per-proof blocks per thread at B = 32; four threads so
         # that a pass's one-workgroup witness interpreter and its latency-bound launches overlap the other passes' hashing: 1.46 k /
