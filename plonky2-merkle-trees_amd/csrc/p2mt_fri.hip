@@ -323,9 +323,28 @@ __global__ __launch_bounds__(kBlock, 4) void k_fri_pow_queue(const ChState* __re
           sticky |= cm;
         }
         sticky |= poseidon_fast::permute<false, 12, false, false, false, 3, 2, 0, true, 7>(s, ctx.rc, &mc);
-        if (__builtin_expect(sticky != 0, 0)) {  // flagged wave: the exact reference permutation from the full input
-          load(s);
-          poseidon::permute<poseidon::MDS_MAD64, poseidon::PARTIAL_NAIVE>(s);
+        if (__builtin_expect(sticky != 0, 0)) {
+          // `sticky` is the mask of the LANES whose rare carry fired (each lane is its own hash): redo those candidates only, one
+          // at a time on the 12-lane layout (permute_wave: ~7 us each) -- the exact permutation for all 64 lanes took ~70 us on a
+          // lone wavefront, and about one launch in five waited for such a wavefront (tools/grind_probe.py: 58 -> 115-140 us).
+          const unsigned lane = threadIdx.x & 63;
+          u64 todo = ctx.force_fallback ? ~0ull : sticky;  // (the tests' knob: every lane)
+          while (todo) {                                    // wave-uniform
+            const unsigned fl = (unsigned)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const u64 cf = base + (u64)blk * kBlock + (threadIdx.x & ~63u) + fl;
+            u64 x = 0;
+            if (lane < 12) {
+              x = st->state[lane];
+              if (lane < 8) {
+                if (lane < n_in) x = st->in[lane];
+                else if (lane == n_in) x = cf;
+              }
+            }
+            x = permute_wave(x, ctx);
+            const u64 r7 = __shfl((unsigned long long)x, 7);
+            if (lane == fl) s[7] = r7;
+          }
         }
       } else {
         permute_reloadable<M, PR>(s, ctx, load, &mc);
@@ -1212,11 +1231,10 @@ int p2mt::fri_prove_openings_epilogue_dev(const p2mt_fri_oracle* oracles, size_t
     auto grind = [&](u64 base) -> int {
       if (single_queue) {
         const u32 max_blocks = (u32)(chunk / kBlock);
-        // (Measured with tools/grind_probe.py under rocprofv3: this launch takes 56-58 us in an inner prove, ~70 us in an outer one -- the
-        // same code at the clock the heavier prove leaves the chip at -- and 115-140 us in about one launch in five: a wavefront whose
-        // rare-carry flag is set redoes its 64 candidates with the exact permutation, ~70 us on a lone wavefront, and the launch waits
-        // for it.  Which launches those are is a function of the transcript, so a benchmark that proves one statement sees it always
-        // or never.)
+        // (Measured with tools/grind_probe.py under rocprofv3: this launch takes 56-58 us in an inner prove and ~70 us in an outer one --
+        // the same code at the clock the heavier prove leaves the chip at.  Until round 5 about one launch in five took 115-140 us: a
+        // wavefront whose rare-carry flag was set redid all 64 candidates with the exact permutation, ~70 us on a lone wavefront; it
+        // redoes the flagged lanes only now, 67-76 us.  Which launches those are is a function of the transcript.)
         hipLaunchKernelGGL((k_fri_pow_queue<2, 5>), dim3(max_blocks), dim3(kBlock), 0, st, (const ChState*)ch->d,
                            (u32)p->proof_of_work_bits, base, max_blocks, d_wit, (u32*)nullptr, 1u, barg(), p2mt::perm_ctx());
         P2MT_LAUNCH_CHECK();
