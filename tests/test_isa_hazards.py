@@ -114,7 +114,7 @@ def test_inline_asm_declares_scc_and_vcc_clobbers():
                 seen += 1
                 if '"scc"' not in blk:
                     bad.append((os.path.basename(path), line, "scc", writes_scc[0]))
-            if (re.search(r"\bvcc\b", code) or re.search(r"v_(add|sub|subrev|addc|subb|subbrev)_co_u32_e32", code)) and '"vcc"' not in blk:
+            if (re.search(r"\bvcc\b", code) or re.search(r"v_(add|sub|subrev|addc|subb|subbrev)_co_u32_e32|v_cmpx?_\w+_e32|v_div_scale", code)) and '"vcc"' not in blk:
                 bad.append((os.path.basename(path), line, "vcc", ""))
     assert seen >= 8, seen  # the flag-form field arithmetic is what this is about
     assert not bad, bad
