@@ -911,19 +911,23 @@ __global__ __launch_bounds__(1024) void k_merkle_top(const u64* __restrict__ in,
   const unsigned c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u64* src = in + ((size_t)c << log_sub) * 4;
   size_t lvl_off = 0;  // offset of level t in `next`, in nodes
+  // four nodes per wavefront (one per 16-lane row, permute_wave4): the 16 nodes of the first level take four wavefronts -- one per
+  // SIMD of the CU -- instead of sixteen sharing them
+  const unsigned rl = lane & 15, row = lane >> 4;
   for (unsigned t = 1; t <= log_sub; ++t) {
     const unsigned cnt = 1u << (log_sub - t);
-    if (wave < cnt) {
+    if (4 * wave < cnt) {  // wave-uniform
+      const unsigned node = 4 * wave + row;
       u64 x = 0;
-      if (lane < 8) {
-        const unsigned child = 2 * wave + (lane >> 2), word = lane & 3;
+      if (rl < 8 && node < cnt) {
+        const unsigned child = 2 * node + (rl >> 2), word = rl & 3;
         x = t == 1 ? src[4 * child + word] : buf[t & 1][child][word];
       }
-      x = gl::canon(p2mt_dev::permute_wave(x, ctx));
-      if (lane < 4) {
-        buf[(t + 1) & 1][wave][lane] = x;
-        if (t == log_sub) cap[4 * (size_t)c + lane] = x;
-        else if (next) next[4 * (lvl_off + ((size_t)c << (log_sub - t)) + wave) + lane] = x;
+      x = gl::canon(p2mt_dev::permute_wave4(x, ctx));
+      if (rl < 4 && node < cnt) {
+        buf[(t + 1) & 1][node][rl] = x;
+        if (t == log_sub) cap[4 * (size_t)c + rl] = x;
+        else if (next) next[4 * (lvl_off + ((size_t)c << (log_sub - t)) + node) + rl] = x;
       }
     }
     lvl_off += n_in >> t;

@@ -298,9 +298,9 @@ __global__ __launch_bounds__(kBlock) void k_merkle_level_wave(const u64* __restr
   out = bp(out, ba);
   __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
-  const size_t j = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (j >= n_out) return;  // wave-uniform
-  two_to_one_wave(in + 8 * j, in + 8 * j + 4, out + 4 * j, ctx);
+  const size_t j0 = 4 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));  // four nodes per wavefront, one per 16-lane row
+  if (j0 >= n_out) return;  // wave-uniform
+  two_to_one_wave4(in, out, j0, n_out, ctx);
 }
 
 __global__ __launch_bounds__(kBlock) void k_merkle_level_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out,
@@ -337,8 +337,8 @@ int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, 
 int launch_merkle_level_dev(const u64* d_in, u64* d_out, size_t n_out) {
   if (n_out == 0) return P2MT_OK;
   const size_t n_all = n_out * p2mt::batch_B();
-  if (n_all <= ((size_t)1 << 12) && rt().mds == 2 && !(rt().throughput && n_all > 16)) {  // small level: one wavefront per node (latency path)
-    const unsigned per_block = kBlock / 64;
+  if (n_all <= ((size_t)1 << 13) && rt().mds == 2 && !(rt().throughput && n_all > 16)) {  // small level: four nodes per wavefront on the 12-lane layout (latency path)
+    const unsigned per_block = 4 * (kBlock / 64);
     hipLaunchKernelGGL(k_merkle_level_wave, bgrid((unsigned)((n_out + per_block - 1) / per_block)), dim3(kBlock), 0,
                        rt().stream, d_in, d_out, n_out, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();

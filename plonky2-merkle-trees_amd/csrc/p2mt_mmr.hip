@@ -224,10 +224,17 @@ __global__ __launch_bounds__(kBlock) void k_mmr_level_wave(u64* __restrict__ ele
                                                            PermCtx ctx) {
   __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
-  const size_t j = j0 + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (j >= j1) return;  // wave-uniform
-  const size_t pos = node_pos(((j + 1) << h) - 1, h);
-  two_to_one_wave(elements + 4 * (pos - ((size_t)1 << h)), elements + 4 * (pos - 1), elements + 4 * pos, ctx);
+  // four nodes per wavefront, one per 16-lane row (tree_common.hip.h permute_wave4)
+  const size_t jw = j0 + 4 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+  if (jw >= j1) return;  // wave-uniform
+  const unsigned rl = threadIdx.x & 15, row = (threadIdx.x >> 4) & 3;
+  const size_t j = jw + row;
+  const bool live = j < j1;
+  const size_t pos = node_pos((((live ? j : jw) + 1) << h) - 1, h);
+  u64 x = 0;
+  if (live && rl < 8) x = rl < 4 ? elements[4 * (pos - ((size_t)1 << h)) + rl] : elements[4 * (pos - 1) + (rl - 4)];
+  x = permute_wave4(x, ctx);
+  if (live && rl < 4) elements[4 * pos + rl] = gl::canon(x);
 }
 
 __global__ __launch_bounds__(kBlock) void k_mmr_level_quad(u64* __restrict__ elements, unsigned h, size_t j0, size_t j1,
@@ -607,7 +614,7 @@ extern "C" int p2mt_mmr_flush(p2mt_mmr* m) {
 
 // one level over [j0, j1) of height h: one wavefront per node while the level is small (latency-bound), one
 // lane per node otherwise
-constexpr size_t kWavePerNodeMax = (size_t)1 << 12;  // measured crossover vs the lane-per-node kernel: ~2^13 nodes
+constexpr size_t kWavePerNodeMax = (size_t)1 << 13;  // four nodes per wavefront (permute_wave4): 2^13 nodes are two wavefronts per SIMD
 constexpr size_t kMinTilesPerStage = 2048;
 // stage 1 at four waves per SIMD (<= 128 VGPRs, 28 bytes of scratch) instead of the three the allocator settles for on its own
 // (136 VGPRs); env P2MT_SUBTREE_OCC=3 selects the latter, for A/B
@@ -632,7 +639,7 @@ static int launch_level(p2mt_mmr* m, unsigned h, size_t j0, size_t j1) {
   if (j1 <= j0) return P2MT_OK;
   const size_t cnt = j1 - j0;
   if (cnt <= kWavePerNodeMax && rt().mds == 2) {
-    const unsigned per_block = kBlock / 64;
+    const unsigned per_block = 4 * (kBlock / 64);
     hipLaunchKernelGGL(k_mmr_level_wave, dim3((unsigned)((cnt + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
                        m->elements, h, j0, j1, p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();

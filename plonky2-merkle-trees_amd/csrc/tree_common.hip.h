@@ -156,9 +156,11 @@ template <int C>
 GL_DEV u64 row_bcast64(u64 v) {
   return (u64)__builtin_amdgcn_update_dpp((long long)0, (long long)v, 0x150 + C, 0xf, 0xf, true);
 }
-template <bool EXACT, typename Hook>
+// ROWS4: every 16-lane row of the wavefront holds a state of its own in its lanes 0..11 -- four permutations per call.  Everything
+// below is row-local already (row_newbcast, row_shl), so the only difference is which lane index picks the MDS row and the constants.
+template <bool EXACT, bool ROWS4 = false, typename Hook>
 GL_DEV u64 permute_wave_impl(u64 x, const PermCtx& ctx, Hook&& hook, u64& sticky) {
-  const unsigned lane = threadIdx.x & 63;
+  const unsigned lane = ROWS4 ? (threadIdx.x & 15) : (threadIdx.x & 63);
   const unsigned w = lane < 12 ? lane : 0;
   u32 kk[12];  // this lane's MDS row: MDS[w][c] = CIRC[(c - w) mod 12] (+8 at [0][0]), picked out of two packed
                // immediates (bytes 17,15,41,16,2,28,13,13 | 39,18,34,20) instead of a per-lane table load
@@ -272,6 +274,24 @@ GL_DEV u64 permute_wave_hook(u64 x, const PermCtx& ctx, Hook&& hook) {
 }
 GL_DEV u64 permute_wave(u64 x, const PermCtx& ctx) {
   return permute_wave_hook(x, ctx, [](int, u64) {});
+}
+// four states per wavefront (one per 16-lane row): same instructions, same latency, a quarter of the wavefronts -- a tree level of a
+// few thousand nodes then runs at one wavefront per SIMD instead of four sharing it
+GL_DEV u64 permute_wave4(u64 x, const PermCtx& ctx) {
+  auto nohook = [](int, u64) {};
+  u64 sticky = ctx.force_fallback;
+  const u64 y = permute_wave_impl<false, true>(x, ctx, nohook, sticky);
+  if (__builtin_expect(sticky != 0, 0)) return permute_wave_impl<true, true>(x, ctx, nohook, sticky);
+  return y;
+}
+// out[4 j ..) = two_to_one(in[8 j .. 8 j + 4), in[8 j + 4 .. 8 j + 8)) for the four nodes j = j0 + row of the calling wave (all 64 lanes
+// call it; rows whose node is >= n_out compute on zeros and store nothing)
+GL_DEV void two_to_one_wave4(const u64* __restrict__ in, u64* __restrict__ out, size_t j0, size_t n_out, const PermCtx& ctx) {
+  const unsigned rl = threadIdx.x & 15, row = (threadIdx.x >> 4) & 3;
+  const size_t j = j0 + row;
+  u64 x = (rl < 8 && j < n_out) ? in[8 * j + rl] : 0;
+  x = permute_wave4(x, ctx);
+  if (rl < 4 && j < n_out) out[4 * j + rl] = gl::canon(x);
 }
 
 // out[0..4) = two_to_one(lp[0..4), rp[0..4)) computed by the calling wave (all 64 lanes must call it)
