@@ -75,12 +75,15 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict
   out = bp(out, ba);
   __shared__ u64 rc_lds[kWaveRcWords];
   ctx = stage_round_constants(rc_lds, ctx);
-  const size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (row >= n) return;  // wave-uniform
-  const unsigned lane = threadIdx.x & 63;
-  const u64* r = in + row * len;
+  // four rows per wavefront, one per 16-lane row of it (permute_wave4); `len` is the same for all, so the loop is wave-uniform
+  const size_t row0 = 4 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+  if (row0 >= n) return;  // wave-uniform
+  const unsigned lane = threadIdx.x & 15;
+  const size_t row = row0 + ((threadIdx.x >> 4) & 3);
+  const bool live = row < n;
+  const u64* r = in + (live ? row : row0) * len;
   if (noop_short && len <= 4) {
-    if (lane < 4) out[4 * row + lane] = lane < len ? gl::canon(r[lane]) : 0;
+    if (live && lane < 4) out[4 * row + lane] = lane < len ? gl::canon(r[lane]) : 0;
     return;
   }
   u64 x = 0;
@@ -89,9 +92,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_rows_wave(const u64* __restrict
   for (size_t off = 0; off < len; off += 8) {
     if (lane < 8 && off + lane < len) x = nx;  // overwrite mode: the other words keep the previous state
     if (lane < 8 && off + 8 + lane < len) nx = r[off + 8 + lane];
-    x = permute_wave(x, ctx);
+    x = permute_wave4(x, ctx);
   }
-  if (lane < 4) out[4 * row + lane] = gl::canon(x);
+  if (live && lane < 4) out[4 * row + lane] = gl::canon(x);
 }
 
 // ---------------------------------------------------------------- PoseidonGate witness rows
@@ -325,7 +328,7 @@ int launch_hash_rows_dev(const u64* d_in, size_t n, size_t len, int noop_short, 
   if (n == 0) return P2MT_OK;
   // (inside a batch of B proofs the layout is chosen for all n B rows of the launch)
   if (n * p2mt::batch_B() <= ((size_t)1 << 12) && rt().mds == 2) {  // small batch: one wavefront per row (latency path)
-    const unsigned per_block = kBlock / 64;
+    const unsigned per_block = 4 * (kBlock / 64);
     hipLaunchKernelGGL(k_hash_rows_wave, bgrid((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0, rt().stream,
                        d_in, n, len, noop_short, d_out, barg(), p2mt::perm_ctx());
     P2MT_LAUNCH_CHECK();
