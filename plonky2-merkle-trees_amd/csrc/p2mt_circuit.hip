@@ -2951,7 +2951,8 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
     P2MT_HIP(hipMemcpyAsync(dv + L.o_proof, proofs, c->proof_len * 8, hipMemcpyHostToDevice, st));
   }
   P2MT_TRY(p2mt::batch_fill(d_flag, 0x7F, 16));  // flag word and result word: "nothing failed / nothing reported yet"
-  P2MT_TRY(p2mt::verify_dev_begin(c->vstreams, dv, dv + L.o_dig, va));
+  const bool host_path = B == 1 && live[0] && host_transcript_on();
+  P2MT_TRY(p2mt::verify_dev_begin(c->vstreams, dv, dv + L.o_dig, va, host_path));
   // from here on kernels are in flight on the side streams: whatever fails below, they are joined before this function returns, so
   // that the next pass on this block does not refill the flag words or the proof under them
   struct JoinSideStreams {
@@ -2961,7 +2962,7 @@ int verify_pass(p2mt_circuit_data* c, u64* dv, p2mt_challenger* ch, size_t strid
       if (armed) p2mt::verify_streams_join(vs);
     }
   } join{c->vstreams};
-  if (B == 1 && live[0] && host_transcript_on()) {
+  if (host_path) {
     // ONE verification: the transcript is a chain of ~100 dependent permutations of words the host already holds -- 6.9 us each on
     // a lone wavefront, ~1.5 us on a host core (host_poseidon.h).  The host derives every challenge while the proof goes up and the
     // row sponges run, sends them up in one small copy, and the three checks that need them run side by side.

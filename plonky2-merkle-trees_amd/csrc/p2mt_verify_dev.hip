@@ -339,8 +339,15 @@ GL_DEV E sbox7(E x) {
 constexpr u32 kMaxTerms = 2 * (1 + 10) + 123;  // num_challenges (1 + num_chunks) + gate constraints, standard_recursion_config
 constexpr int kOpenBlock = 1024;                // 16 wavefronts: 0 Poseidon, 1 permutation + L_0, 2 small gates, 3.. one per other gate
 
+// phase 0: the whole check.  A single verification with the transcript on the host splits it: the gates' unfiltered constraints are
+// functions of the OPENED VALUES alone (no challenge enters them), and replaying the PoseidonGate's 30 rounds over the extension
+// field on twelve lanes is ~100 us of the ~110 -- phase 1 does that part as soon as the proof is on the device, beside the row
+// sponges and the host's transcript, and leaves the constraints in `gcs`; phase 2, behind the challenges, filters and folds them
+// with the powers of alpha, checks the permutation argument and compares with Z_H(zeta) q(zeta) (~10 us).
+constexpr u32 kGcsWords = 2 * p2mt_cb::kMaxGateTypes * p2mt_cb::kNumGateConstraints + 2;  // constraints, then the "bad" word
 __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __restrict__ dv, int* __restrict__ res_ok,
-                                                                const u64* __restrict__ k_is, VerifyDevArgs a, BatchArg ba) {
+                                                                const u64* __restrict__ k_is, VerifyDevArgs a, BatchArg ba,
+                                                                u64* __restrict__ gcs, int phase) {
   dv = bp(dv, ba);
   res_ok = bp(res_ok, ba);
   __shared__ E s_w[p2mt_cb::kNumWires];
@@ -362,8 +369,9 @@ __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __res
   const E zeta{out[3 * nch], out[3 * nch + 1]};
   const u32 n_terms = nch * (1 + num_chunks) + p2mt_cb::kNumGateConstraints;
   for (u32 j = t; j < d.num_wires; j += kOpenBlock) s_w[j] = e_at(wires, j);
-  for (u32 j = t; j < p2mt_cb::kMaxGateTypes * p2mt_cb::kNumGateConstraints; j += kOpenBlock) (&s_cs[0][0])[j] = e_of(0);
-  if (t == 0) s_bad = 0;
+  for (u32 j = t; j < p2mt_cb::kMaxGateTypes * p2mt_cb::kNumGateConstraints; j += kOpenBlock)
+    (&s_cs[0][0])[j] = phase == 2 ? E{gcs[2 * j], gcs[2 * j + 1]} : e_of(0);
+  if (t == 0) s_bad = phase == 2 ? (int)gcs[kGcsWords - 2] : 0;
   __syncthreads();
   E zn = zeta;
   for (u32 i = 0; i < d.degree_bits; ++i) zn = e_mul(zn, zn);
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __res
     }
   }
   if (wave == 0) {
-    if (my_gate >= 0) {
+    if (my_gate >= 0 && phase != 2) {
       // PoseidonGate::eval_unfiltered: the permutation replayed from the opened wires, sponge word = lane (123 constraints)
       E* cs = s_cs[my_gate];
       const bool act = lane < 12;
@@ -425,6 +433,7 @@ __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __res
       if (act) cs[idx + i] = e_sub(s, s_w[12 + i]);
     }
   } else if (wave == 1) {
+    if (phase != 1) {
     // permutation argument: lane (c, q) = one chunk's check; lanes 32 + c: L_0(zeta) (Z_c(zeta) - 1)
     const bool subgroup = e_eq(zn, e_of(1));  // zeta in the subgroup: L_0 / Z_H degenerate (the prover refuses such a zeta)
     if (lane == 0 && subgroup) s_bad = 1;
@@ -445,9 +454,10 @@ __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __res
       const E l0 = e_mul(zh, e_inv(e_scale(e_sub(zeta, e_of(1)), ((u64)1 << d.degree_bits) % gl::P)));
       s_terms[c] = e_mul(l0, e_sub(e_at(zs, c), e_of(1)));
     }
+    }
   } else if (wave == 2) {
-    // the small gates, one lane per constraint
-    for (u32 g = 0; g < d.n_kinds; ++g) {
+    // the small gates, one lane per constraint (phase 2: the public-input hash arrives with the challenges)
+    for (u32 g = 0; phase != 1 && g < d.n_kinds; ++g) {
       const u32 k = d.kind[g];
       if (k == p2mt_cb::G_CONSTANT) {
         if (lane < d.num_constants) s_cs[g][lane] = e_sub(e_at(gc, lane), s_w[lane]);
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __res
                                                          e_mul(s_w[4 * lane + 2], e_at(gc, 1))));
       }
     }
-  } else if (my_gate >= 0 && lane == 0) {
+  } else if (my_gate >= 0 && lane == 0 && phase != 2) {
     // one gate type of the in-circuit verifier, sequentially on one lane (a few hundred extension multiplications)
     E* cs = s_cs[my_gate];
     auto W = [&](int j) { return s_w[j]; };
@@ -478,6 +488,14 @@ __global__ __launch_bounds__(kOpenBlock) void k_verify_openings(const u64* __res
     }
   }
   __syncthreads();
+  if (phase == 1) {  // (workgroup-uniform)
+    for (u32 j = t; j < p2mt_cb::kMaxGateTypes * p2mt_cb::kNumGateConstraints; j += kOpenBlock) {
+      const E v = (&s_cs[0][0])[j];
+      gcs[2 * j] = v.a, gcs[2 * j + 1] = v.b;
+    }
+    if (t == 0) gcs[kGcsWords - 2] = (u64)s_bad;
+    return;
+  }
   // filtered sum per constraint index: sum_g f_g(selector openings) cs_g[j]
   if (t < p2mt_cb::kNumGateConstraints) {
     E acc = e_of(0);
@@ -531,6 +549,8 @@ namespace {
 struct VerifyStreams {
   hipStream_t s_leaf = nullptr, s_open = nullptr;
   hipEvent_t e_proof = nullptr, e_zeta = nullptr, e_leaf = nullptr, e_open = nullptr;
+  u64* d_gcs = nullptr;  // the gates' unfiltered constraints between the two phases of a single verification (k_verify_openings)
+  bool early = false;    // phase 1 is in flight for the verification at hand
 };
 bool args_ok(const VerifyDevArgs& a) {
   const unsigned chunks = (a.d.num_routed + a.d.quotient_degree_factor - 1) / a.d.quotient_degree_factor;
@@ -557,6 +577,11 @@ int p2mt::verify_streams_create(void** out) {
     p2mt::verify_streams_destroy(v);
     return p2mt::fail(P2MT_EHIP, "verify: cannot create streams / events");
   }
+  if (hipMalloc((void**)&v->d_gcs, kGcsWords * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    p2mt::verify_streams_destroy(v);
+    return p2mt::fail(P2MT_ENOMEM, "verify: hipMalloc(gate constraints) failed");
+  }
   *out = v;
   return P2MT_OK;
 }
@@ -567,6 +592,7 @@ void p2mt::verify_streams_destroy(void* p) {
   if (v->s_open) (void)hipStreamDestroy(v->s_open);
   for (hipEvent_t e : {v->e_proof, v->e_zeta, v->e_leaf, v->e_open})
     if (e) (void)hipEventDestroy(e);
+  if (v->d_gcs) (void)hipFree(v->d_gcs);
   delete v;
 }
 
@@ -579,8 +605,9 @@ void p2mt::verify_streams_join(void* p) {
 }
 
 // (1) the proof is on the device: the row sponges start on their own stream
-int p2mt::verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const VerifyDevArgs& a) {
+int p2mt::verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const VerifyDevArgs& a, bool early_gates) {
   VerifyStreams* v = static_cast<VerifyStreams*>(vs);
+  v->early = false;
   if (!args_ok(a)) return p2mt::fail(P2MT_EINVAL, "verify: circuit configuration beyond standard_recursion_config");
   const unsigned n_items = a.fri.num_query_rounds * (4 + a.fri.num_reductions);
   P2MT_HIP(hipEventRecord(v->e_proof, p2mt::rt().stream));
@@ -589,6 +616,12 @@ int p2mt::verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, co
                      d_digests, a, barg(), p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipEventRecord(v->e_leaf, v->s_leaf));
+  if (early_gates) {  // single verification, transcript on the host: the challenge-free part of the vanishing-polynomial check starts now
+    P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_proof, 0));
+    hipLaunchKernelGGL(k_verify_openings, dim3(1), dim3(kOpenBlock), 0, v->s_open, dv, (int*)nullptr, (const u64*)nullptr, a, barg(), v->d_gcs, 1);
+    P2MT_LAUNCH_CHECK();
+    v->early = true;
+  }
   return P2MT_OK;
 }
 // (2) betas, gammas, alphas and zeta are out: the vanishing-polynomial check runs beside the rest of the transcript.
@@ -597,7 +630,7 @@ int p2mt::verify_dev_after_zeta(void* vs, const uint64_t* dv, int* d_res, const 
   VerifyStreams* v = static_cast<VerifyStreams*>(vs);
   P2MT_HIP(hipEventRecord(v->e_zeta, p2mt::rt().stream));
   P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_zeta, 0));
-  hipLaunchKernelGGL(k_verify_openings, bgrid(1), dim3(kOpenBlock), 0, v->s_open, dv, d_res, d_k_is, a, barg());
+  hipLaunchKernelGGL(k_verify_openings, bgrid(1), dim3(kOpenBlock), 0, v->s_open, dv, d_res, d_k_is, a, barg(), (u64*)nullptr, 0);
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipEventRecord(v->e_open, v->s_open));
   return P2MT_OK;
@@ -636,17 +669,20 @@ int p2mt::verify_dev_with_challenges(void* vs, const uint64_t* dv, const uint64_
   hipStream_t st = p2mt::rt().stream;
   const unsigned nq = a.fri.num_query_rounds, n_items = nq * (4 + a.fri.num_reductions);
   P2MT_HIP(hipEventRecord(v->e_zeta, st));  // "the challenges are on the device"
-  P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_zeta, 0));
-  hipLaunchKernelGGL(k_verify_openings, bgrid(1), dim3(kOpenBlock), 0, v->s_open, dv, d_res, d_k_is, a, barg());
+  // the longest of the three first, on the stream the challenges came up on (no event between them): it was the last to be
+  // enqueued and its ~54 us were the tail of a verification
+  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, st, dv, d_res + 1, a, barg());
   P2MT_LAUNCH_CHECK();
-  P2MT_HIP(hipEventRecord(v->e_open, v->s_open));
   P2MT_HIP(hipStreamWaitEvent(v->s_leaf, v->e_zeta, 0));  // (behind k_verify_leaf_digests on that stream)
   hipLaunchKernelGGL(k_verify_paths, bgrid((n_items + kMerkleBlock / 64 - 1) / (kMerkleBlock / 64)), dim3(kMerkleBlock), 0, v->s_leaf, dv,
                      a, d_digests, n_items, d_flag, barg(), p2mt::perm_ctx());
   P2MT_LAUNCH_CHECK();
   P2MT_HIP(hipEventRecord(v->e_leaf, v->s_leaf));
-  hipLaunchKernelGGL(k_verify_fri, bgrid((nq + kFriBlock / 16 - 1) / (kFriBlock / 16)), dim3(kFriBlock), 0, st, dv, d_res + 1, a, barg());
+  P2MT_HIP(hipStreamWaitEvent(v->s_open, v->e_zeta, 0));
+  hipLaunchKernelGGL(k_verify_openings, bgrid(1), dim3(kOpenBlock), 0, v->s_open, dv, d_res, d_k_is, a, barg(), v->d_gcs, v->early ? 2 : 0);
   P2MT_LAUNCH_CHECK();
+  v->early = false;
+  P2MT_HIP(hipEventRecord(v->e_open, v->s_open));
   P2MT_HIP(hipStreamWaitEvent(st, v->e_open, 0));
   P2MT_HIP(hipStreamWaitEvent(st, v->e_leaf, 0));
   return P2MT_OK;

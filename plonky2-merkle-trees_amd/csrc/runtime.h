@@ -244,7 +244,7 @@ struct VerifyDevArgs {
 int verify_streams_create(void** out);
 void verify_streams_destroy(void* vs);
 void verify_streams_join(void* vs);  // host wait for both side streams (error paths)
-int verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const VerifyDevArgs& a);
+int verify_dev_begin(void* vs, const uint64_t* dv, uint64_t* d_digests, const VerifyDevArgs& a, bool early_gates = false);
 int verify_dev_after_zeta(void* vs, const uint64_t* dv, int* d_res, const uint64_t* d_k_is, const VerifyDevArgs& a);
 int verify_dev_finish(void* vs, const uint64_t* dv, void* d_items, const uint64_t* d_digests, int* d_flag, int* d_res,
                       const VerifyDevArgs& a);
